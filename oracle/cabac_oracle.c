@@ -1,0 +1,713 @@
+/*
+ * cabac_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see cabac_oracle.h).
+ *
+ * CPU restatement of the reference CABAC path.  Written from the algorithm, not
+ * copied: tables are generated from the H.264/H.265 definitions (rangeTabLps
+ * ITU-T H.265 Table 9-46, transIdxLps Table 9-45) and cross-checked against the
+ * compiled reference (tests/test_oracle_vs_ref.py).  Citations: /root/reference/.
+ */
+#include "cabac_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Tables
+ * ---------------------------------------------------------------------------------------- */
+
+/* rangeTabLps[state][q], one little-endian dword per state (byte q = column q).
+ * Same numbers as sm_aucLPSTable, CABAC/CABAC_ArithmeticEncoder.cpp:414-480 and its
+ * byte-identical copy CABAC_ArithmeticDecoder.cpp:474-540. */
+static const uint32_t k_lps_row[64] = {
+    0xF0D0B080u, 0xE3C5A780u, 0xD8BB9E80u, 0xCDB2967Bu, 0xC3A98E74u, 0xB9A0876Fu, 0xAF988069u,
+    0xA6907A64u, 0x9E89745Fu, 0x96826E5Au, 0x8E7B6855u, 0x87756351u, 0x806F5E4Du, 0x7A695949u,
+    0x74645545u, 0x6E5F5042u, 0x685A4C3Eu, 0x6356483Bu, 0x5E514538u, 0x594D4135u, 0x55493E33u,
+    0x50453B30u, 0x4C42382Eu, 0x483F352Bu, 0x453B3229u, 0x41383027u, 0x3E362D25u, 0x3B332B23u,
+    0x38302921u, 0x352E2720u, 0x322B251Eu, 0x3029231Du, 0x2D27211Bu, 0x2B251F1Au, 0x29231E18u,
+    0x27211C17u, 0x25201B16u, 0x231E1A15u, 0x211D1814u, 0x1F1B1713u, 0x1E1A1612u, 0x1C191511u,
+    0x1B171410u, 0x1916130Fu, 0x1815120Eu, 0x1714110Eu, 0x1613100Du, 0x15120F0Cu, 0x14110E0Cu,
+    0x13100E0Bu, 0x120F0D0Bu, 0x110F0C0Au, 0x100E0C0Au, 0x0F0D0B09u, 0x0E0C0B09u, 0x0E0C0A08u,
+    0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u,
+    0x02020202u};
+
+/* transIdxLps[state]; state 63 maps to itself (the reference's 128-entry table keeps
+ * packed 126/127 fixed, ContextModel.cpp:156-157). */
+static const uint8_t k_trans_lps[64] = {
+    0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12, 13, 13, 15, 15, 16, 16,
+    18, 18, 19, 19, 21, 21, 22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30,
+    31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63};
+
+uint8_t orc_lps_table(uint32_t state, uint32_t q) {
+  return (uint8_t)(k_lps_row[state & 63] >> (8 * (q & 3)));
+}
+
+/* sm_aucRenormTable (CABAC_ArithmeticEncoder.cpp:482-492): shift that brings an LPS
+ * range back into [256,512); index is lps >> 3.  6 for index 0, else 5 - floor(log2(i)). */
+uint8_t orc_renorm_table(uint32_t i) {
+  i &= 31;
+  if (i == 0) return 6;
+  int lg = 0;
+  while ((i >> (lg + 1)) != 0) lg++;
+  return (uint8_t)(5 - lg);
+}
+
+uint8_t orc_ctx_pack(uint32_t mps, uint32_t state) { return (uint8_t)((state << 1) + mps); }
+
+/* m_aucNextStateMPS (ContextModel.cpp:136-146): state+1, saturating at 62; 63 stays. */
+uint8_t orc_ctx_next_mps(uint8_t p) {
+  uint32_t state = p >> 1, mps = p & 1;
+  if (state < 62) state++;
+  return (uint8_t)((state << 1) | mps);
+}
+
+/* m_aucNextStateLPS (ContextModel.cpp:148-158): transIdxLps, MPS flips only at state 0. */
+uint8_t orc_ctx_next_lps(uint8_t p) {
+  uint32_t state = p >> 1, mps = p & 1;
+  if (state == 0) mps ^= 1;
+  return (uint8_t)((k_trans_lps[state] << 1) | mps);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * p(0) -> state   (CABAC_ContextModelsInit.cpp:124-148)
+ * ---------------------------------------------------------------------------------------- */
+uint8_t orc_p0_to_packed(double p0) {
+  double p_lps;
+  uint32_t mps;
+  if (p0 >= 0.5) { p_lps = 1.0 - p0; mps = 0; }
+  else           { p_lps = p0;       mps = 1; }
+  if (p_lps < 0.01875) p_lps = 0.01875;
+  int state = (int)round(62.0 * log10(2.0 * p_lps) / log10(2.0 * 0.01875));
+  if (state < 0) state = 0;
+  if (state > 62) state = 62;
+  return orc_ctx_pack(mps, (uint32_t)state);
+}
+
+void orc_init_by_prob(const double *p0, int nctx, uint8_t *out) {
+  for (int c = 0; c < nctx; c++) out[c] = orc_p0_to_packed(p0[c]);
+}
+
+void orc_init_by_state(const double *t, int nctx, uint8_t *out) {
+  /* CABAC_ContextModelsInit.cpp:70-74: slot 3c is ignored, 3c+1 = mps, 3c+2 = state */
+  for (int c = 0; c < nctx; c++)
+    out[c] = orc_ctx_pack((uint32_t)t[3 * c + 1], (uint32_t)t[3 * c + 2]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sink  (CABAC_BitstreamFile.cpp:95-151)
+ * ---------------------------------------------------------------------------------------- */
+void orc_sink_init(orc_sink *s, uint8_t *buf, size_t cap) {
+  memset(s, 0, sizeof *s);
+  s->buf = buf;
+  s->cap = cap;
+}
+
+static void sink_put(orc_sink *s, uint32_t byte) {
+  if (s->len < s->cap) s->buf[s->len] = (uint8_t)byte;
+  else s->overflow = 1;
+  s->len++;
+  s->bits_written += 8;
+}
+
+void orc_sink_write(orc_sink *s, uint32_t bits, uint32_t nbits) {
+  uint32_t total = nbits + s->num_held;
+  uint32_t next_held = total & 7;
+  /* the new low-order bits that do not complete a byte, msb-aligned in a byte */
+  uint32_t next_held_bits = (bits << (8 - next_held)) & 0xFF;
+  uint32_t nbytes = total >> 3;
+  if (nbytes == 0) {
+    s->held_bits |= next_held_bits;
+    s->num_held = next_held;
+    return;
+  }
+  /* held bits go in front of the (nbits - next_held) bits that are written now */
+  uint32_t shift_in = (nbits - next_held) & ~7u;
+  uint32_t word = (s->held_bits << shift_in) | (bits >> next_held);
+  for (uint32_t b = nbytes; b-- > 0;) sink_put(s, (word >> (8 * b)) & 0xFF);
+  s->held_bits = next_held_bits;
+  s->num_held = next_held;
+}
+
+void orc_sink_align_zero(orc_sink *s) {
+  if (s->num_held == 0) return;
+  sink_put(s, s->held_bits);
+  s->held_bits = 0;
+  s->num_held = 0;
+}
+
+uint64_t orc_sink_bits(const orc_sink *s) { return s->bits_written + s->num_held; }
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder  (CABAC_ArithmeticEncoder.cpp)
+ * ---------------------------------------------------------------------------------------- */
+void orc_enc_start(orc_encoder *e, uint8_t *buf, size_t cap) {
+  e->low = 0;
+  e->range = 510;
+  e->bits_left = 23;
+  e->num_buffered = 0;
+  e->buffered_byte = 0xFF;
+  e->bins_coded = 0;
+  orc_sink_init(&e->sink, buf, cap);
+}
+
+static orc_counters g_cnt;
+void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof g_cnt); }
+const orc_counters *orc_counters_get(void) { return &g_cnt; }
+
+/* writeOut, :380-412 */
+static void enc_write_out(orc_encoder *e) {
+  uint32_t lead = e->low >> (24 - e->bits_left);
+  e->bits_left += 8;
+  e->low &= 0xFFFFFFFFu >> e->bits_left;
+  g_cnt.writeouts++;
+  if (lead == 0xFF) {
+    e->num_buffered++;
+    g_cnt.ff_leads++;
+    if ((uint64_t)e->num_buffered > g_cnt.max_num_buffered) g_cnt.max_num_buffered = (uint64_t)e->num_buffered;
+    return;
+  }
+  if (e->num_buffered > 0) {
+    uint32_t carry = lead >> 8;
+    g_cnt.carry_resolves += carry;
+    uint32_t byte = e->buffered_byte + carry;
+    e->buffered_byte = lead & 0xFF;
+    orc_sink_write(&e->sink, byte, 8);
+    byte = (0xFF + carry) & 0xFF;
+    while (e->num_buffered > 1) {
+      orc_sink_write(&e->sink, byte, 8);
+      e->num_buffered--;
+    }
+  } else {
+    e->num_buffered = 1;
+    e->buffered_byte = lead;
+  }
+}
+
+static void enc_test_write_out(orc_encoder *e) { /* :369-375 */
+  if (e->bits_left < 12) enc_write_out(e);
+}
+
+void orc_enc_bin(orc_encoder *e, uint32_t bin, uint8_t *ctx) {
+  uint32_t p = *ctx;
+  e->bins_coded++;
+  uint32_t lps = orc_lps_table(p >> 1, (e->range >> 6) & 3);
+  e->range -= lps;
+  if (bin != (p & 1)) {
+    int n = orc_renorm_table(lps >> 3);
+    e->low = (e->low + e->range) << n;
+    e->range = lps << n;
+    *ctx = orc_ctx_next_lps((uint8_t)p);
+    e->bits_left -= n;
+  } else {
+    *ctx = orc_ctx_next_mps((uint8_t)p);
+    if (e->range >= 256) return;
+    e->low <<= 1;
+    e->range <<= 1;
+    e->bits_left--;
+  }
+  enc_test_write_out(e);
+}
+
+void orc_enc_bin_ep(orc_encoder *e, uint32_t bin) {
+  e->bins_coded++;
+  e->low <<= 1;
+  if (bin) e->low += e->range;
+  e->bits_left--;
+  enc_test_write_out(e);
+}
+
+void orc_enc_bins_ep(orc_encoder *e, uint32_t bins, int nbins) {
+  e->bins_coded += (uint32_t)nbins;
+  while (nbins > 8) {
+    nbins -= 8;
+    uint32_t pattern = bins >> nbins;
+    e->low <<= 8;
+    e->low += e->range * pattern;
+    bins -= pattern << nbins;
+    e->bits_left -= 8;
+    enc_test_write_out(e);
+  }
+  e->low <<= nbins;
+  e->low += e->range * bins;
+  e->bits_left -= nbins;
+  enc_test_write_out(e);
+}
+
+void orc_enc_bin_trm(orc_encoder *e, uint32_t bin) {
+  e->bins_coded++;
+  e->range -= 2;
+  if (bin) {
+    e->low += e->range;
+    e->low <<= 7;
+    e->range = 2 << 7;
+    e->bits_left -= 7;
+  } else if (e->range >= 256) {
+    return;
+  } else {
+    e->low <<= 1;
+    e->range <<= 1;
+    e->bits_left--;
+  }
+  enc_test_write_out(e);
+}
+
+void orc_enc_finish(orc_encoder *e) {
+  orc_enc_bin_trm(e, 1);
+  if (e->low >> (32 - e->bits_left)) {
+    g_cnt.finish_carries++;
+    orc_sink_write(&e->sink, e->buffered_byte + 1, 8);
+    while (e->num_buffered > 1) {
+      orc_sink_write(&e->sink, 0x00, 8);
+      e->num_buffered--;
+    }
+    e->low -= 1u << (32 - e->bits_left);
+  } else {
+    if (e->num_buffered > 0) orc_sink_write(&e->sink, e->buffered_byte, 8);
+    while (e->num_buffered > 1) {
+      orc_sink_write(&e->sink, 0xFF, 8);
+      e->num_buffered--;
+    }
+  }
+  orc_sink_write(&e->sink, e->low >> 8, (uint32_t)(24 - e->bits_left));
+  orc_sink_write(&e->sink, 1, 1);
+  orc_sink_align_zero(&e->sink);
+}
+
+size_t orc_enc_bytes(const orc_encoder *e) { return e->sink.len; }
+uint64_t orc_enc_bits(const orc_encoder *e) { return orc_sink_bits(&e->sink); }
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder  (CABAC_ArithmeticDecoder.cpp; byte source = CABAC_BitstreamFile.cpp:153-158)
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t dec_read_byte(orc_decoder *d) {
+  uint32_t b;
+  if (d->pos < d->len) b = d->buf[d->pos];
+  else { b = 0xFF; d->overreads++; } /* fstream::get() at EOF -> (unsigned char)EOF */
+  d->pos++;
+  d->last_byte = b;
+  return b;
+}
+
+void orc_dec_start(orc_decoder *d, const uint8_t *buf, size_t len) {
+  d->buf = buf;
+  d->len = len;
+  d->pos = 0;
+  d->last_byte = 0;
+  d->overreads = 0;
+  d->range = 510;
+  d->bits_needed = -8;
+  d->value = dec_read_byte(d) << 8;
+  d->value |= dec_read_byte(d);
+}
+
+uint32_t orc_dec_bin(orc_decoder *d, uint8_t *ctx) {
+  uint32_t p = *ctx, bin;
+  uint32_t lps = orc_lps_table(p >> 1, (d->range >> 6) - 4);
+  d->range -= lps;
+  uint32_t scaled = d->range << 7;
+  if (d->value < scaled) {
+    bin = p & 1;
+    *ctx = orc_ctx_next_mps((uint8_t)p);
+    if (scaled >= (256u << 7)) return bin;
+    d->range = scaled >> 6;
+    d->value += d->value;
+    if (++d->bits_needed == 0) {
+      d->bits_needed = -8;
+      d->value += dec_read_byte(d);
+    }
+  } else {
+    int n = orc_renorm_table(lps >> 3);
+    d->value = (d->value - scaled) << n;
+    d->range = lps << n;
+    bin = 1 - (p & 1);
+    *ctx = orc_ctx_next_lps((uint8_t)p);
+    d->bits_needed += n;
+    if (d->bits_needed >= 0) {
+      d->value += dec_read_byte(d) << d->bits_needed;
+      d->bits_needed -= 8;
+    }
+  }
+  return bin;
+}
+
+uint32_t orc_dec_bin_ep(orc_decoder *d) {
+  d->value += d->value;
+  if (++d->bits_needed >= 0) {
+    d->bits_needed = -8;
+    d->value += dec_read_byte(d);
+  }
+  uint32_t scaled = d->range << 7;
+  if (d->value >= scaled) {
+    d->value -= scaled;
+    return 1;
+  }
+  return 0;
+}
+
+uint32_t orc_dec_bins_ep(orc_decoder *d, int nbins) {
+  uint32_t bins = 0;
+  while (nbins > 8) {
+    d->value = (d->value << 8) + (dec_read_byte(d) << (8 + d->bits_needed));
+    uint32_t scaled = d->range << 15;
+    for (int i = 0; i < 8; i++) {
+      bins += bins;
+      scaled >>= 1;
+      if (d->value >= scaled) { bins++; d->value -= scaled; }
+    }
+    nbins -= 8;
+  }
+  d->bits_needed += nbins;
+  d->value <<= nbins;
+  if (d->bits_needed >= 0) {
+    d->value += dec_read_byte(d) << d->bits_needed;
+    d->bits_needed -= 8;
+  }
+  uint32_t scaled = d->range << (nbins + 7);
+  for (int i = 0; i < nbins; i++) {
+    bins += bins;
+    scaled >>= 1;
+    if (d->value >= scaled) { bins++; d->value -= scaled; }
+  }
+  return bins;
+}
+
+uint32_t orc_dec_bin_trm(orc_decoder *d) {
+  d->range -= 2;
+  uint32_t scaled = d->range << 7;
+  if (d->value >= scaled) return 1;
+  if (scaled < (256u << 7)) {
+    d->range = scaled >> 6;
+    d->value += d->value;
+    if (++d->bits_needed == 0) {
+      d->bits_needed = -8;
+      d->value += dec_read_byte(d);
+    }
+  }
+  return 0;
+}
+
+uint32_t orc_dec_finish(orc_decoder *d) {
+  uint32_t status = 0;
+  if (orc_dec_bin_trm(d) != 1) status |= 1;
+  if (((d->last_byte << (8 + d->bits_needed)) & 0xFF) != 0x80) status |= 2;
+  if (d->overreads) status |= 4;
+  return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Whole streams and batches
+ * ---------------------------------------------------------------------------------------- */
+size_t orc_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t nbins,
+                         const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
+                         uint64_t *bits_before_finish, uint8_t *ctx_final) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm); /* ContextModel() default, ContextModel.cpp:54 */
+  if (nctx > 0) memcpy(cm, ctx_init, (size_t)nctx);
+  orc_encoder e;
+  orc_enc_start(&e, out, cap);
+  for (uint32_t i = 0; i < nbins; i++) {
+    if (ctx[i] == ORC_BYPASS_CTX) orc_enc_bin_ep(&e, bins[i]);
+    else orc_enc_bin(&e, bins[i], &cm[ctx[i]]);
+  }
+  if (bits_before_finish) *bits_before_finish = orc_sink_bits(&e.sink);
+  orc_enc_finish(&e);
+  if (ctx_final && nctx > 0) memcpy(ctx_final, cm, (size_t)nctx);
+  return e.sink.overflow ? 0 : e.sink.len;
+}
+
+uint32_t orc_decode_stream(const uint8_t *payload, size_t len, const uint8_t *ctx,
+                           uint32_t nbins, const uint8_t *ctx_init, int nctx,
+                           uint8_t *bins_out, uint8_t *ctx_final) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  if (nctx > 0) memcpy(cm, ctx_init, (size_t)nctx);
+  orc_decoder d;
+  orc_dec_start(&d, payload, len);
+  for (uint32_t i = 0; i < nbins; i++) {
+    if (ctx[i] == ORC_BYPASS_CTX) bins_out[i] = (uint8_t)orc_dec_bin_ep(&d);
+    else bins_out[i] = (uint8_t)orc_dec_bin(&d, &cm[ctx[i]]);
+  }
+  if (ctx_final && nctx > 0) memcpy(ctx_final, cm, (size_t)nctx);
+  return orc_dec_finish(&d);
+}
+
+uint64_t orc_encode_batch(const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins,
+                          uint64_t S, uint32_t B, const uint8_t *ctx_init, int nctx,
+                          uint8_t *payload, uint64_t cap, uint64_t *offsets) {
+  uint64_t off = 0;
+  for (uint64_t s = 0; s < S; s++) {
+    uint32_t n = nbins ? nbins[s] : B;
+    offsets[s] = off;
+    size_t len = orc_encode_stream(bins + s * B, ctx + s * B, n, ctx_init, nctx,
+                                   payload + off, (size_t)(cap - off), NULL, NULL);
+    if (len == 0) return (uint64_t)-1;
+    off += len;
+  }
+  offsets[S] = off;
+  return off;
+}
+
+void orc_decode_batch(const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                      const uint32_t *nbins, uint64_t S, uint32_t B, const uint8_t *ctx_init,
+                      int nctx, uint8_t *bins_out, uint32_t *status) {
+  for (uint64_t s = 0; s < S; s++) {
+    uint32_t n = nbins ? nbins[s] : B;
+    uint32_t st = orc_decode_stream(payload + offsets[s], (size_t)(offsets[s + 1] - offsets[s]),
+                                    ctx + s * B, n, ctx_init, nctx, bins_out + s * B, NULL);
+    if (status) status[s] = st;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Binarisation  (cabacBinarizer.m / cabacDebinarizer.m)
+ * ---------------------------------------------------------------------------------------- */
+int orc_binarize_tu(uint32_t v, uint32_t max_val, uint8_t *bins) {
+  /* TUCode, cabacBinarizer.m:30-37: v ones, then a zero unless v == max_val */
+  int n = 0;
+  if (v == max_val) {
+    for (uint32_t i = 0; i < max_val; i++) bins[n++] = 1;
+  } else {
+    for (uint32_t i = 0; i < v; i++) bins[n++] = 1;
+    bins[n++] = 0;
+  }
+  return n;
+}
+
+int orc_binarize_egk(uint32_t v, uint32_t k, uint8_t *bins) {
+  /* EGCode, cabacBinarizer.m:56-69 */
+  uint32_t t = (v >> k) + 1; /* floor(v / 2^k) + 1 ; floor(log2(v/2^k + 1)) == floor(log2(t)) */
+  int lg = 0;
+  while ((t >> (lg + 1)) != 0) lg++;
+  int n_p = lg + 1;
+  int n_s = (int)k + n_p - 1;
+  uint32_t v_s = v - ((((uint32_t)1 << (n_p - 1)) - 1) << k);
+  int n = 0;
+  for (int i = 0; i < n_p - 1; i++) bins[n++] = 1;
+  bins[n++] = 0;
+  for (int i = n_s - 1; i >= 0; i--) bins[n++] = (uint8_t)((v_s >> i) & 1); /* FLCode, :71-75 */
+  return n;
+}
+
+uint32_t orc_debinarize_tu(const uint8_t *bins, int n, uint32_t max_val) {
+  /* rTUCode, cabacDebinarizer.m:28-31 */
+  for (int i = 0; i < n; i++)
+    if (!bins[i]) return (uint32_t)i;
+  return max_val;
+}
+
+uint32_t orc_debinarize_egk(const uint8_t *bins, int n, uint32_t k) {
+  /* rEGCode, cabacDebinarizer.m:46-53 */
+  int n_p = 0;
+  while (n_p < n && bins[n_p]) n_p++;
+  n_p++; /* 1-based index of the first zero */
+  uint32_t suffix = 0;
+  for (int i = n_p; i < n; i++) suffix = (suffix << 1) | bins[i];
+  return ((((uint32_t)1 << (n_p - 1)) - 1) << k) + suffix;
+}
+
+/* incremental end-of-symbol test, cabacDecodeSymbolFinished.m:12-30.
+ * g[n-1] is the bin just decoded (n is 1-based). */
+typedef struct { int n_p, n_s; } sym_state;
+
+static int symbol_finished(const uint8_t *g, int n, uint32_t nq, int method, uint32_t k,
+                           sym_state *st) {
+  if (method == 0) return g[n - 1] == 0 || (uint32_t)n == nq - 1;
+  if (st->n_s == -1) {
+    if (g[n - 1] == 0) {
+      st->n_p += n;
+      st->n_s = (int)k + st->n_p - 1;
+      if (st->n_s == 0) return 1;
+    }
+    return 0;
+  }
+  if (st->n_s == 1) return 1;
+  st->n_s--;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Context selectors
+ * ---------------------------------------------------------------------------------------- */
+static int first_zero_1based(const uint8_t *g, int len) {
+  for (int i = 0; i < len; i++)
+    if (!g[i]) return i + 1;
+  return 0; /* "isempty" */
+}
+
+int orc_iss_ctx(int n, const uint8_t *g_prev, const uint8_t *g_up1, int len_up1,
+                unsigned types, int N) {
+  /* cabacContextSelection.m:24-67 */
+  int np_prev = first_zero_1based(g_prev, n - 1);
+  int prefix_prev = !(np_prev && n > np_prev);
+  int np_up1 = first_zero_1based(g_up1, len_up1);
+  int prefix_up1 = !(np_up1 && n > np_up1);
+  int id;
+  if (prefix_prev) {
+    if (n <= N) {
+      id = n;
+      if (len_up1 >= n && prefix_up1) {
+        if (g_up1[n - 1] == 0 && (types & 1)) id = N + n;
+        else if (g_up1[n - 1] == 1 && (types & 2)) id = 2 * N + n;
+      } else if (n > 1 && g_prev[n - 2] == 1 && (types & 16)) {
+        id = 3 * N + n - 1;
+      }
+    } else {
+      id = 7 * N + 1;
+    }
+  } else {
+    int j = n - np_prev;
+    if (j <= N) {
+      id = 4 * N + j;
+      if (len_up1 >= n && !prefix_up1) {
+        if (g_up1[n - 1] == 0 && (types & 4)) id = 5 * N + j;
+        else if (g_up1[n - 1] == 1 && (types & 8)) id = 6 * N + j;
+      }
+    } else {
+      id = 7 * N + 2;
+    }
+  }
+  return id;
+}
+
+#define ORC_MAX_SYM_BINS 96
+
+static int binarize(uint32_t v, uint32_t nq, int method, uint32_t k, uint8_t *g) {
+  return method == 0 ? orc_binarize_tu(v, nq - 1, g) : orc_binarize_egk(v, k, g);
+}
+
+size_t orc_iss_encode_column(const uint32_t *sym, int rows, uint32_t nq, int method, uint32_t k,
+                             unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
+                             uint8_t *out, size_t cap, uint32_t *nbins_out) {
+  /* one column of the (d, cnt) loops of cabacEncode.m:45-70 */
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  memcpy(cm, ctx_init, (size_t)nctx);
+  uint8_t g[ORC_MAX_SYM_BINS], up[ORC_MAX_SYM_BINS];
+  int len_up = 0;
+  uint32_t total = 0;
+  orc_encoder e;
+  orc_enc_start(&e, out, cap);
+  for (int d = 0; d < rows; d++) {
+    int len = binarize(sym[d], nq, method, k, g);
+    for (int cnt = 1; cnt <= len; cnt++) {
+      int id = orc_iss_ctx(cnt, g, up, len_up, types, nlbp);
+      orc_enc_bin(&e, g[cnt - 1], &cm[id - 1]); /* cabacEncode.m:64 passes id-1 */
+      total++;
+    }
+    memcpy(up, g, (size_t)len);
+    len_up = len;
+  }
+  orc_enc_finish(&e);
+  if (nbins_out) *nbins_out = total;
+  return e.sink.overflow ? 0 : e.sink.len;
+}
+
+uint32_t orc_iss_decode_column(const uint8_t *payload, size_t len, int rows, uint32_t nq,
+                               int method, uint32_t k, unsigned types, int nlbp,
+                               const uint8_t *ctx_init, int nctx, uint32_t *sym_out) {
+  /* one column of cabacDecode.m:29-55 */
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  memcpy(cm, ctx_init, (size_t)nctx);
+  uint8_t g[ORC_MAX_SYM_BINS], up[ORC_MAX_SYM_BINS];
+  int len_up = 0;
+  orc_decoder dec;
+  orc_dec_start(&dec, payload, len);
+  for (int d = 0; d < rows; d++) {
+    sym_state st = {0, -1};
+    int n = 1, done = 0;
+    while (!done && n <= ORC_MAX_SYM_BINS) {
+      int id = orc_iss_ctx(n, g, up, len_up, types, nlbp);
+      g[n - 1] = (uint8_t)orc_dec_bin(&dec, &cm[id - 1]);
+      done = symbol_finished(g, n, nq, method, k, &st);
+      n++;
+    }
+    int glen = n - 1;
+    sym_out[d] = method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
+    memcpy(up, g, (size_t)glen);
+    len_up = glen;
+  }
+  return orc_dec_finish(&dec);
+}
+
+/* cabacDemo.m:113-121 (and :158-166): bin 1 of symbol it>1 uses ctx 1 / 2 when the first bin
+ * of the previous symbol was 1 / 0; everything else uses ctx 0. */
+static int demo_ctx(int n, int have_prev, uint8_t prev_first) {
+  if (n == 1 && have_prev) return prev_first == 1 ? 1 : 2;
+  return 0;
+}
+
+size_t orc_demo_encode(const uint32_t *sym, int nsym, uint32_t nq, const uint8_t *ctx_init,
+                       uint8_t *out, size_t cap, uint32_t *nbins_out) {
+  uint8_t cm[3];
+  memcpy(cm, ctx_init, 3);
+  uint8_t g[ORC_MAX_SYM_BINS], prev_first = 0;
+  uint32_t total = 0;
+  orc_encoder e;
+  orc_enc_start(&e, out, cap);
+  for (int it = 0; it < nsym; it++) {
+    int len = orc_binarize_tu(sym[it], nq - 1, g);
+    for (int n = 1; n <= len; n++) {
+      orc_enc_bin(&e, g[n - 1], &cm[demo_ctx(n, it > 0, prev_first)]);
+      total++;
+    }
+    prev_first = g[0];
+  }
+  orc_enc_finish(&e);
+  if (nbins_out) *nbins_out = total;
+  return e.sink.overflow ? 0 : e.sink.len;
+}
+
+uint32_t orc_demo_decode(const uint8_t *payload, size_t len, int nsym, uint32_t nq,
+                         const uint8_t *ctx_init, uint32_t *sym_out) {
+  uint8_t cm[3];
+  memcpy(cm, ctx_init, 3);
+  uint8_t g[ORC_MAX_SYM_BINS], prev_first = 0;
+  orc_decoder d;
+  orc_dec_start(&d, payload, len);
+  for (int it = 0; it < nsym; it++) {
+    sym_state st = {0, -1};
+    int n = 1, done = 0;
+    while (!done) {
+      g[n - 1] = (uint8_t)orc_dec_bin(&d, &cm[demo_ctx(n, it > 0, prev_first)]);
+      done = symbol_finished(g, n, nq, 0, 0, &st);
+      n++;
+    }
+    sym_out[it] = orc_debinarize_tu(g, n - 1, nq - 1);
+    prev_first = g[0];
+  }
+  return orc_dec_finish(&d);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic generator, SURVEY.md section 8(d)
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t fmix32(uint32_t h) { /* murmur3 finaliser */
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+void orc_synth_fill(uint32_t seed, uint64_t s0, uint64_t nS, uint32_t B, uint32_t C,
+                    int ep_half, uint8_t *bins, uint8_t *ctx) {
+  int pow2 = (C & (C - 1)) == 0;
+  for (uint64_t r = 0; r < nS; r++) {
+    uint32_t s = (uint32_t)(s0 + r);
+    for (uint32_t i = 0; i < B; i++) {
+      uint32_t h = fmix32(seed ^ (s * 0x9E3779B1u) ^ (i * 0x85EBCA77u));
+      uint32_t h2 = fmix32(h + 0x6A09E667u);
+      uint32_t c = pow2 ? (h & (C - 1)) : (((h & 0xFFFFu) * C) >> 16);
+      uint32_t thr = ((2 * c + 1) << 24) / (2 * C);
+      uint8_t bin = (uint8_t)((h2 >> 8) < thr);
+      uint8_t cb = (uint8_t)c;
+      if (ep_half && (h >> 31)) {
+        cb = ORC_BYPASS_CTX;
+        bin = (uint8_t)(h2 & 1);
+      }
+      bins[r * B + i] = bin;
+      ctx[r * B + i] = cb;
+    }
+  }
+}
