@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode round-trip throughput of the batched CABAC engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic bin streams: encode (kernel + offsets
+scan + payload gather) followed by decode, inputs already resident in HBM.  Workload = BASELINE.json
+config 3 (1 Mi streams x 4 Ki bins, 64 contexts, SURVEY.md 8(d) generator) per GPU; with N > 1 every rank
+codes its own shard of the global stream range (streams are independent: no data-path collective,
+"weak" scaling), and the final bitstream gather to rank 0 is timed separately (gather_ms), outside `value`.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longer of the encode / decode
+kernels), its duration measured with HIP events on the launch stream inside the engine; algorithmic bytes
+follow SURVEY.md 8(d): encode reads 2 B/bin and writes P + 8 B/stream, decode reads 1 B/bin + P + 8 B/stream
+and writes 1 B/bin (P = measured payload bytes).  `cpu_baseline` times the real reference classes
+(oracle/_ref, kind "reference") or, where that build is absent, the C restatement (kind "port") on a bounded
+sample of the same workload on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (S, B, C, seed, ep_half)
+    "config3": (1 << 20, 4096, 64, 0xCABAC003, False),
+    "config2": (1 << 16, 1024, 3, 0xCABAC002, False),
+    "config5_per_gpu": (1 << 20, 8192, 64, 0xCABAC005, True),
+}
+
+
+def cpu_baseline(seed, B, C, ep, budget_s):
+    """Reference (or port) round trip on a bounded sample of the same synthetic workload, one host core."""
+    import numpy as np
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    init = np.zeros(C, np.uint8)
+    use_ref = pyoracle.have_reference()
+    ref = pyoracle.Reference() if use_ref else None
+    chunk = 512
+    done, t_enc, t_dec, s0 = 0, 0.0, 0.0, 0
+    port_bins, port_t = 0, 0.0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s:
+        bins, ctx = orc.synth(seed, s0, chunk, B, C, ep)
+        s0 += chunk
+        if use_ref:
+            _tot, te, td = ref.roundtrip_batch(bins, ctx, init, decode=True)
+            t_enc += te
+            t_dec += td
+        else:
+            t0 = time.perf_counter()
+            payload, offsets = orc.encode_batch(bins, ctx, init)
+            t1 = time.perf_counter()
+            dec, status = orc.decode_batch(payload, offsets, ctx, init)
+            t2 = time.perf_counter()
+            assert (dec == bins).all() and (status == 0).all()
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+        done += chunk
+        if use_ref and port_t < budget_s / 4:  # also time the in-memory port, for orientation
+            t0 = time.perf_counter()
+            payload, offsets = orc.encode_batch(bins, ctx, init)
+            orc.decode_batch(payload, offsets, ctx, init)
+            port_t += time.perf_counter() - t0
+            port_bins += chunk * B
+    total_bins = done * B
+    out = {
+        "value": total_bins / (t_enc + t_dec) / 1e9,
+        "unit": "Gbin/s",
+        "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "sample": "%d streams x %d bins of the same generator (seed 0x%X), encode+decode, "
+                  "%s" % (done, B, seed, "reference classes, one scratch file per stream on /dev/shm"
+                          if use_ref else "C restatement, in-memory sink"),
+        "encode_Gbin_s": total_bins / t_enc / 1e9,
+        "decode_Gbin_s": total_bins / t_dec / 1e9,
+    }
+    if port_bins:
+        out["port_in_memory_Gbin_s"] = port_bins / port_t / 1e9
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (debug)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from isscabac_amd import Engine
+    S, B, C, seed, ep = WORKLOADS[args.workload]
+    if args.streams:
+        S = args.streams
+    eng = Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_profiling(True)
+
+    # ---- synthetic inputs, resident in HBM before anything is timed ----------------------------------
+    s0 = rank * S  # this rank's shard of the global stream range
+    bins = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    ctx = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    eng.synth_dev(seed, s0, S, B, B, C, ep, bins.data_ptr(), ctx.data_ptr())
+    init = np.zeros(C, np.uint8)  # (mps 0, state 0) == initByProb(0.5), cabacDemo.m:49
+    cap = S * (B // 8 + B // 16 + 64)  # 1.5 bit/bin: EP-heavy streams stay below ~1.01
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    out = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    status = torch.empty((S,), dtype=torch.int32, device=dev)
+
+    kms = {"encode": [], "scan": [], "gather": [], "decode": []}
+
+    def step(record):
+        total = eng.encode_dev(bins.data_ptr(), ctx.data_ptr(), S, B, B, init, payload.data_ptr(), cap,
+                               offsets.data_ptr())
+        if record:
+            m = eng.last_kernel_ms()
+            for k in ("encode", "scan", "gather"):
+                kms[k].append(m[k])
+        eng.decode_dev(payload.data_ptr(), total, offsets.data_ptr(), ctx.data_ptr(), S, B, B, init, out.data_ptr(),
+                       status.data_ptr())
+        if record:
+            kms["decode"].append(eng.last_kernel_ms()["decode"])
+        return total
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(args.steps):
+        total = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness gate (outside the timed region) ---------------------------------------------------
+    verified = None
+    if not args.no_verify:
+        assert int(status.abs().sum()) == 0, "decoder integrity flags set"
+        assert torch.equal(out, bins), "decoded bins differ from the input"
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
+        off = offsets.cpu().numpy().astype(np.uint64)
+        for s in list(range(0, S, max(1, S // 48))) + [S - 1]:
+            hb, hc = orc.synth(seed, s0 + s, 1, B, C, ep)
+            want = orc.encode_stream(hb[0], hc[0], init)
+            got = payload[int(off[s]):int(off[s + 1])].cpu().numpy()
+            assert got.tobytes() == want.tobytes(), "payload of stream %d differs from the oracle" % s
+        verified = True
+
+    # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
+    gather_ms = None
+    if world > 1:
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([total], dtype=torch.int64, device=dev)
+        fence()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(sizes, mine)
+        hs = sizes.cpu().tolist()
+        if rank == 0:
+            parts = [torch.empty(n, dtype=torch.uint8, device=dev) for n in hs]
+            reqs = [dist.irecv(parts[r], src=r) for r in range(1, world)]
+            for r in reqs:
+                r.wait()
+        else:
+            dist.send(payload[:total], dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        bins_total = float(S) * B * world * args.steps
+        value = bins_total / elapsed / 1e9
+        P = float(total)
+        enc_ms = sum(kms["encode"]) / len(kms["encode"])
+        dec_ms = sum(kms["decode"]) / len(kms["decode"])
+        enc_bytes = 2.0 * S * B + P + 8.0 * S
+        dec_bytes = 2.0 * S * B + P + 8.0 * S
+        if enc_ms >= dec_ms:
+            kname, kbytes, kms_avg = "k_encode", enc_bytes, enc_ms
+        else:
+            kname, kbytes, kms_avg = "k_decode", dec_bytes, dec_ms
+        achieved = kbytes / (kms_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(args.workload, {}).get(kname)
+                if ent and not args.streams:
+                    traffic = ent["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gbin/s encode+decode round-trip, 1M streams x 4K bins; bit-exact vs HM CPU",
+            "value": value,
+            "unit": "Gbin/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d streams x %d bins per GPU, %d contexts%s, SURVEY 8(d) generator seed 0x%X"
+                                   % (args.workload, S, B, C, ", 50% bypass" if ep else "", seed),
+                       "streams_per_gpu": S, "bins_per_stream": B, "contexts": C,
+                       "payload_bytes_per_gpu": int(total), "bits_per_bin": 8.0 * P / (float(S) * B)},
+            "verified_bit_exact": verified,
+            "kernels_ms": {k: (sum(v) / len(v) if v else None) for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": kbytes, "ms_per_launch": kms_avg},
+            "gather_ms": gather_ms,
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(seed, B, C, ep, args.cpu_seconds)
+        elif args.cpu_seconds > 0:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/*
+ * isscabac.h -- C ABI of the MI355X-native batched CABAC engine (libisscabac_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of christianrohlfing/ISScabac: everything below
+ * the reference's MEX gateway (CABAC/SimpleCABACMex.cpp) that touches bins -- the HM-derived
+ * CABAC_ArithmeticEncoder / CABAC_ArithmeticDecoder, ContextModel, CABAC_BitstreamFile and the
+ * context-init half of CABAC_ContextModels -- re-built as HIP kernels for gfx950.  Plain pointers and
+ * sizes only; no torch / MATLAB types.  A thin MEX shim (matlab/SimpleCABACMex.cpp) or any FFI
+ * (ctypes: isscabac_amd/engine.py) binds exactly these symbols; see INTEGRATION.md.
+ *
+ * Citations "ref:" are relative to the reference checkout (/root/reference).
+ *
+ * Conventions
+ *   - A *stream* is one independent CABAC bitstream (the reference: one `class CABAC` handle + one
+ *     file, ref: CABAC/SimpleCABACMex.cpp:69-80).  A *batch* is S streams coded in one call.
+ *   - bins / ctx arrays are stream-major: element i of stream s lives at [s * pitch + i]
+ *     (a MATLAB B x S uint8 matrix, column-major, is exactly this with pitch = B).
+ *     pitch must be a multiple of 16 and the base pointers 16-byte aligned.
+ *   - ctx[i] = context index 0..nctx-1, or ISSCABAC_BYPASS (0xFF) for an equiprobable bin
+ *     (ref: encodeBinEP, CABAC/CABAC_ArithmeticEncoder.cpp:250-270 -- not reachable through the
+ *     reference MEX; additive).
+ *   - ctx_init: nctx packed context states, byte = (state << 1) | mps, i.e. ContextModel::m_ucState
+ *     (ref: CABAC/ContextModel.h:78-80,101); the same initial states are used for every stream of the
+ *     batch, as one reference handle would.  state must be 0..62.
+ *   - payload: tight concatenation of the S bitstreams; stream s occupies
+ *     [offsets[s], offsets[s+1]) -- byte-identical to the file the reference writes for that stream.
+ *   - all calls are synchronous on the given HIP stream: they return after the work has completed
+ *     unless stated otherwise.  A handle is not thread safe; distinct handles are independent.
+ *   - return value: 0 = ok, otherwise an ISSCABAC_ERR_* code; isscabac_last_error() has the text.
+ */
+#ifndef ISSCABAC_H
+#define ISSCABAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISSCABAC_BYPASS 0xFFu
+#define ISSCABAC_MAX_CTX 255
+
+enum {
+  ISSCABAC_OK = 0,
+  ISSCABAC_ERR_ARG = 1,      /* bad argument (null, alignment, range) */
+  ISSCABAC_ERR_HIP = 2,      /* HIP runtime error (no GPU, launch failure, ...) */
+  ISSCABAC_ERR_NOMEM = 3,    /* device allocation failed */
+  ISSCABAC_ERR_CAPACITY = 4, /* caller's payload buffer too small; *total_bytes holds the need */
+  ISSCABAC_ERR_STATE = 5     /* call sequence error on a single-stream handle */
+};
+
+/* decoder integrity flags (per stream), the two asserts of ref: CABAC_ArithmeticDecoder.cpp:78-81
+ * turned into data, plus an end-of-payload over-read flag */
+#define ISSCABAC_ST_NO_TERMINATE 1u
+#define ISSCABAC_ST_BAD_STOP_BIT 2u
+#define ISSCABAC_ST_OVERREAD 4u
+
+typedef struct isscabac_engine isscabac_engine;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * replaces `new CABAC` / never-freed handle of ref: SimpleCABACMex.cpp:149-156 */
+int isscabac_create(int device, isscabac_engine **out);
+void isscabac_destroy(isscabac_engine *e);
+/* e may be NULL: returns the text of the last error of a failed isscabac_create on this thread */
+const char *isscabac_last_error(const isscabac_engine *e);
+int isscabac_abi_version(void);
+/* use this HIP stream (hipStream_t) for all work of the engine; NULL = the engine's own stream */
+int isscabac_set_stream(isscabac_engine *e, void *hip_stream);
+
+/* ---- context initialisation (host side, pure functions) --------------------------------------
+ * ref: CABAC_ContextModels::initContextModelsByP0Prob / xMapProbabilityToState,
+ *      CABAC/CABAC_ContextModelsInit.cpp:82-148 */
+int isscabac_init_by_prob(const double *p0, int nctx, uint8_t *packed_out);
+/* ref: initContextModelsByMpsState, CABAC_ContextModelsInit.cpp:51-80: flat triples
+ * [ctxIdx, mps, state]; ctxIdx is ignored exactly as the reference ignores it */
+int isscabac_init_by_state(const double *triples, int nctx, uint8_t *packed_out);
+
+/* ---- sizing ------------------------------------------------------------------------------------ */
+/* provable upper bound of one stream's bitstream length: ceil((6*nbins + 9) / 8) */
+uint64_t isscabac_stream_bound(uint32_t nbins);
+
+/* ---- batch coding on device-resident buffers (the hot path) ---------------------------------------
+ * replaces the per-bin loop  encodeBin -> CABAC_ArithmeticEncoder::encodeBin -> writeOut ->
+ * CABAC_BitstreamFile::write  (ref: SimpleCABACMex.cpp:210-247, CABAC_ArithmeticEncoder.cpp:113-178,
+ * 369-412, CABAC_BitstreamFile.cpp:95-138) and encodeFinish (ref: :70-105) for S streams at once.
+ *
+ *   d_bins, d_ctx : device, [S * pitch] bytes each
+ *   d_nbins       : device, S x u32 bins actually coded per stream (<= pitch), or NULL => nbins
+ *   d_payload     : device, payload_cap bytes
+ *   d_offsets     : device, (S + 1) x u64
+ *   total_bytes   : host, receives offsets[S] (may be NULL)
+ */
+int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx,
+                              const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                              const uint8_t *ctx_init, int nctx, uint8_t *d_payload,
+                              uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes);
+
+/* replaces decodeStart / decodeBin / decodeFinish (ref: SimpleCABACMex.cpp:280-354,
+ * CABAC_ArithmeticDecoder.cpp:54-190,288-331,423-472) for S streams at once.
+ *   d_bins_out : device, [S * pitch] bytes; bins beyond a stream's count are written as 0
+ *   d_status   : device, S x u32 ISSCABAC_ST_* flags, or NULL
+ *   payload_bytes : offsets[S] (size of the valid part of d_payload) */
+int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
+                              const uint64_t *d_offsets, const uint8_t *d_ctx,
+                              const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                              const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out,
+                              uint32_t *d_status);
+
+/* ---- batch coding on host buffers (what a MEX / FFI caller holding host arrays uses) --------------
+ * same semantics; the engine stages through its own device buffers (H2D, kernels, D2H).
+ * payload_cap in bytes; on ISSCABAC_ERR_CAPACITY nothing is written but *total_bytes is set. */
+int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx,
+                          const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins,
+                          uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                          uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes);
+int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets,
+                          const uint8_t *ctx, const uint32_t *nbins_per_stream, uint64_t S,
+                          uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                          uint8_t *bins_out, uint32_t *status);
+
+/* ---- measurement hooks --------------------------------------------------------------------------- */
+/* when enabled, every batch call brackets each of its kernels with hipEvents on the engine's stream */
+int isscabac_set_profiling(isscabac_engine *e, int enabled);
+/* kernel times of the last batch call in ms: [0] encode kernel, [1] offsets scan, [2] payload gather,
+ * [3] decode kernel; unused entries are 0 */
+int isscabac_last_kernel_ms(const isscabac_engine *e, float ms[4]);
+
+/* synthetic workload generator of SURVEY.md section 8(d) (counter based, identical to
+ * oracle/cabac_oracle.c:orc_synth_fill), filling device buffers for global streams s0 .. s0+S-1 */
+int isscabac_synth_fill_dev(isscabac_engine *e, uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins,
+                            uint32_t pitch, uint32_t nctx, int ep_half, uint8_t *d_bins, uint8_t *d_ctx);
+
+/* raw device memory helpers for callers without their own HIP allocator (MEX shim, tests) */
+int isscabac_dev_alloc(isscabac_engine *e, uint64_t bytes, void **d_ptr);
+int isscabac_dev_free(isscabac_engine *e, void *d_ptr);
+int isscabac_copy_h2d(isscabac_engine *e, void *d_dst, const void *h_src, uint64_t bytes);
+int isscabac_copy_d2h(isscabac_engine *e, void *h_dst, const void *d_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

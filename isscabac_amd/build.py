@@ -1,0 +1,42 @@
+"""Build the HIP engine in-tree: isscabac_amd/lib/libisscabac_hip.so (gfx950 only)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libisscabac_hip.so")
+SOURCES = ["cabac_kernels.hip", "cabac_capi.cpp"]
+HEADERS = ["cabac_lane.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X engine cannot be built on this machine")
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> lib/libisscabac_hip.so.  Cross-compiles without a GPU."""
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,379 @@
+// cabac_capi.cpp -- the C ABI of include/isscabac.h on top of the HIP launchers.
+//
+// Host-side only: argument checking, workspace ownership, staging for host-buffer calls, error text.
+// There is deliberately NO CPU coding path in this library: without a working HIP device every coding
+// call fails with ISSCABAC_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/isscabac.h"
+#include "cabac_internal.h"
+
+using namespace isscabac;
+
+struct isscabac_engine {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
+  std::string err;
+  // engine-owned device scratch, grow-only
+  uint8_t *slots = nullptr;
+  uint64_t slots_bytes = 0;
+  uint32_t *lens = nullptr;
+  uint64_t lens_bytes = 0;
+  void *scan_tmp = nullptr;
+  uint64_t scan_tmp_bytes = 0;
+  // staging for the host-buffer entry points
+  void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[8] = {};
+  bool ev_ready = false;
+  float last_ms[4] = {0, 0, 0, 0};
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(isscabac_engine *e, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf;
+  else g_create_err = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                              \
+  do {                                                                                                \
+    hipError_t _err = (call);                                                                         \
+    if (_err != hipSuccess)                                                                           \
+      return fail(e, _err == hipErrorOutOfMemory ? ISSCABAC_ERR_NOMEM : ISSCABAC_ERR_HIP, "%s: %s", #call, \
+                  hipGetErrorString(_err));                                                           \
+  } while (0)
+
+static int grow(isscabac_engine *e, void **p, uint64_t *have, uint64_t need) {
+  if (*have >= need) return ISSCABAC_OK;
+  if (*p) {
+    HIP_TRY(e, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  HIP_TRY(e, hipMalloc(p, need));
+  *have = need;
+  return ISSCABAC_OK;
+}
+
+extern "C" {
+
+int isscabac_abi_version(void) { return 1; }
+
+int isscabac_create(int device, isscabac_engine **out) {
+  if (!out) return fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_create: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t err = hipGetDeviceCount(&ndev);
+  if (err != hipSuccess || ndev <= 0)
+    return fail(nullptr, ISSCABAC_ERR_HIP, "isscabac_create: no HIP device (%s)", hipGetErrorString(err));
+  if (device < 0 || device >= ndev)
+    return fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_create: device %d out of range (%d devices)", device, ndev);
+  isscabac_engine *e = new isscabac_engine;
+  e->device = device;
+  if ((err = hipSetDevice(device)) != hipSuccess || (err = hipStreamCreate(&e->own_stream)) != hipSuccess) {
+    const int rc = fail(nullptr, ISSCABAC_ERR_HIP, "isscabac_create: %s", hipGetErrorString(err));
+    delete e;
+    return rc;
+  }
+  e->stream = e->own_stream;
+  *out = e;
+  return ISSCABAC_OK;
+}
+
+void isscabac_destroy(isscabac_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  if (e->slots) (void)hipFree(e->slots);
+  if (e->lens) (void)hipFree(e->lens);
+  if (e->scan_tmp) (void)hipFree(e->scan_tmp);
+  for (void *p : e->stage)
+    if (p) (void)hipFree(p);
+  if (e->ev_ready)
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+const char *isscabac_last_error(const isscabac_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int isscabac_set_stream(isscabac_engine *e, void *hip_stream) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+  return ISSCABAC_OK;
+}
+
+// ---- context initialisation ------------------------------------------------------------------------
+// xMapProbabilityToState, ref: CABAC/CABAC_ContextModelsInit.cpp:124-148 (double arithmetic, host)
+static uint8_t p0_to_packed(double p0) {
+  const bool zero_is_mps = p0 >= 0.5;
+  double p_lps = zero_is_mps ? 1.0 - p0 : p0;
+  if (p_lps < 0.01875) p_lps = 0.01875;
+  int state = (int)std::round(62.0 * std::log10(2.0 * p_lps) / std::log10(2.0 * 0.01875));
+  state = state < 0 ? 0 : (state > 62 ? 62 : state);
+  return (uint8_t)((state << 1) | (zero_is_mps ? 0 : 1));
+}
+
+int isscabac_init_by_prob(const double *p0, int nctx, uint8_t *packed_out) {
+  if (!p0 || !packed_out || nctx < 0) return ISSCABAC_ERR_ARG;
+  for (int c = 0; c < nctx; c++) {
+    if (!(p0[c] >= 0.0 && p0[c] <= 1.0)) return ISSCABAC_ERR_ARG;  // the reference asserts, :127
+    packed_out[c] = p0_to_packed(p0[c]);
+  }
+  return ISSCABAC_OK;
+}
+
+int isscabac_init_by_state(const double *triples, int nctx, uint8_t *packed_out) {
+  if (!triples || !packed_out || nctx < 0) return ISSCABAC_ERR_ARG;
+  for (int c = 0; c < nctx; c++) {
+    const unsigned mps = (unsigned)triples[3 * c + 1], state = (unsigned)triples[3 * c + 2];
+    // the reference stores (state << 1) + mps unchecked; state 63 makes its own decoder index out of
+    // bounds (CABAC_ArithmeticDecoder.cpp:94), so anything outside 0..62 / 0..1 is refused here
+    if (mps > 1 || state > 62) return ISSCABAC_ERR_ARG;
+    packed_out[c] = (uint8_t)((state << 1) | mps);
+  }
+  return ISSCABAC_OK;
+}
+
+uint64_t isscabac_stream_bound(uint32_t nbins) { return (6ull * nbins + 9 + 7) / 8; }
+
+// ---- helpers ---------------------------------------------------------------------------------------
+static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t nbins, uint32_t pitch,
+                       const uint8_t *ctx_init, int nctx, BatchShape *sh) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (S == 0) return fail(e, ISSCABAC_ERR_ARG, "%s: S must be > 0", who);
+  if (pitch == 0 || (pitch & 15u)) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) must be a positive multiple of 16", who, pitch);
+  if (nbins > pitch) return fail(e, ISSCABAC_ERR_ARG, "%s: nbins (%u) exceeds pitch (%u)", who, nbins, pitch);
+  if (nctx < 1 || nctx > ISSCABAC_MAX_CTX) return fail(e, ISSCABAC_ERR_ARG, "%s: nctx (%d) must be 1..%d", who, nctx, ISSCABAC_MAX_CTX);
+  if (!ctx_init) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init is null", who);
+  if (S > (1ull << 38)) return fail(e, ISSCABAC_ERR_ARG, "%s: S too large", who);
+  memset(sh, 0, sizeof *sh);
+  sh->S = S;
+  sh->nbins = nbins;
+  sh->pitch = pitch;
+  sh->nctx = (uint32_t)nctx;
+  for (int c = 0; c < nctx; c++) {
+    if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
+    sh->ctx_init[c] = ctx_init[c];
+  }
+  // contexts the caller did not initialise behave like the reference's default ContextModel(): (mps 1, state 0)
+  for (int c = nctx; c < 256; c++) sh->ctx_init[c] = 1;
+  return ISSCABAC_OK;
+}
+
+static bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+static int prof_begin(isscabac_engine *e) {
+  if (!e->profiling) return ISSCABAC_OK;
+  if (!e->ev_ready) {
+    for (hipEvent_t &ev : e->ev) HIP_TRY(e, hipEventCreate(&ev));
+    e->ev_ready = true;
+  }
+  for (float &m : e->last_ms) m = 0;
+  return ISSCABAC_OK;
+}
+#define PROF_MARK(e, i)                                           \
+  do {                                                            \
+    if ((e)->profiling) HIP_TRY(e, hipEventRecord((e)->ev[i], (e)->stream)); \
+  } while (0)
+
+// ---- batch encode, device buffers ---------------------------------------------------------------------
+int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
+                              uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                              uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes) {
+  BatchShape sh;
+  int rc = check_shape(e, "isscabac_encode_batch_dev", S, nbins, pitch, ctx_init, nctx, &sh);
+  if (rc) return rc;
+  if (!d_bins || !d_ctx || !d_payload || !d_offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch_dev: null buffer");
+  if (misaligned(d_bins) || misaligned(d_ctx)) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch_dev: bins/ctx must be 16-byte aligned");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t stride = slot_stride_for(nbins);
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
+  if ((rc = prof_begin(e))) return rc;
+
+  PROF_MARK(e, 0);
+  HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
+  PROF_MARK(e, 1);
+  HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
+  PROF_MARK(e, 2);
+  HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
+  PROF_MARK(e, 3);
+  uint64_t total = 0;
+  HIP_TRY(e, hipMemcpyAsync(&total, d_offsets + S, sizeof total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->profiling) {
+    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[0], e->ev[0], e->ev[1]));
+    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[1], e->ev[1], e->ev[2]));
+    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[2], e->ev[2], e->ev[3]));
+  }
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch_dev: payload needs %llu bytes, capacity is %llu",
+                (unsigned long long)total, (unsigned long long)payload_cap);
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                              const uint8_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                              const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out, uint32_t *d_status) {
+  BatchShape sh;
+  int rc = check_shape(e, "isscabac_decode_batch_dev", S, nbins, pitch, ctx_init, nctx, &sh);
+  if (rc) return rc;
+  if (!d_payload || !d_offsets || !d_ctx || !d_bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: null buffer");
+  if (misaligned(d_ctx) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
+    return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if ((rc = prof_begin(e))) return rc;
+  PROF_MARK(e, 0);
+  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->stream));
+  PROF_MARK(e, 1);
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->profiling) HIP_TRY(e, hipEventElapsedTime(&e->last_ms[3], e->ev[0], e->ev[1]));
+  return ISSCABAC_OK;
+}
+
+// ---- batch coding, host buffers -----------------------------------------------------------------------
+int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                          uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                          uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+  BatchShape sh;
+  int rc = check_shape(e, "isscabac_encode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
+  if (rc) return rc;
+  if (!bins || !ctx || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch: null buffer");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t in_bytes = S * pitch;
+  // worst-case payload on device so that the gather can never overflow; copy back only what is used
+  const uint64_t dev_cap = S * isscabac_stream_bound(nbins);
+  if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;
+  if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], in_bytes))) return rc;
+  if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
+  if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], bins, in_bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx, in_bytes, hipMemcpyHostToDevice, e->stream));
+  if (nbins_per_stream)
+    HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  uint64_t total = 0;
+  rc = isscabac_encode_batch_dev(e, static_cast<uint8_t *>(e->stage[0]), static_cast<uint8_t *>(e->stage[1]),
+                                 nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nbins, pitch, ctx_init,
+                                 nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap, static_cast<uint64_t *>(e->stage[4]),
+                                 &total);
+  if (rc) return rc;
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch: payload needs %llu bytes, capacity is %llu",
+                (unsigned long long)total, (unsigned long long)payload_cap);
+  HIP_TRY(e, hipMemcpyAsync(payload, e->stage[3], total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(offsets, e->stage[4], (S + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                          const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                          const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status) {
+  BatchShape sh;
+  int rc = check_shape(e, "isscabac_decode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
+  if (rc) return rc;
+  if (!payload || !offsets || !ctx || !bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch: null buffer");
+  for (uint64_t s = 0; s < S; s++)
+    if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
+      return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch: offsets not monotone at stream %llu", (unsigned long long)s);
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t in_bytes = S * pitch, total = offsets[S];
+  if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;  // decoded bins
+  if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], in_bytes))) return rc;  // ctx
+  if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
+  if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx, in_bytes, hipMemcpyHostToDevice, e->stream));
+  if (nbins_per_stream)
+    HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[3], payload, total, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[4], offsets, (S + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  rc = isscabac_decode_batch_dev(e, static_cast<uint8_t *>(e->stage[3]), total, static_cast<uint64_t *>(e->stage[4]),
+                                 static_cast<uint8_t *>(e->stage[1]),
+                                 nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nbins, pitch, ctx_init,
+                                 nctx, static_cast<uint8_t *>(e->stage[0]), static_cast<uint32_t *>(e->stage[5]));
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(bins_out, e->stage[0], in_bytes, hipMemcpyDeviceToHost, e->stream));
+  if (status) HIP_TRY(e, hipMemcpyAsync(status, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+// ---- measurement hooks, utilities -----------------------------------------------------------------------
+int isscabac_set_profiling(isscabac_engine *e, int enabled) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  e->profiling = enabled != 0;
+  return ISSCABAC_OK;
+}
+
+int isscabac_last_kernel_ms(const isscabac_engine *e, float ms[4]) {
+  if (!e || !ms) return ISSCABAC_ERR_ARG;
+  for (int i = 0; i < 4; i++) ms[i] = e->last_ms[i];
+  return ISSCABAC_OK;
+}
+
+int isscabac_synth_fill_dev(isscabac_engine *e, uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch,
+                            uint32_t nctx, int ep_half, uint8_t *d_bins, uint8_t *d_ctx) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!d_bins || !d_ctx || S == 0 || pitch == 0 || (pitch & 15u) || nbins > pitch || nctx < 1 || nctx > ISSCABAC_MAX_CTX ||
+      misaligned(d_bins) || misaligned(d_ctx))
+    return fail(e, ISSCABAC_ERR_ARG, "isscabac_synth_fill_dev: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, launch_synth(seed, s0, S, nbins, pitch, nctx, ep_half, d_bins, d_ctx, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_dev_alloc(isscabac_engine *e, uint64_t bytes, void **d_ptr) {
+  if (!e || !d_ptr) return ISSCABAC_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMalloc(d_ptr, bytes ? bytes : 16));
+  return ISSCABAC_OK;
+}
+
+int isscabac_dev_free(isscabac_engine *e, void *d_ptr) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipFree(d_ptr));
+  return ISSCABAC_OK;
+}
+
+int isscabac_copy_h2d(isscabac_engine *e, void *d_dst, const void *h_src, uint64_t bytes) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_copy_d2h(isscabac_engine *e, void *h_dst, const void *d_src, uint64_t bytes) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+}  // extern "C"

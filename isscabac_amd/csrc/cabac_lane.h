@@ -1,0 +1,398 @@
+// cabac_lane.h -- the per-stream (= per-lane) CABAC arithmetic of the MI355X engine.
+//
+// One wavefront lane owns one bitstream, so everything in here is lane-private sequential integer
+// work: no cross-lane traffic, no MFMA.  The functions are written against two small policies so
+// that the very same code is compiled into the HIP kernels (cabac_kernels.hip: context states in LDS
+// or a VGPR, tables through ds_bpermute, bytes to an HBM slot) and into a host harness used by the
+// CPU test-suite (tests/lane_harness.cpp: plain arrays) -- the harness is a test build of THIS code,
+// not a fallback.
+//
+// What is restated (ref: = /root/reference):
+//   enc_bin / enc_bin_ep  CABAC_ArithmeticEncoder::encodeBin / encodeBinEP   ref: CABAC/CABAC_ArithmeticEncoder.cpp:113-178, 250-270
+//   enc_flush / enc_lead  testAndWriteOut / writeOut                         ref: :369-412
+//   enc_finish            encodeBinTrm(1) + finish                           ref: :326-367, :70-105
+//   dec_bin / dec_bin_ep  CABAC_ArithmeticDecoder::decodeBin / decodeBinEP   ref: CABAC/CABAC_ArithmeticDecoder.cpp:87-190, 288-331
+//   dec_finish            decodeBinTrm + finish                              ref: :423-472, :73-85
+//   next_mps / next_lps   ContextModel::updateMPS / updateLPS                ref: CABAC/ContextModel.cpp:107-123,136-158
+//
+// How it differs from the reference's formulation (results are bit-identical):
+//   * encoder `low` is 64 bit wide and bytes are moved out every few bins instead of after every bin
+//     (the byte sequence is the same big number either way); renorm count = clz32(lps)-23 instead of
+//     sm_aucRenormTable (equal for every reachable LPS value, states 0..62);
+//   * decoder keeps up to 16 look-ahead bits in `v` and moves the comparison point (`sh`) instead of
+//     shifting the value and pulling one byte at a time; the MPS/LPS decision only depends on bits the
+//     reference has also read, so every decoded bin is identical.
+#ifndef ISSCABAC_LANE_H
+#define ISSCABAC_LANE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CABAC_HD __host__ __device__ __forceinline__
+#define CABAC_HD_RARE __host__ __device__ __noinline__
+#else
+#define CABAC_HD inline
+#define CABAC_HD_RARE inline
+#endif
+
+namespace isscabac {
+
+constexpr uint32_t kBypass = 0xFFu;
+
+// rangeTabLps (ITU-T H.265 Table 9-46 / H.264 Table 9-44), one dword per state, byte q = column q.
+// Same values as sm_aucLPSTable, ref: CABAC/CABAC_ArithmeticEncoder.cpp:414-480.
+#define ISSCABAC_LPS_ROWS                                                                            \
+  0xF0D0B080u, 0xE3C5A780u, 0xD8BB9E80u, 0xCDB2967Bu, 0xC3A98E74u, 0xB9A0876Fu, 0xAF988069u,         \
+  0xA6907A64u, 0x9E89745Fu, 0x96826E5Au, 0x8E7B6855u, 0x87756351u, 0x806F5E4Du, 0x7A695949u,         \
+  0x74645545u, 0x6E5F5042u, 0x685A4C3Eu, 0x6356483Bu, 0x5E514538u, 0x594D4135u, 0x55493E33u,         \
+  0x50453B30u, 0x4C42382Eu, 0x483F352Bu, 0x453B3229u, 0x41383027u, 0x3E362D25u, 0x3B332B23u,         \
+  0x38302921u, 0x352E2720u, 0x322B251Eu, 0x3029231Du, 0x2D27211Bu, 0x2B251F1Au, 0x29231E18u,         \
+  0x27211C17u, 0x25201B16u, 0x231E1A15u, 0x211D1814u, 0x1F1B1713u, 0x1E1A1612u, 0x1C191511u,         \
+  0x1B171410u, 0x1916130Fu, 0x1815120Eu, 0x1714110Eu, 0x1613100Du, 0x15120F0Cu, 0x14110E0Cu,         \
+  0x13100E0Bu, 0x120F0D0Bu, 0x110F0C0Au, 0x100E0C0Au, 0x0F0D0B09u, 0x0E0C0B09u, 0x0E0C0A08u,         \
+  0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u,         \
+  0x02020202u
+
+// transIdxLps (H.265 Table 9-45), the state part of m_aucNextStateLPS, ref: CABAC/ContextModel.cpp:148-158
+#define ISSCABAC_TRANS_LPS                                                                           \
+  0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, \
+  22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34,    \
+  35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63
+
+CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
+
+// ContextModel::updateMPS: state + 1 saturating at 62 (packed: +2 while p < 124)
+CABAC_HD uint32_t next_mps(uint32_t p) { return p + (p < 124u ? 2u : 0u); }
+// ContextModel::updateLPS: transIdxLps, MPS flips only at state 0
+CABAC_HD uint32_t next_lps(uint32_t p, uint32_t trans_state) {
+  return (trans_state << 1) | ((p & 1u) ^ (p < 2u ? 1u : 0u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder
+// ------------------------------------------------------------------------------------------------
+struct EncCore {
+  uint64_t low;       // W valid bits, a possible carry at bit W
+  uint32_t range;     // 256..510 between bins
+  int32_t W;          // number of valid bits in low  (reference: 32 - m_bitsLeft)
+  uint32_t buffered;  // m_bufferedByte
+  uint32_t nbuf;      // m_numBufferedBytes
+};
+
+CABAC_HD void enc_start(EncCore &e) {  // ref: CABAC_ArithmeticEncoder.cpp:54-68
+  e.low = 0;
+  e.range = 510;
+  e.W = 9;  // bitsLeft = 23
+  e.buffered = 0xFF;
+  e.nbuf = 0;
+}
+
+// States policy: load(ctx) -> packed state, store(ctx, p), lps_row(state), trans_lps(state)
+template <class States>
+CABAC_HD void enc_bin(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
+  const uint32_t p = st.load(ctx);
+  const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t q8 = (e.range >> 3) & 0x18u;  // 8 * ((range >> 6) & 3)
+  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t rmps = e.range - lps;
+  const bool is_lps = ((bin ^ p) & 1u) != 0;
+  const uint32_t n_lps = clz32(lps) - 23u;       // == sm_aucRenormTable[lps >> 3] for lps in 6..240
+  const uint32_t n_mps = (rmps >> 8) ^ 1u;       // 1 iff rmps < 256
+  const uint32_t n = is_lps ? n_lps : n_mps;
+  e.low = (e.low + (is_lps ? rmps : 0u)) << n;
+  e.range = (is_lps ? lps : rmps) << n;
+  e.W += (int32_t)n;
+  const uint32_t tr = st.trans_lps(p >> 1);  // unconditional: the lookup may be a cross-lane op
+  st.store(ctx, is_lps ? next_lps(p, tr) : next_mps(p));
+}
+
+// context-coded or bypass bin in one branch-free step (ctx == kBypass selects encodeBinEP); lets a wave
+// whose lanes mix both kinds stay convergent
+template <class States>
+CABAC_HD void enc_bin_any(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
+  const bool ep = ctx == kBypass;
+  const uint32_t c = ep ? 0u : ctx;
+  const uint32_t p = st.load(c);
+  const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t q8 = (e.range >> 3) & 0x18u;
+  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t rmps = e.range - lps;
+  const bool is_lps = !ep && (((bin ^ p) & 1u) != 0);
+  const uint32_t n_lps = clz32(lps) - 23u;
+  const uint32_t n_mps = (rmps >> 8) ^ 1u;
+  const uint32_t n = ep ? 1u : (is_lps ? n_lps : n_mps);
+  e.low = ((e.low + (is_lps ? rmps : 0u)) << n) + ((ep && bin) ? e.range : 0u);
+  e.range = ep ? e.range : ((is_lps ? lps : rmps) << n);
+  e.W += (int32_t)n;
+  const uint32_t tr = st.trans_lps(p >> 1);
+  st.store(c, ep ? p : (is_lps ? next_lps(p, tr) : next_mps(p)));
+}
+
+CABAC_HD void enc_bin_ep(EncCore &e, uint32_t bin) {  // ref: :250-270
+  e.low = (e.low << 1) + (bin ? e.range : 0u);
+  e.W += 1;
+}
+
+// one 9-bit lead value through the outstanding-byte logic of writeOut, ref: :388-411
+template <class Sink>
+CABAC_HD void enc_lead(EncCore &e, uint32_t lead, Sink &out) {
+  if (lead == 0xFFu) {
+    e.nbuf++;
+  } else if (e.nbuf > 0) {
+    const uint32_t carry = lead >> 8;
+    out.put((e.buffered + carry) & 0xFFu);
+    const uint32_t fill = (0xFFu + carry) & 0xFFu;
+    while (e.nbuf > 1) {
+      out.put(fill);
+      e.nbuf--;
+    }
+    e.buffered = lead & 0xFFu;
+  } else {
+    e.nbuf = 1;
+    e.buffered = lead;
+  }
+}
+
+// move complete bytes out of low.  The reference does this after every bin (bitsLeft < 12 <=> W >= 21);
+// here it may run less often, W just has to stay below 63.
+template <class Sink>
+CABAC_HD void enc_flush(EncCore &e, Sink &out) {
+  while (e.W >= 21) {
+    e.W -= 8;
+    const uint32_t lead = (uint32_t)(e.low >> e.W) & 0x1FFu;
+    e.low &= (1ull << e.W) - 1ull;
+    enc_lead(e, lead, out);
+  }
+}
+
+template <class Sink>
+CABAC_HD void enc_finish(EncCore &e, Sink &out) {
+  // encodeBinTrm(1), ref: :326-341
+  e.range -= 2;
+  e.low = (e.low + e.range) << 7;
+  e.range = 256;
+  e.W += 7;
+  enc_flush(e, out);  // now 13 <= W <= 20, as in the reference after its testAndWriteOut
+  // finish(), ref: :76-104
+  if ((e.low >> e.W) & 1ull) {
+    out.put((e.buffered + 1u) & 0xFFu);
+    while (e.nbuf > 1) {
+      out.put(0x00u);
+      e.nbuf--;
+    }
+    e.low -= 1ull << e.W;
+  } else {
+    if (e.nbuf > 0) out.put(e.buffered & 0xFFu);
+    while (e.nbuf > 1) {
+      out.put(0xFFu);
+      e.nbuf--;
+    }
+  }
+  // write(low >> 8, 24 - bitsLeft); write(1, 1); writeAlignZero()
+  const uint32_t nb = (uint32_t)e.W - 8u;  // 5..12 payload bits
+  uint32_t tail = ((((uint32_t)(e.low >> 8)) & ((1u << nb) - 1u)) << 1) | 1u;  // nb + 1 bits
+  if (nb + 1u <= 8u) {
+    out.put((tail << (8u - (nb + 1u))) & 0xFFu);
+  } else {
+    tail <<= 16u - (nb + 1u);
+    out.put(tail >> 8);
+    out.put(tail & 0xFFu);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder
+// ------------------------------------------------------------------------------------------------
+// v holds the code value with (sh) fraction bits below the 9-bit range: the reference's m_uiValue is
+// v >> (sh - 7) with its not-yet-read low bits zero.  Invariant between bins: 8 <= sh <= 23.
+struct DecCore {
+  uint32_t v;
+  uint32_t range;
+  int32_t sh;
+  uint32_t nread;  // bytes merged into v so far (the reference has read fewer or as many)
+};
+
+// Src policy: uint32_t next() -> next payload byte (0xFF past the end, like fstream::get at EOF)
+template <class Src>
+CABAC_HD void dec_refill(DecCore &d, Src &src) {
+  while (d.sh <= 15) {
+    d.v = (d.v << 8) | src.next();
+    d.sh += 8;
+    d.nread++;
+  }
+}
+
+// branch-free top-up used at fixed points of the bin loop: brings sh to 16..23 taking at most two bytes
+// (Src::take(k), k in 0..2, returns the next k bytes as a big-endian integer)
+template <class Src>
+CABAC_HD void dec_topup(DecCore &d, Src &src) {
+  const uint32_t k = (uint32_t)(23 - d.sh) >> 3;
+  d.v = (d.v << (8u * k)) | src.take(k);
+  d.sh += (int32_t)(8u * k);
+  d.nread += k;
+}
+
+template <class Src>
+CABAC_HD void dec_start(DecCore &d, Src &src) {  // ref: CABAC_ArithmeticDecoder.cpp:54-71
+  d.range = 510;
+  d.v = src.next() << 8;
+  d.v |= src.next();
+  d.sh = 7;
+  d.nread = 2;
+  dec_refill(d, src);
+}
+
+template <class States>
+CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
+  const uint32_t p = st.load(ctx);
+  const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t q8 = (d.range >> 3) & 0x18u;
+  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  const bool is_lps = d.v >= scaled;
+  const uint32_t n_lps = clz32(lps) - 23u;
+  const uint32_t n_mps = (rmps >> 8) ^ 1u;
+  const uint32_t n = is_lps ? n_lps : n_mps;
+  d.v -= is_lps ? scaled : 0u;
+  d.range = (is_lps ? lps : rmps) << n;
+  d.sh -= (int32_t)n;
+  const uint32_t tr = st.trans_lps(p >> 1);
+  st.store(ctx, is_lps ? next_lps(p, tr) : next_mps(p));
+  return (p & 1u) ^ (is_lps ? 1u : 0u);
+}
+
+template <class States>
+CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
+  const bool ep = ctx == kBypass;
+  const uint32_t c = ep ? 0u : ctx;
+  const uint32_t p = st.load(c);
+  const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t q8 = (d.range >> 3) & 0x18u;
+  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t rmps = d.range - lps;
+  const int32_t sh = d.sh - (ep ? 1 : 0);
+  const uint32_t scaled = (ep ? d.range : rmps) << sh;
+  const bool hit = d.v >= scaled;  // LPS for a context bin, 1 for a bypass bin
+  const uint32_t n_lps = clz32(lps) - 23u;
+  const uint32_t n_mps = (rmps >> 8) ^ 1u;
+  const uint32_t n = ep ? 0u : (hit ? n_lps : n_mps);
+  d.v -= hit ? scaled : 0u;
+  d.range = ep ? d.range : ((hit ? lps : rmps) << n);
+  d.sh = sh - (int32_t)n;
+  const uint32_t tr = st.trans_lps(p >> 1);
+  st.store(c, ep ? p : (hit ? next_lps(p, tr) : next_mps(p)));
+  return ep ? (hit ? 1u : 0u) : ((p & 1u) ^ (hit ? 1u : 0u));
+}
+
+CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331
+  d.sh -= 1;
+  const uint32_t scaled = d.range << d.sh;
+  const bool one = d.v >= scaled;
+  d.v -= one ? scaled : 0u;
+  return one ? 1u : 0u;
+}
+
+// decodeBinTrm + the two asserts of finish() as flags; len = payload length of this stream.
+// last_byte_at(i) must return payload byte i (i < len).
+template <class ByteAt>
+CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t len, ByteAt byte_at) {
+  uint32_t status = 0;
+  d.range -= 2;
+  // bits the reference has shifted in total; it has read 2 + floor(shifted / 8) bytes
+  uint32_t shifted = 8u * (d.nread - 2u) - (uint32_t)(d.sh - 7);
+  if (!(d.v >= (d.range << d.sh))) {
+    status |= 1u;                      // terminate bin != 1 ...
+    if (d.range < 256u) shifted += 1;  // ... and the reference then renormalises by one bit (:452-463)
+  }
+  const uint32_t last_idx = 1u + (shifted >> 3);
+  const uint32_t r = shifted & 7u;  // 8 + m_bitsNeeded
+  const uint32_t last = last_idx < len ? byte_at(last_idx) : 0xFFu;
+  if (((last << r) & 0xFFu) != 0x80u) status |= 2u;
+  if (last_idx >= len || len < 2u) status |= 4u;
+  return status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Byte source for the decoder: a 64-bit big-endian window `cur` over the stream's payload bytes that is
+// re-based at wave-uniform points (boundary()) from a 16-byte piece fetched one boundary earlier, so the
+// HBM/L2 latency of the fetch is never on the bin loop's critical path.
+// Mem policy: void load16(uint32_t off, uint64_t &lo, uint64_t &hi) -> payload bytes [a, a+16) of this
+// stream, a = off rounded down to 4 (little-endian in lo, hi); returns nothing past the payload buffer.
+// ------------------------------------------------------------------------------------------------
+template <class Mem>
+struct WindowSrc {
+  Mem mem;
+  uint32_t len;   // payload bytes of this stream; reads at or past len give 0xFF (fstream EOF)
+  uint32_t pos;   // offset of the next byte to hand out
+  uint64_t cur;   // next bytes, big endian (next byte in bits 63..56)
+  int32_t cnt;    // valid bytes in cur
+  uint64_t nlo, nhi;
+  uint32_t npos;  // nlo/nhi hold bytes [npos, npos + 16)
+
+  CABAC_HD void prefetch() {
+    npos = pos & ~3u;
+    mem.load16(npos, nlo, nhi);
+  }
+  CABAC_HD void eof_fill() {
+    if (pos + 8u > len) {
+      const uint32_t k = len > pos ? len - pos : 0u;  // real bytes in cur
+      cur |= k == 0 ? ~0ull : (~0ull >> (8u * k));
+    }
+  }
+  // rare paths are free functions taking and returning values, so that the window itself never has
+  // its address taken and stays in registers
+  static CABAC_HD_RARE uint64_t fetch8(Mem m, uint32_t at) {
+    uint64_t a, b;
+    const uint32_t base = at & ~3u, d = at - base;
+    m.load16(base, a, b);
+    return d == 0 ? a : (a >> (8u * d)) | (b << (64u - 8u * d));
+  }
+  CABAC_HD void reload_blocking() {
+    cur = __builtin_bswap64(fetch8(mem, pos));
+    cnt = 8;
+    eof_fill();
+  }
+  CABAC_HD void start(uint32_t first) {
+    pos = first;
+    cnt = 0;
+    cur = 0;
+    prefetch();
+  }
+  // re-base cur on the prefetched piece and fetch the next one
+  CABAC_HD void boundary() {
+    const uint32_t d = pos - npos;
+    if (d <= 8u) {
+      const uint64_t x = d == 0 ? nlo : (d == 8u ? nhi : (nlo >> (8u * d)) | (nhi << (64u - 8u * d)));
+      cur = __builtin_bswap64(x);
+      cnt = 8;
+      eof_fill();
+    } else {
+      reload_blocking();  // more than 8 bytes used since the last boundary: rare
+    }
+    prefetch();
+  }
+  CABAC_HD uint32_t next() {
+    if (cnt == 0) reload_blocking();
+    const uint32_t b = (uint32_t)(cur >> 56);
+    cur <<= 8;
+    cnt--;
+    pos++;
+    return b;
+  }
+  CABAC_HD uint32_t take(uint32_t k) {  // k in 0..2
+    if ((int32_t)k > cnt) {
+      uint32_t x = 0;
+      for (uint32_t i = 0; i < k; i++) x = (x << 8) | next();
+      return x;
+    }
+    const uint32_t x = (uint32_t)(cur >> 48) >> (16u - 8u * k);
+    cur <<= 8u * k;
+    cnt -= (int32_t)k;
+    pos += k;
+    return x;
+  }
+};
+
+}  // namespace isscabac
+#endif

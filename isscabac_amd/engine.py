@@ -1,0 +1,231 @@
+"""ctypes binding of the C ABI in include/isscabac.h (lib/libisscabac_hip.so).
+
+This is the Python form of the FFI stub INTEGRATION.md describes: plain pointers and sizes go straight
+through.  Device buffers are passed as integer addresses (e.g. ``tensor.data_ptr()``); host numpy arrays
+go through the ``encode`` / ``decode`` convenience methods, which call the host-buffer entry points.
+
+There is no CPU coding path: if the library or a HIP device is missing, constructing an Engine raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+BYPASS = 0xFF
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("isscabac error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -m isscabac_amd.build` (needs hipcc); there is no CPU "
+                           "fallback for the coding path" % path)
+    L = C.CDLL(path)
+    L.isscabac_abi_version.restype = C.c_int
+    L.isscabac_create.argtypes = [C.c_int, C.POINTER(_vp)]
+    L.isscabac_destroy.argtypes = [_vp]
+    L.isscabac_destroy.restype = None
+    L.isscabac_last_error.argtypes = [_vp]
+    L.isscabac_last_error.restype = C.c_char_p
+    L.isscabac_set_stream.argtypes = [_vp, _vp]
+    L.isscabac_init_by_prob.argtypes = [_f64p, C.c_int, _u8p]
+    L.isscabac_init_by_state.argtypes = [_f64p, C.c_int, _u8p]
+    L.isscabac_stream_bound.argtypes = [C.c_uint32]
+    L.isscabac_stream_bound.restype = C.c_uint64
+    L.isscabac_encode_batch_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                            _vp, C.c_uint64, _vp, _u64p]
+    L.isscabac_decode_batch_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                            _u8p, C.c_int, _vp, _vp]
+    L.isscabac_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                        _u8p, C.c_uint64, _u64p, _u64p]
+    L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
+                                        C.c_int, _u8p, _u32p]
+    L.isscabac_set_profiling.argtypes = [_vp, C.c_int]
+    L.isscabac_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
+    L.isscabac_synth_fill_dev.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_int, _vp, _vp]
+    L.isscabac_dev_alloc.argtypes = [_vp, C.c_uint64, C.POINTER(_vp)]
+    L.isscabac_dev_free.argtypes = [_vp, _vp]
+    L.isscabac_copy_h2d.argtypes = [_vp, _vp, _vp, C.c_uint64]
+    L.isscabac_copy_d2h.argtypes = [_vp, _vp, _vp, C.c_uint64]
+    _lib = L
+    return L
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype)
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def init_by_prob(p0):
+    """ref: SimpleCABACMex('initByProb', ...) -> initContextModelsByP0Prob (CABAC_ContextModelsInit.cpp:82-148)."""
+    p0 = _np(p0, np.float64).ravel()
+    out = np.zeros(p0.size, np.uint8)
+    rc = _load().isscabac_init_by_prob(_ptr(p0, _f64p), p0.size, _ptr(out, _u8p))
+    if rc:
+        raise EngineError(rc, "init_by_prob: p0 outside [0, 1]")
+    return out
+
+
+def init_by_state(triples):
+    """ref: SimpleCABACMex('initByState', ...) -> initContextModelsByMpsState (:51-80); flat [ctxIdx,mps,state]*."""
+    t = _np(triples, np.float64).ravel()
+    n = t.size // 3
+    out = np.zeros(n, np.uint8)
+    rc = _load().isscabac_init_by_state(_ptr(t, _f64p), n, _ptr(out, _u8p))
+    if rc:
+        raise EngineError(rc, "init_by_state: mps must be 0/1 and state 0..62")
+    return out
+
+
+def stream_bound(nbins):
+    return int(_load().isscabac_stream_bound(int(nbins)))
+
+
+class Engine:
+    """One engine handle = one GPU + its scratch.  Not thread safe."""
+
+    def __init__(self, device=0):
+        self._L = _load()
+        h = _vp()
+        rc = self._L.isscabac_create(int(device), C.byref(h))
+        if rc:
+            raise EngineError(rc, self._L.isscabac_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.isscabac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(rc, self._L.isscabac_last_error(self._h).decode())
+
+    # ---- configuration -------------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = engine's own."""
+        self._check(self._L.isscabac_set_stream(self._h, _vp(hip_stream or 0)))
+
+    def set_profiling(self, on):
+        self._check(self._L.isscabac_set_profiling(self._h, int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 4)()
+        self._check(self._L.isscabac_last_kernel_ms(self._h, ms))
+        return dict(encode=ms[0], scan=ms[1], gather=ms[2], decode=ms[3])
+
+    # ---- device-buffer hot path ------------------------------------------------------------------------
+    def encode_dev(self, d_bins, d_ctx, S, nbins, pitch, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0):
+        ci = _np(ctx_init, np.uint8)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_batch_dev(self._h, _vp(d_bins), _vp(d_ctx), _vp(d_nbins or 0), int(S),
+                                                      int(nbins), int(pitch), _ptr(ci, _u8p), ci.size, _vp(d_payload),
+                                                      int(payload_cap), _vp(d_offsets), C.byref(total)))
+        return int(total.value)
+
+    def decode_dev(self, d_payload, payload_bytes, d_offsets, d_ctx, S, nbins, pitch, ctx_init, d_bins_out,
+                   d_status=0, d_nbins=0):
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_decode_batch_dev(self._h, _vp(d_payload), int(payload_bytes), _vp(d_offsets),
+                                                      _vp(d_ctx), _vp(d_nbins or 0), int(S), int(nbins), int(pitch),
+                                                      _ptr(ci, _u8p), ci.size, _vp(d_bins_out), _vp(d_status or 0)))
+
+    def synth_dev(self, seed, s0, S, nbins, pitch, nctx, ep_half, d_bins, d_ctx):
+        self._check(self._L.isscabac_synth_fill_dev(self._h, int(seed), int(s0), int(S), int(nbins), int(pitch),
+                                                    int(nctx), int(bool(ep_half)), _vp(d_bins), _vp(d_ctx)))
+
+    # ---- host-buffer entry points ---------------------------------------------------------------------
+    @staticmethod
+    def _pad_rows(a, pitch):
+        a = _np(a, np.uint8)
+        if a.shape[1] == pitch:
+            return a
+        out = np.zeros((a.shape[0], pitch), np.uint8)
+        out[:, :a.shape[1]] = a
+        return out
+
+    def encode(self, bins, ctx, ctx_init, nbins=None):
+        """bins, ctx: [S, B] uint8 (stream-major).  Returns (payload uint8[total], offsets uint64[S+1])."""
+        bins = _np(bins, np.uint8)
+        ctx = _np(ctx, np.uint8)
+        assert bins.ndim == 2 and bins.shape == ctx.shape
+        S, B = bins.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        bins, ctx = self._pad_rows(bins, pitch), self._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        cap = S * stream_bound(B)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_batch(self._h, _ptr(bins, _u8p), _ptr(ctx, _u8p), _ptr(nb, _u32p), S, B,
+                                                  pitch, _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
+                                                  _ptr(offsets, _u64p), C.byref(total)))
+        return payload[:int(total.value)].copy(), offsets
+
+    def decode(self, payload, offsets, ctx, ctx_init, nbins=None):
+        """Returns (bins uint8[S, B], status uint32[S])."""
+        payload = _np(payload, np.uint8)
+        offsets = _np(offsets, np.uint64)
+        ctx = _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        ctxp = self._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        bins = np.zeros((S, pitch), np.uint8)
+        status = np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_decode_batch(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ctxp, _u8p),
+                                                  _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
+                                                  _ptr(bins, _u8p), _ptr(status, _u32p)))
+        return bins[:, :B].copy(), status
+
+    # ---- raw device memory (for callers without torch) ---------------------------------------------------
+    def alloc(self, nbytes):
+        p = _vp()
+        self._check(self._L.isscabac_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def free(self, d_ptr):
+        self._check(self._L.isscabac_dev_free(self._h, _vp(d_ptr)))
+
+    def h2d(self, d_dst, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self._L.isscabac_copy_h2d(self._h, _vp(d_dst), _vp(arr.ctypes.data), arr.nbytes))
+
+    def d2h(self, arr, d_src):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(self._L.isscabac_copy_d2h(self._h, _vp(arr.ctypes.data), _vp(d_src), arr.nbytes))

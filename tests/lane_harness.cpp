@@ -1,0 +1,129 @@
+// lane_harness.cpp -- host build of the engine's per-lane CABAC code (isscabac_amd/csrc/cabac_lane.h)
+// for the CPU test-suite.  It drives the SAME inline functions the HIP kernels call, with the same
+// cadence of flush / top-up / boundary calls, over plain arrays, so arithmetic bugs are caught (and
+// ASan/UBSan can run) without a GPU.  It is a test build of product code, never a runtime fallback.
+//
+//   g++ -O1 -g -shared -fPIC [-fsanitize=address,undefined] -I isscabac_amd/csrc tests/lane_harness.cpp
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "cabac_lane.h"
+
+using namespace isscabac;
+
+namespace {
+
+const uint32_t kLpsRow[64] = {ISSCABAC_LPS_ROWS};
+const uint8_t kTransLps[64] = {ISSCABAC_TRANS_LPS};
+
+struct HostStates {
+  uint8_t cm[256];
+  uint32_t load(uint32_t c) const { return cm[c]; }
+  void store(uint32_t c, uint32_t p) { cm[c] = (uint8_t)p; }
+  uint32_t lps_row(uint32_t s) const { return kLpsRow[s]; }
+  uint32_t trans_lps(uint32_t s) const { return kTransLps[s]; }
+};
+
+struct HostSink {
+  uint8_t *buf;
+  size_t len, cap;
+  void put(uint32_t b) {
+    if (len < cap) buf[len] = (uint8_t)b;
+    len++;
+  }
+};
+
+// payload bytes of one stream inside a bigger buffer, with the device's bounds rule
+struct HostMem {
+  const uint8_t *base;    // first byte of this stream
+  uint64_t avail;         // bytes from base to the end of the whole payload buffer
+  uint32_t *fast, *slow;  // counters
+  void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
+    uint8_t tmp[16];
+    if ((uint64_t)off + 16 <= avail) {
+      std::memcpy(tmp, base + off, 16);
+      if (fast) (*fast)++;
+    } else {
+      for (uint32_t i = 0; i < 16; i++) tmp[i] = (uint64_t)off + i < avail ? base[off + i] : 0;
+      if (slow) (*slow)++;
+    }
+    std::memcpy(&lo, tmp, 8);
+    std::memcpy(&hi, tmp + 8, 8);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+// flush_every: bins between enc_flush calls (1 = reference cadence, 4 = kernel cadence)
+// flush_every < 0: same cadence, but every bin goes through the combined enc_bin_any step
+long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, const uint8_t *ctx_init, int nctx,
+                        int flush_every, uint8_t *out, size_t cap, uint8_t *ctx_final, int *max_w) {
+  const bool any = flush_every < 0;
+  if (any) flush_every = -flush_every;
+  HostStates st;
+  std::memset(st.cm, 1, sizeof st.cm);
+  std::memcpy(st.cm, ctx_init, (size_t)nctx);
+  HostSink sink{out, 0, cap};
+  EncCore e;
+  enc_start(e);
+  int mw = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (any) enc_bin_any(e, bins[i], ctx[i], st);
+    else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
+    else enc_bin(e, bins[i], ctx[i], st);
+    if (e.W > mw) mw = e.W;
+    if ((i + 1) % (uint32_t)flush_every == 0) enc_flush(e, sink);
+  }
+  enc_flush(e, sink);
+  enc_finish(e, sink);
+  if (ctx_final) std::memcpy(ctx_final, st.cm, (size_t)nctx);
+  if (max_w) *max_w = mw;
+  return sink.len <= cap ? (long)sink.len : -1;
+}
+
+// the stream's payload is buf[start, start+len) inside a buffer of `total` bytes.
+// chunk = bins per boundary() (kernel: 16), group = bins per top-up (kernel: 4)
+uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx,
+                            uint32_t n, const uint8_t *ctx_init, int nctx, int chunk, int group, uint8_t *bins_out,
+                            uint8_t *ctx_final, uint32_t *counters /* [fast, slow, slow_refills] */) {
+  const bool any = group < 0;
+  if (any) group = -group;
+  HostStates st;
+  std::memset(st.cm, 1, sizeof st.cm);
+  std::memcpy(st.cm, ctx_init, (size_t)nctx);
+  uint32_t fast = 0, slow = 0, slow_refills = 0;
+  // like the kernel: the window works from the 4-byte aligned address below the stream's first byte
+  const uint64_t abase = start & ~3ull;
+  const uint32_t skew = (uint32_t)(start - abase);
+  WindowSrc<HostMem> src;
+  src.mem = HostMem{buf + abase, total - abase, &fast, &slow};
+  src.len = skew + len;
+  src.start(skew);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  for (uint32_t i = 0; i < n; i++) {
+    if (i % (uint32_t)chunk == 0) src.boundary();
+    if (i % (uint32_t)group == 0) dec_topup(d, src);
+    if (d.sh < 8) {
+      dec_refill(d, src);
+      slow_refills++;
+    }
+    if (any) bins_out[i] = (uint8_t)dec_bin_any(d, ctx[i], st);
+    else bins_out[i] = (uint8_t)(ctx[i] == kBypass ? dec_bin_ep(d) : dec_bin(d, ctx[i], st));
+  }
+  const uint8_t *p = buf + start;
+  uint32_t status = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+  if (ctx_final) std::memcpy(ctx_final, st.cm, (size_t)nctx);
+  if (counters) {
+    counters[0] = fast;
+    counters[1] = slow;
+    counters[2] = slow_refills;
+  }
+  return status;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+"""Host build of the engine's per-lane code (isscabac_amd/csrc/cabac_lane.h via tests/lane_harness.cpp)
+against the oracle and the golden vectors.  Same inline functions the HIP kernels call, same flush /
+top-up / boundary cadence, compiled with UBSan.  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "lane_harness.cpp")
+HDR = os.path.join(ROOT, "isscabac_amd", "csrc", "cabac_lane.h")
+OUT = os.path.join(ROOT, "tests", "_build", "liblane_harness.so")
+u8p = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def lane():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=undefined",
+                               "-fno-sanitize-recover=undefined", "-I", os.path.dirname(HDR), SRC, "-o", OUT])
+    L = C.CDLL(OUT)
+    L.lane_encode_stream.restype = C.c_long
+    L.lane_encode_stream.argtypes = [u8p, u8p, C.c_uint32, u8p, C.c_int, C.c_int, u8p, C.c_size_t, u8p,
+                                     C.POINTER(C.c_int)]
+    L.lane_decode_stream.restype = C.c_uint32
+    L.lane_decode_stream.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
+                                     C.c_int, u8p, u8p, C.POINTER(C.c_uint32)]
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(u8p)
+
+
+def lane_encode(L, bins, ctx, init, flush_every):
+    bins = np.ascontiguousarray(bins, np.uint8)
+    ctx = np.ascontiguousarray(ctx, np.uint8)
+    init = np.ascontiguousarray(init, np.uint8)
+    out = np.zeros((6 * bins.size + 9 + 7) // 8 + 8, np.uint8)
+    fin = np.zeros(max(1, init.size), np.uint8)
+    mw = C.c_int(0)
+    n = L.lane_encode_stream(_p(bins), _p(ctx), bins.size, _p(init), init.size, flush_every, _p(out), out.size,
+                             _p(fin), C.byref(mw))
+    assert n >= 0
+    return out[:n], fin[:init.size], mw.value
+
+
+def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=0, fill=0xA5):
+    payload = np.ascontiguousarray(payload, np.uint8)
+    buf = np.concatenate([np.full(pad_front, fill, np.uint8), payload, np.full(pad_back, fill, np.uint8)])
+    ctx = np.ascontiguousarray(ctx, np.uint8)
+    init = np.ascontiguousarray(init, np.uint8)
+    bins = np.zeros(max(1, ctx.size), np.uint8)
+    fin = np.zeros(max(1, init.size), np.uint8)
+    cnt = (C.c_uint32 * 3)()
+    st = L.lane_decode_stream(_p(buf), buf.size, pad_front, payload.size, _p(ctx), ctx.size, _p(init), init.size,
+                              chunk, group, _p(bins), _p(fin), cnt)
+    return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
+
+
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4])
+def test_encode_golden(lane, golden, flush_every):
+    for s in golden["streams"]:
+        out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
+        assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
+        assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
+        assert mw <= 20 + 6 * abs(flush_every) + 1
+
+
+@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4)])
+def test_decode_golden(lane, golden, pads):
+    for s in golden["streams"]:
+        bins, st, fin, _ = lane_decode(lane, s["payload_a"], s["ctx_a"], s["ctx_init_a"], pad_front=pads[0],
+                                       pad_back=pads[1], group=pads[2])
+        assert st == 0, s["name"]
+        assert (bins == s["bins_a"]).all(), s["name"]
+        assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
+
+
+def test_fuzz_vs_oracle(lane, oracle):
+    rng = np.random.default_rng(99)
+    slow = 0
+    for it in range(300):
+        n = int(rng.integers(0, 3000))
+        Cn = int(rng.choice([1, 3, 4, 5, 23, 64, 255]))
+        init = rng.integers(0, 126, Cn).astype(np.uint8)
+        ctx = rng.integers(0, Cn, n).astype(np.uint8)
+        if it % 3 == 1:
+            ctx[rng.random(n) < 0.5] = 0xFF
+        skew = rng.random(Cn + 1) ** (1 + it % 4)
+        bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
+        want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
+        got, fin, _ = lane_encode(lane, bins, ctx, init, 4)
+        assert got.tobytes() == want.tobytes()
+        assert fin.tobytes() == want_fin.tobytes()
+        dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
+                                         pad_back=int(rng.integers(0, 20)))
+        assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes()
+        slow += cnt[2]
+    assert slow > 0  # the in-chunk refill path was exercised
+
+
+def test_all_lps_worst_case_width(lane, oracle, golden):
+    s = {x["name"]: x for x in golden["streams"]}["all_lps_4ctx"]
+    _out, _fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], 4)
+    assert mw <= 44
+
+
+def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
+    rng = np.random.default_rng(5)
+    flagged = 0
+    for _ in range(300):
+        n = int(rng.integers(8, 800))
+        Cn = int(rng.choice([1, 3, 64]))
+        init = rng.integers(0, 126, Cn).astype(np.uint8)
+        ctx = rng.integers(0, Cn, n).astype(np.uint8)
+        if rng.random() < 0.3:
+            ctx[rng.random(n) < 0.4] = 0xFF
+        bins = rng.integers(0, 2, n).astype(np.uint8)
+        payload = oracle.encode_stream(bins, ctx, init)
+        bad = payload.copy()
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            bad[rng.integers(0, bad.size)] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:
+            bad = bad[:max(1, bad.size - int(rng.integers(1, 4)))]  # truncated: the reference reads 0xFF at EOF
+        else:
+            bad = np.concatenate([bad, rng.integers(0, 256, 3).astype(np.uint8)])
+        want, st_want = oracle.decode_stream(bad, ctx, init)
+        got, st, _, _ = lane_decode(lane, bad, ctx, init, pad_front=2, pad_back=int(rng.integers(0, 30)))
+        assert (got == want).all()
+        assert st == st_want
+        flagged += st != 0
+    assert flagged > 100
