@@ -30,7 +30,14 @@
 namespace isscabac {
 
 __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
-__device__ const uint32_t c_trans_lps[64] = {ISSCABAC_TRANS_LPS};
+struct NextTab {
+  uint32_t e[64];
+  constexpr NextTab() : e{} {
+    constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
+    for (uint32_t s = 0; s < 64; s++) e[s] = next_state_entry(s, trans[s]);
+  }
+};
+__device__ const NextTab c_next{};
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kTabBytes = 512;
@@ -125,16 +132,16 @@ struct LdsStatesXbar {
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return base[((c & ~3u) << 6) | (c & 3u)]; }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) { base[((c & ~3u) << 6) | (c & 3u)] = (uint8_t)p; }
   __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)row_tab); }
-  __device__ __forceinline__ uint32_t trans_lps(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
 };
 // states in LDS, tables in LDS memory: any exec mask
 struct LdsStatesMem {
   uint8_t *base;
-  const uint32_t *tab;  // [0..63] rows, [64..127] trans
+  const uint32_t *tab;  // [0..63] rangeTabLps rows, [64..127] next-state entries
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return base[((c & ~3u) << 6) | (c & 3u)]; }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) { base[((c & ~3u) << 6) | (c & 3u)] = (uint8_t)p; }
   __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return tab[s]; }
-  __device__ __forceinline__ uint32_t trans_lps(uint32_t s) const { return tab[64 + s]; }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return tab[64 + s]; }
 };
 // <= 4 contexts: the four state bytes in one VGPR
 struct RegStatesXbar {
@@ -143,7 +150,7 @@ struct RegStatesXbar {
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return (*packed >> (8 * c)) & 0xFFu; }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) { *packed = (*packed & ~(0xFFu << (8 * c))) | (p << (8 * c)); }
   __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)row_tab); }
-  __device__ __forceinline__ uint32_t trans_lps(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
 };
 struct RegStatesMem {
   uint32_t *packed;
@@ -151,7 +158,7 @@ struct RegStatesMem {
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return (*packed >> (8 * c)) & 0xFFu; }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) { *packed = (*packed & ~(0xFFu << (8 * c))) | (p << (8 * c)); }
   __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return tab[s]; }
-  __device__ __forceinline__ uint32_t trans_lps(uint32_t s) const { return tab[64 + s]; }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return tab[64 + s]; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -201,7 +208,7 @@ __global__ void __launch_bounds__(256) k_encode(EncArgs a) {
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
-    tab[64 + tid] = c_trans_lps[tid];
+    tab[64 + tid] = c_next.e[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -224,7 +231,7 @@ __global__ void __launch_bounds__(256) k_encode(EncArgs a) {
     const uint32_t ngrp = (a.nctx + 3) / 4;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = a.ctx_init[g];
   }
-  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_trans_lps[lane];
+  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_next.e[lane];
 
   EncCore e;
   enc_start(e);
@@ -368,7 +375,7 @@ __global__ void __launch_bounds__(256) k_decode(DecArgs a) {
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
-    tab[64 + tid] = c_trans_lps[tid];
+    tab[64 + tid] = c_next.e[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -390,7 +397,7 @@ __global__ void __launch_bounds__(256) k_decode(DecArgs a) {
     const uint32_t ngrp = (a.nctx + 3) / 4;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = a.ctx_init[g];
   }
-  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_trans_lps[lane];
+  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_next.e[lane];
 
   // payload window
   const uint64_t start = a.offsets[s], end = a.offsets[s + 1];

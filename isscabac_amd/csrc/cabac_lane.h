@@ -61,11 +61,16 @@ constexpr uint32_t kBypass = 0xFFu;
 
 CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 
-// ContextModel::updateMPS: state + 1 saturating at 62 (packed: +2 while p < 124)
-CABAC_HD uint32_t next_mps(uint32_t p) { return p + (p < 124u ? 2u : 0u); }
-// ContextModel::updateLPS: transIdxLps, MPS flips only at state 0
-CABAC_HD uint32_t next_lps(uint32_t p, uint32_t trans_state) {
-  return (trans_state << 1) | ((p & 1u) ^ (p < 2u ? 1u : 0u));
+// Next-state table entry of one state s, both transitions in one word so that a single lookup serves
+// ContextModel::updateLPS and updateMPS (ref: CABAC/ContextModel.cpp:107-123, tables :136-158):
+//   byte 0 = (transIdxLps[s] << 1) | (s == 0)   -- xor with the mps bit gives the packed LPS successor
+//                                                  (the MPS flips only when an LPS hits state 0)
+//   byte 1 = min(s + 1, 62) << 1                 -- xor with the mps bit gives the packed MPS successor
+constexpr uint32_t next_state_entry(uint32_t s, uint32_t trans) {
+  return ((trans << 1) | (s == 0 ? 1u : 0u)) | (((s < 62 ? s + 1 : s) << 1) << 8);
+}
+CABAC_HD uint32_t next_state(uint32_t p, bool is_lps, uint32_t entry) {
+  return ((entry >> (is_lps ? 0u : 8u)) & 0xFFu) ^ (p & 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -87,23 +92,24 @@ CABAC_HD void enc_start(EncCore &e) {  // ref: CABAC_ArithmeticEncoder.cpp:54-68
   e.nbuf = 0;
 }
 
-// States policy: load(ctx) -> packed state, store(ctx, p), lps_row(state), trans_lps(state)
+// States policy: load(ctx) -> packed state, store(ctx, p), lps_row(state), next_entry(state)
 template <class States>
 CABAC_HD void enc_bin(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
   const uint32_t p = st.load(ctx);
   const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t nx = st.next_entry(p >> 1);  // unconditional: the lookup may be a cross-lane op
   const uint32_t q8 = (e.range >> 3) & 0x18u;  // 8 * ((range >> 6) & 3)
   const uint32_t lps = (row >> q8) & 0xFFu;
   const uint32_t rmps = e.range - lps;
   const bool is_lps = ((bin ^ p) & 1u) != 0;
-  const uint32_t n_lps = clz32(lps) - 23u;       // == sm_aucRenormTable[lps >> 3] for lps in 6..240
-  const uint32_t n_mps = (rmps >> 8) ^ 1u;       // 1 iff rmps < 256
-  const uint32_t n = is_lps ? n_lps : n_mps;
+  // new range before renormalisation; its leading zeros give the shift for both paths:
+  // LPS: clz32(lps) - 23 == sm_aucRenormTable[lps >> 3] (lps in 6..240); MPS: rmps in 128..510 -> 1 or 0
+  const uint32_t r = is_lps ? lps : rmps;
+  const uint32_t n = clz32(r) - 23u;
   e.low = (e.low + (is_lps ? rmps : 0u)) << n;
-  e.range = (is_lps ? lps : rmps) << n;
+  e.range = r << n;
   e.W += (int32_t)n;
-  const uint32_t tr = st.trans_lps(p >> 1);  // unconditional: the lookup may be a cross-lane op
-  st.store(ctx, is_lps ? next_lps(p, tr) : next_mps(p));
+  st.store(ctx, next_state(p, is_lps, nx));
 }
 
 // context-coded or bypass bin in one branch-free step (ctx == kBypass selects encodeBinEP); lets a wave
@@ -114,18 +120,18 @@ CABAC_HD void enc_bin_any(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
   const uint32_t c = ep ? 0u : ctx;
   const uint32_t p = st.load(c);
   const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t nx = st.next_entry(p >> 1);
   const uint32_t q8 = (e.range >> 3) & 0x18u;
   const uint32_t lps = (row >> q8) & 0xFFu;
   const uint32_t rmps = e.range - lps;
   const bool is_lps = !ep && (((bin ^ p) & 1u) != 0);
-  const uint32_t n_lps = clz32(lps) - 23u;
-  const uint32_t n_mps = (rmps >> 8) ^ 1u;
-  const uint32_t n = ep ? 1u : (is_lps ? n_lps : n_mps);
+  const uint32_t r = ep ? e.range : (is_lps ? lps : rmps);
+  const uint32_t n = ep ? 1u : clz32(r) - 23u;
   e.low = ((e.low + (is_lps ? rmps : 0u)) << n) + ((ep && bin) ? e.range : 0u);
-  e.range = ep ? e.range : ((is_lps ? lps : rmps) << n);
+  e.range = ep ? e.range : (r << n);
   e.W += (int32_t)n;
-  const uint32_t tr = st.trans_lps(p >> 1);
-  st.store(c, ep ? p : (is_lps ? next_lps(p, tr) : next_mps(p)));
+  const uint32_t pn = next_state(p, is_lps, nx);
+  st.store(c, ep ? p : pn);
 }
 
 CABAC_HD void enc_bin_ep(EncCore &e, uint32_t bin) {  // ref: :250-270
@@ -246,20 +252,19 @@ template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
   const uint32_t p = st.load(ctx);
   const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t nx = st.next_entry(p >> 1);
   const uint32_t q8 = (d.range >> 3) & 0x18u;
   const uint32_t lps = (row >> q8) & 0xFFu;
   const uint32_t rmps = d.range - lps;
   const uint32_t scaled = rmps << d.sh;
   const bool is_lps = d.v >= scaled;
-  const uint32_t n_lps = clz32(lps) - 23u;
-  const uint32_t n_mps = (rmps >> 8) ^ 1u;
-  const uint32_t n = is_lps ? n_lps : n_mps;
+  const uint32_t r = is_lps ? lps : rmps;
+  const uint32_t n = clz32(r) - 23u;
   d.v -= is_lps ? scaled : 0u;
-  d.range = (is_lps ? lps : rmps) << n;
+  d.range = r << n;
   d.sh -= (int32_t)n;
-  const uint32_t tr = st.trans_lps(p >> 1);
-  st.store(ctx, is_lps ? next_lps(p, tr) : next_mps(p));
-  return (p & 1u) ^ (is_lps ? 1u : 0u);
+  st.store(ctx, next_state(p, is_lps, nx));
+  return (p ^ (is_lps ? 1u : 0u)) & 1u;
 }
 
 template <class States>
@@ -268,21 +273,21 @@ CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
   const uint32_t c = ep ? 0u : ctx;
   const uint32_t p = st.load(c);
   const uint32_t row = st.lps_row(p >> 1);
+  const uint32_t nx = st.next_entry(p >> 1);
   const uint32_t q8 = (d.range >> 3) & 0x18u;
   const uint32_t lps = (row >> q8) & 0xFFu;
   const uint32_t rmps = d.range - lps;
   const int32_t sh = d.sh - (ep ? 1 : 0);
   const uint32_t scaled = (ep ? d.range : rmps) << sh;
   const bool hit = d.v >= scaled;  // LPS for a context bin, 1 for a bypass bin
-  const uint32_t n_lps = clz32(lps) - 23u;
-  const uint32_t n_mps = (rmps >> 8) ^ 1u;
-  const uint32_t n = ep ? 0u : (hit ? n_lps : n_mps);
+  const uint32_t r = hit ? lps : rmps;
+  const uint32_t n = ep ? 0u : clz32(r) - 23u;
   d.v -= hit ? scaled : 0u;
-  d.range = ep ? d.range : ((hit ? lps : rmps) << n);
+  d.range = ep ? d.range : (r << n);
   d.sh = sh - (int32_t)n;
-  const uint32_t tr = st.trans_lps(p >> 1);
-  st.store(c, ep ? p : (hit ? next_lps(p, tr) : next_mps(p)));
-  return ep ? (hit ? 1u : 0u) : ((p & 1u) ^ (hit ? 1u : 0u));
+  const uint32_t pn = next_state(p, hit, nx);
+  st.store(c, ep ? p : pn);
+  return ep ? (hit ? 1u : 0u) : ((p ^ (hit ? 1u : 0u)) & 1u);
 }
 
 CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331
@@ -359,7 +364,8 @@ struct WindowSrc {
     cur = 0;
     prefetch();
   }
-  // re-base cur on the prefetched piece and fetch the next one
+  // re-base cur on the prefetched piece; fetch a new piece only once 4 of its bytes are used up, so that
+  // on average every payload byte is requested ~2x instead of ~10x (the re-reads were missing in L2)
   CABAC_HD void boundary() {
     const uint32_t d = pos - npos;
     if (d <= 8u) {
@@ -368,9 +374,9 @@ struct WindowSrc {
       cnt = 8;
       eof_fill();
     } else {
-      reload_blocking();  // more than 8 bytes used since the last boundary: rare
+      reload_blocking();  // more than 8 bytes into the piece: rare
     }
-    prefetch();
+    if (d >= 4u) prefetch();
   }
   CABAC_HD uint32_t next() {
     if (cnt == 0) reload_blocking();

@@ -16,13 +16,20 @@ namespace {
 
 const uint32_t kLpsRow[64] = {ISSCABAC_LPS_ROWS};
 const uint8_t kTransLps[64] = {ISSCABAC_TRANS_LPS};
+struct NextTab {
+  uint32_t e[64];
+  NextTab() {
+    for (uint32_t s = 0; s < 64; s++) e[s] = next_state_entry(s, kTransLps[s]);
+  }
+};
+const NextTab kNext;
 
 struct HostStates {
   uint8_t cm[256];
   uint32_t load(uint32_t c) const { return cm[c]; }
   void store(uint32_t c, uint32_t p) { cm[c] = (uint8_t)p; }
   uint32_t lps_row(uint32_t s) const { return kLpsRow[s]; }
-  uint32_t trans_lps(uint32_t s) const { return kTransLps[s]; }
+  uint32_t next_entry(uint32_t s) const { return kNext.e[s]; }
 };
 
 struct HostSink {
