@@ -3,17 +3,18 @@
 // Mapping (DESIGN.md has the long version):
 //   * one wavefront = 64 consecutive streams, one lane = one bitstream.  The serial range / low /
 //     renormalisation dependency of CABAC stays inside a lane; lanes never talk during coding.
-//   * bins / ctx arrive stream-major (each stream's bins contiguous).  A wave reads a 64 x T byte tile
-//     with coalesced 16-byte loads (T/16 lanes cover one stream's T contiguous bytes), parks it in LDS
-//     with an XOR swizzle and every lane then pulls its own stream's bytes back 16 at a time with
-//     conflict-free ds_read_b128.  The next tile's global loads are issued before the current tile is
-//     coded, so HBM latency hides behind ~T bins of arithmetic.
+//   * bins / ctx arrive stream-major (each stream's bins contiguous).  A wave reads 64 bytes of each of
+//     its 64 streams with coalesced 16-byte loads (4 lanes cover one stream's 64 contiguous bytes), moves
+//     them through LDS 32 bytes per stream at a time with an XOR swizzle, and every lane pulls its own
+//     stream's bytes back 16 at a time with conflict-free ds_read_b128.  The next round's global loads
+//     are issued while the current one is coded, so HBM latency hides behind >= 32 bins of arithmetic.
 //   * per-stream context states: one byte per (stream, ctx) in LDS at  (ctx/4)*256 + lane*4 + ctx%4 ,
 //     so every lane always hits its own bank; with <= 4 contexts they live in one VGPR instead.
 //   * rangeTabLps row and transIdxLps are 64-entry tables: lane i keeps entry i in a VGPR and a lookup
 //     is one ds_bpermute_b32 (LDS crossbar, no bank conflicts); divergent (ragged) sections use an LDS
 //     copy instead because bpermute cannot read inactive lanes.
-//   * emitted bytes go to a per-stream HBM slot of provable worst-case size; a scan over the lengths and
+//   * emitted bytes are staged 16 per lane in LDS and go to a per-stream HBM slot of provable worst-case
+//     size with 16-byte stores; a scan over the lengths and
 //     a gather kernel then produce the tight payload + offsets (the reference's one-file-per-stream
 //     content, concatenated).
 //   * the decoder fetches its payload bytes 16 at a time, one chunk ahead of use (WindowSrc).
@@ -23,6 +24,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "cabac_internal.h"
 #include "cabac_lane.h"
@@ -66,39 +68,38 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64 x T byte tile: coalesced global <-> swizzled LDS <-> one row per lane
+// 64 streams x 64 bytes per load round, 32 bytes per stream resident in LDS at a time
 // ------------------------------------------------------------------------------------------------
-template <int T>
+// A wave fetches 64 contiguous bytes of each of its 64 streams per round (4 lanes x 16 B cover one stream:
+// every HBM request is a full 64-byte segment -- 32-byte segments were measured to double FETCH_SIZE), keeps
+// them in registers, and moves one 32-byte half at a time through LDS, where lane r reads its own stream's
+// row back with ds_read_b128.  Halving the LDS residency is what lets 4 workgroups share a CU.
 struct Tile {
-  static_assert(T == 32 || T == 64 || T == 128 || T == 256, "tile bytes per stream");
-  static constexpr int NCH = T / 16;    // 16-byte chunks per row = lanes that share a row in one load
-  static constexpr int RPI = 64 / NCH;  // rows covered by one wave-wide load instruction
-  static constexpr int RPB = 16 / NCH;  // rows per 256-byte LDS bank row
-  // chunk c of row r lives in slot c ^ f(r): the 16 lanes of every ds_read_b128 lane group then hit
-  // 16 distinct 16-byte slots of the bank row
-  __device__ static __forceinline__ uint32_t swz(uint32_t row) { return (row / RPB) % NCH; }
-  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t ch) {
-    return row * T + ((ch ^ swz(row)) << 4);
-  }
+  static constexpr int T = 64;   // bytes per stream per load round
+  static constexpr int H = 32;   // bytes per stream resident in LDS
+  static constexpr int NLD = 4;  // wave-wide load instructions per round (16 streams each)
+  // LDS image: row r = 32 bytes = two 16-byte chunks; chunk c sits in slot c ^ ((r >> 3) & 1), which makes
+  // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * 16 + (lane >> 2); }
+  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane & 3; }
 
-  // lane -> (row, chunk) of load instruction k
-  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * RPI + lane / NCH; }
-  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % NCH; }
-
-  __device__ static __forceinline__ void load(uint4 (&r)[NCH], const uint8_t *base, uint64_t s0, uint64_t S,
-                                              uint32_t pitch, uint32_t off, int lane) {
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *base, uint64_t s0, uint64_t S, uint32_t pitch,
+                                              uint32_t off, int lane) {
 #pragma unroll
-    for (int k = 0; k < NCH; k++) {
+    for (int k = 0; k < NLD; k++) {
       uint64_t s = s0 + row_of(k, lane);
       s = s < S ? s : S - 1;
       const uint32_t boff = off + ch_of(lane) * 16;
       r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(base + s * pitch + boff) : make_uint4(0, 0, 0, 0);
     }
   }
-  __device__ static __forceinline__ void to_lds(uint8_t *tile, const uint4 (&r)[NCH], int lane) {
+  // half h (0: bytes 0..31 of the round, 1: bytes 32..63) of the registers -> LDS
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
+    if ((int)(ch_of(lane) >> 1) == h) {
 #pragma unroll
-    for (int k = 0; k < NCH; k++)
-      *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane))) = r[k];
+      for (int k = 0; k < NLD; k++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane) & 1)) = r[k];
+    }
   }
   __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
     return *reinterpret_cast<const uint4 *>(tile + lds_off(lane, j));
@@ -106,81 +107,93 @@ struct Tile {
   __device__ static __forceinline__ void put_row_chunk(uint8_t *tile, int lane, int j, uint4 v) {
     *reinterpret_cast<uint4 *>(tile + lds_off(lane, j)) = v;
   }
-  __device__ static __forceinline__ void store(uint8_t *base, const uint8_t *tile, uint64_t s0, uint64_t S, uint32_t pitch,
-                                               uint32_t off, int lane) {
+  // LDS half image -> global, 32 contiguous bytes per stream: 2 lanes per row, 32 rows per instruction
+  __device__ static __forceinline__ void store_half(uint8_t *base, const uint8_t *tile, uint64_t s0, uint64_t S, uint32_t pitch,
+                                                    uint32_t off, int lane) {
 #pragma unroll
-    for (int k = 0; k < NCH; k++) {
-      const uint32_t row = row_of(k, lane);
+    for (int k = 0; k < 2; k++) {
+      const uint32_t row = k * 32 + (lane >> 1), c = lane & 1;
       const uint64_t s = s0 + row;
-      const uint32_t boff = off + ch_of(lane) * 16;
+      const uint32_t boff = off + c * 16;
       if (s < S && boff < pitch)
-        *reinterpret_cast<uint4 *>(base + s * pitch + boff) = *reinterpret_cast<const uint4 *>(tile + lds_off(row, ch_of(lane)));
+        *reinterpret_cast<uint4 *>(base + s * pitch + boff) = *reinterpret_cast<const uint4 *>(tile + lds_off(row, c));
     }
   }
 };
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 __device__ __forceinline__ uint32_t byte_of(const uint4 &v, int k) { return (word_of(v, k >> 2) >> (8 * (k & 3))) & 0xFFu; }
+// a word whose bit 1 is bin k of the chunk (bins are bytes 0/1): what enc_bin's b1 wants, one shift
+__device__ __forceinline__ uint32_t bin_at_bit1(const uint4 &v, int k) {
+  const uint32_t w = word_of(v, k >> 2);
+  return (k & 3) == 0 ? (w << 1) : (w >> (8 * (k & 3) - 1));
+}
 
 // ------------------------------------------------------------------------------------------------
 // context-state policies (see cabac_lane.h: States)
 // ------------------------------------------------------------------------------------------------
-// states in LDS, tables through the crossbar: only legal while all 64 lanes are active
-struct LdsStatesXbar {
-  uint8_t *base;  // wave's state region + lane * 4
-  uint32_t row_tab, trans_tab;
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return base[((c & ~3u) << 6) | (c & 3u)]; }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) { base[((c & ~3u) << 6) | (c & 3u)] = (uint8_t)p; }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)row_tab); }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
+// One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
+// pick, lane l only ever touches bank l % 32.  TABLES: true = ds_bpermute from a VGPR that holds entry `lane`
+// (legal only while all 64 lanes are active), false = LDS copy of the tables (any exec mask).
+template <bool XBAR>
+struct LdsStates {
+  uint8_t *base;        // wave's state region + lane * 4
+  const uint32_t *tab;  // LDS: [0..63] rangeTabLps rows, [64..127] next-state entries
+  uint32_t row_tab, next_tab;
+  __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
+  __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
+  __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
+  __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
+  // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
+    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
+  }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
+    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
+  }
 };
-// states in LDS, tables in LDS memory: any exec mask
-struct LdsStatesMem {
-  uint8_t *base;
-  const uint32_t *tab;  // [0..63] rangeTabLps rows, [64..127] next-state entries
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return base[((c & ~3u) << 6) | (c & 3u)]; }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) { base[((c & ~3u) << 6) | (c & 3u)] = (uint8_t)p; }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return tab[s]; }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return tab[64 + s]; }
-};
-// <= 4 contexts: the four state bytes in one VGPR
-struct RegStatesXbar {
-  uint32_t *packed;
-  uint32_t row_tab, trans_tab;
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return (*packed >> (8 * c)) & 0xFFu; }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) { *packed = (*packed & ~(0xFFu << (8 * c))) | (p << (8 * c)); }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)row_tab); }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)trans_tab); }
-};
-struct RegStatesMem {
+// <= 4 contexts: the four state bytes live in one VGPR
+template <bool XBAR>
+struct RegStates {
   uint32_t *packed;
   const uint32_t *tab;
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return (*packed >> (8 * c)) & 0xFFu; }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) { *packed = (*packed & ~(0xFFu << (8 * c))) | (p << (8 * c)); }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t s) const { return tab[s]; }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t s) const { return tab[64 + s]; }
+  uint32_t row_tab, next_tab;
+  __device__ __forceinline__ uint32_t addr(uint32_t c) const { return 8u * (c & 3u); }
+  __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return (*packed >> a) & 0xFFu; }
+  // only the low byte of q is meaningful (next_state_q leaves garbage above it)
+  __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *packed = (*packed & ~(0xFFu << a)) | ((q & 0xFFu) << a); }
+  __device__ __forceinline__ uint32_t load(uint32_t c) const { return load_at(addr(c)); }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { store_at(addr(c), p); }
+  // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
+    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
+  }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
+    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
-// byte sink: dword accumulator -> this stream's HBM slot
+// byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
+// (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
 // ------------------------------------------------------------------------------------------------
 struct SlotSink {
-  uint32_t *slot;
-  uint32_t acc, nacc, wpos;
+  uint8_t *stage;  // LDS, this lane's 16 bytes
+  uint8_t *slot;   // HBM, this stream's slot (16-byte aligned)
+  uint32_t pos;
   bool on;
   __device__ __forceinline__ void put(uint32_t b) {
-    acc |= b << (8 * nacc);
-    nacc++;
-    if (nacc == 4) {
-      if (on) slot[wpos] = acc;
-      wpos++;
-      acc = 0;
-      nacc = 0;
+    stage[pos & 15u] = (uint8_t)b;
+    pos++;
+    if ((pos & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage);
+      if (on) *reinterpret_cast<uint4 *>(slot + pos - 16) = v;
     }
   }
-  __device__ __forceinline__ uint32_t bytes() const { return wpos * 4 + nacc; }
+  __device__ __forceinline__ uint32_t bytes() const { return pos; }
   __device__ __forceinline__ void close() {
-    if (on && nacc) slot[wpos] = acc;
+    if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slot + (pos & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
   }
 };
 
@@ -194,15 +207,23 @@ struct EncArgs {
   uint32_t ctx_init[64];
 };
 
+// LDS bytes of one wave: context states, two half tiles, (encoder) the output staging
 template <int CM>
-__device__ __forceinline__ uint32_t state_bytes_per_wave() { return CM == 0 ? 0u : (CM == 1 ? 4096u : 16384u); }
+struct WaveLds {
+  static constexpr uint32_t SB = CM == 0 ? 0u : (CM == 1 ? 4096u : 16384u);
+  static constexpr uint32_t TILE = Tile::H * 64;
+  static constexpr uint32_t STAGE = 16 * 64;
+  static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE;
+};
 
 // ------------------------------------------------------------------------------------------------
 // encode kernel
 // ------------------------------------------------------------------------------------------------
-template <int T, int CM>
-__global__ void __launch_bounds__(256) k_encode(EncArgs a) {
-  using TL = Tile<T>;
+template <int CM, bool XBAR>
+using StatesFor = typename std::conditional<CM == 0, RegStates<XBAR>, LdsStates<XBAR>>::type;
+
+template <int CM>
+__global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -214,9 +235,9 @@ __global__ void __launch_bounds__(256) k_encode(EncArgs a) {
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
   if (s0 >= a.S) return;
 
-  constexpr uint32_t SB = CM == 0 ? 0u : (CM == 1 ? 4096u : 16384u);
-  uint8_t *wbase = smem + kTabBytes + wib * (SB + 2 * T * 64);
-  uint8_t *tile_b = wbase + SB, *tile_c = tile_b + T * 64;
+  using WL = WaveLds<CM>;
+  uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
+  uint8_t *tile_b = wbase + WL::SB, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
 
   const bool valid = s0 + lane < a.S;
   const uint64_t s = valid ? s0 + lane : a.S - 1;
@@ -225,99 +246,84 @@ __global__ void __launch_bounds__(256) k_encode(EncArgs a) {
   const uint32_t nmax = wave_max_u32(n), nmin = wave_min_u32(n);
 
   // context states
-  uint32_t packed = a.ctx_init[0];
+  // doubled states q = m_ucState << 1, four per dword
+  uint32_t packed = (a.ctx_init[0] & 0x7F7F7F7Fu) << 1;
   if (CM != 0) {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
     const uint32_t ngrp = (a.nctx + 3) / 4;
-    for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = a.ctx_init[g];
+    for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_next.e[lane];
+  StatesFor<CM, true> stx;
+  StatesFor<CM, false> stm;
+  if constexpr (CM == 0) {
+    stx = {&packed, tab, c_lps_rows[lane], c_next.e[lane]};
+    stm = {&packed, tab, 0, 0};
+  } else {
+    stx = {wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
+    stm = {wbase + lane * 4, tab, 0, 0};
+  }
 
   EncCore e;
   enc_start(e);
   SlotSink sink;
-  sink.slot = reinterpret_cast<uint32_t *>(a.slots + s * a.slot_stride);
-  sink.acc = 0;
-  sink.nacc = 0;
-  sink.wpos = 0;
+  sink.stage = stage + lane * 16;
+  sink.slot = a.slots + s * a.slot_stride;
+  sink.pos = 0;
   sink.on = valid;
 
-  const uint32_t ntiles = (nmax + T - 1) / T;
-  uint4 pb[TL::NCH], pc[TL::NCH];
-  if (ntiles) {
-    TL::load(pb, a.bins, s0, a.S, a.pitch, 0, lane);
-    TL::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
+  const uint32_t nrounds = (nmax + Tile::T - 1) / Tile::T;
+  uint4 pb[Tile::NLD], pc[Tile::NLD];
+  if (nrounds) {
+    Tile::load(pb, a.bins, s0, a.S, a.pitch, 0, lane);
+    Tile::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
   }
   wave_lds_sync();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    TL::to_lds(tile_b, pb, lane);
-    TL::to_lds(tile_c, pc, lane);
-    wave_lds_sync();
-    if (t + 1 < ntiles) {
-      TL::load(pb, a.bins, s0, a.S, a.pitch, (t + 1) * T, lane);
-      TL::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * T, lane);
-    }
-    for (int j = 0; j < TL::NCH; j++) {
-      const uint32_t i0 = t * T + j * 16;
-      if (i0 >= nmax) break;
-      const uint4 wb = TL::row_chunk(tile_b, lane, j);
-      const uint4 wc = TL::row_chunk(tile_c, lane, j);
-      const bool full = i0 + 16 <= nmin;
-      const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
-      if (full && !hi) {
-        // every lane codes 16 context bins: convergent, tables through the crossbar
-        if (CM == 0) {
-          RegStatesXbar st{&packed, row_tab, trans_tab};
+  for (uint32_t t = 0; t < nrounds; t++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      Tile::half_to_lds(tile_b, pb, h, lane);
+      Tile::half_to_lds(tile_c, pc, h, lane);
+      wave_lds_sync();
+      if (h == 1 && t + 1 < nrounds) {  // registers are free again: fetch the next round behind 32 bins of work
+        Tile::load(pb, a.bins, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+        Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+      }
+      for (int j = 0; j < 2; j++) {
+        const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
+        if (i0 >= nmax) break;
+        const uint4 wb = Tile::row_chunk(tile_b, lane, j);
+        const uint4 wc = Tile::row_chunk(tile_c, lane, j);
+        const bool full = i0 + 16 <= nmin;
+        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
+        if (full && !hi) {
+          // every lane codes 16 context bins: convergent, tables through the crossbar
 #pragma unroll
           for (int k = 0; k < 16; k++) {
-            enc_bin(e, byte_of(wb, k) & 1u, byte_of(wc, k), st);
+            enc_bin(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
+          }
+        } else if (full) {
+          // bypass bins (or contexts >= 128) somewhere in the wave: combined step, still convergent
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
             if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
           }
         } else {
-          LdsStatesXbar st{wbase + lane * 4, row_tab, trans_tab};
-#pragma unroll
-          for (int k = 0; k < 16; k++) {
-            enc_bin(e, byte_of(wb, k) & 1u, byte_of(wc, k), st);
-            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
-          }
-        }
-      } else if (full) {
-        // bypass bins (or contexts >= 128) somewhere in the wave: combined step, still convergent
-        if (CM == 0) {
-          RegStatesXbar st{&packed, row_tab, trans_tab};
-#pragma unroll
-          for (int k = 0; k < 16; k++) {
-            enc_bin_any(e, byte_of(wb, k) & 1u, byte_of(wc, k), st);
-            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
-          }
-        } else {
-          LdsStatesXbar st{wbase + lane * 4, row_tab, trans_tab};
-#pragma unroll
-          for (int k = 0; k < 16; k++) {
-            enc_bin_any(e, byte_of(wb, k) & 1u, byte_of(wc, k), st);
-            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
-          }
-        }
-      } else {
-        // ragged end: lanes drop out one by one, tables from LDS memory
+          // ragged end: lanes drop out one by one, tables from LDS memory
 #pragma unroll 4
-        for (int k = 0; k < 16; k++) {
-          if (i0 + k < n) {
-            const uint32_t bin = (word_of(wb, k >> 2) >> (8 * (k & 3))) & 1u;
-            const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-            if (CM == 0) {
-              RegStatesMem st{&packed, tab};
-              enc_bin_any(e, bin, cx, st);
-            } else {
-              LdsStatesMem st{wbase + lane * 4, tab};
-              enc_bin_any(e, bin, cx, st);
+          for (int k = 0; k < 16; k++) {
+            if (i0 + k < n) {
+              const uint32_t b1 = (word_of(wb, k >> 2) >> (8 * (k & 3))) << 1;
+              const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
+              enc_bin_any(e, b1, cx, stm);
             }
+            if ((k & 3) == 3) enc_flush(e, sink);
           }
-          if ((k & 3) == 3) enc_flush(e, sink);
         }
       }
+      wave_lds_sync();
     }
-    wave_lds_sync();
   }
   enc_flush(e, sink);
   enc_finish(e, sink);
@@ -367,9 +373,8 @@ struct DecArgs {
   uint32_t ctx_init[64];
 };
 
-template <int T, int CM>
-__global__ void __launch_bounds__(256) k_decode(DecArgs a) {
-  using TL = Tile<T>;
+template <int CM>
+__global__ void __launch_bounds__(256, 3) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -381,9 +386,9 @@ __global__ void __launch_bounds__(256) k_decode(DecArgs a) {
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
   if (s0 >= a.S) return;
 
-  constexpr uint32_t SB = CM == 0 ? 0u : (CM == 1 ? 4096u : 16384u);
-  uint8_t *wbase = smem + kTabBytes + wib * (SB + 2 * T * 64);
-  uint8_t *tile_c = wbase + SB, *tile_o = tile_c + T * 64;
+  using WL = WaveLds<CM>;
+  uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
+  uint8_t *tile_c = wbase + WL::SB, *tile_o = tile_c + WL::TILE;
 
   const bool valid = s0 + lane < a.S;
   const uint64_t s = valid ? s0 + lane : a.S - 1;
@@ -391,13 +396,22 @@ __global__ void __launch_bounds__(256) k_decode(DecArgs a) {
   n = min(n, a.nbins);
   const uint32_t nmin = wave_min_u32(n);
 
-  uint32_t packed = a.ctx_init[0];
+  // doubled states q = m_ucState << 1, four per dword
+  uint32_t packed = (a.ctx_init[0] & 0x7F7F7F7Fu) << 1;
   if (CM != 0) {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
     const uint32_t ngrp = (a.nctx + 3) / 4;
-    for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = a.ctx_init[g];
+    for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  const uint32_t row_tab = c_lps_rows[lane], trans_tab = c_next.e[lane];
+  StatesFor<CM, true> stx;
+  StatesFor<CM, false> stm;
+  if constexpr (CM == 0) {
+    stx = {&packed, tab, c_lps_rows[lane], c_next.e[lane]};
+    stm = {&packed, tab, 0, 0};
+  } else {
+    stx = {wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
+    stm = {wbase + lane * 4, tab, 0, 0};
+  }
 
   // payload window
   const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
@@ -413,97 +427,67 @@ __global__ void __launch_bounds__(256) k_decode(DecArgs a) {
   DecCore d;
   dec_start(d, src);
 
-  const uint32_t ntiles = (a.nbins + T - 1) / T;
-  uint4 pc[TL::NCH];
-  if (ntiles) TL::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
+  const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
+  uint4 pc[Tile::NLD];
+  if (nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
   wave_lds_sync();
-  for (uint32_t t = 0; t < ntiles; t++) {
-    TL::to_lds(tile_c, pc, lane);
-    wave_lds_sync();
-    if (t + 1 < ntiles) TL::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * T, lane);
-    for (int j = 0; j < TL::NCH; j++) {
-      const uint32_t i0 = t * T + j * 16;
-      uint4 ob = make_uint4(0, 0, 0, 0);
-      if (i0 < a.nbins) {
-        const uint4 wc = TL::row_chunk(tile_c, lane, j);
-        const bool full = i0 + 16 <= nmin;
-        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
-        uint32_t o[4] = {0, 0, 0, 0};
-        src.boundary();
-        if (full && !hi) {
-          if (CM == 0) {
-            RegStatesXbar st{&packed, row_tab, trans_tab};
+  for (uint32_t t = 0; t < nrounds; t++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      Tile::half_to_lds(tile_c, pc, h, lane);
+      wave_lds_sync();
+      if (h == 1 && t + 1 < nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+      for (int j = 0; j < 2; j++) {
+        const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
+        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        if (i0 < a.nbins) {
+          const uint4 wc = Tile::row_chunk(tile_c, lane, j);
+          const bool full = i0 + 16 <= nmin;
+          const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
+          src.boundary();
+          if (full && !hi) {
+            // context bins only: a top-up leaves sh >= 16 and a context bin takes at most 6 bits, so two bins
+            // per top-up never see sh < 7 and need no look-ahead guard
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+              if ((k & 1) == 0) dec_topup(d, src);
+              o[k >> 2] |= dec_bin(d, byte_of(wc, k), stx) << (8 * (k & 3));
+            }
+            o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
+          } else if (full) {
+            uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 16; k++) {
               if ((k & 3) == 0) dec_topup(d, src);
               if (wave_any(d.sh < 8)) {
                 if (d.sh < 8) dec_refill(d, src);
               }
-              o[k >> 2] |= dec_bin(d, byte_of(wc, k), st) << (8 * (k & 3));
+              o[k >> 2] |= dec_bin_any(d, byte_of(wc, k), stx) << (8 * (k & 3));
             }
+            o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
           } else {
-            LdsStatesXbar st{wbase + lane * 4, row_tab, trans_tab};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-              if ((k & 3) == 0) dec_topup(d, src);
-              if (wave_any(d.sh < 8)) {
-                if (d.sh < 8) dec_refill(d, src);
-              }
-              o[k >> 2] |= dec_bin(d, byte_of(wc, k), st) << (8 * (k & 3));
-            }
-          }
-        } else if (full) {
-          if (CM == 0) {
-            RegStatesXbar st{&packed, row_tab, trans_tab};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-              if ((k & 3) == 0) dec_topup(d, src);
-              if (wave_any(d.sh < 8)) {
-                if (d.sh < 8) dec_refill(d, src);
-              }
-              o[k >> 2] |= dec_bin_any(d, byte_of(wc, k), st) << (8 * (k & 3));
-            }
-          } else {
-            LdsStatesXbar st{wbase + lane * 4, row_tab, trans_tab};
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-              if ((k & 3) == 0) dec_topup(d, src);
-              if (wave_any(d.sh < 8)) {
-                if (d.sh < 8) dec_refill(d, src);
-              }
-              o[k >> 2] |= dec_bin_any(d, byte_of(wc, k), st) << (8 * (k & 3));
-            }
-          }
-        } else {
 #pragma unroll 4
-          for (int k = 0; k < 16; k++) {
-            if ((k & 3) == 0) dec_topup(d, src);
-            if (i0 + k < n) {
-              if (d.sh < 8) dec_refill(d, src);
-              const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-              uint32_t bin;
-              if (CM == 0) {
-                RegStatesMem st{&packed, tab};
-                bin = dec_bin_any(d, cx, st);
-              } else {
-                LdsStatesMem st{wbase + lane * 4, tab};
-                bin = dec_bin_any(d, cx, st);
+            for (int k = 0; k < 16; k++) {
+              if ((k & 3) == 0) dec_topup(d, src);
+              if (i0 + k < n) {
+                if (d.sh < 8) dec_refill(d, src);
+                const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
+                const uint32_t sel = dec_bin_any(d, cx, stm) << (8 * (k & 3));
+                if ((k >> 2) == 0) o0 |= sel;
+                else if ((k >> 2) == 1) o1 |= sel;
+                else if ((k >> 2) == 2) o2 |= sel;
+                else o3 |= sel;
               }
-              const uint32_t sel = bin << (8 * (k & 3));
-              if ((k >> 2) == 0) o[0] |= sel;
-              else if ((k >> 2) == 1) o[1] |= sel;
-              else if ((k >> 2) == 2) o[2] |= sel;
-              else o[3] |= sel;
             }
           }
         }
-        ob = make_uint4(o[0], o[1], o[2], o[3]);
+        Tile::put_row_chunk(tile_o, lane, j, make_uint4(o0, o1, o2, o3));
       }
-      TL::put_row_chunk(tile_o, lane, j, ob);
+      wave_lds_sync();
+      Tile::store_half(a.bins_out, tile_o, s0, a.S, a.pitch, t * Tile::T + h * Tile::H, lane);
+      wave_lds_sync();
     }
-    wave_lds_sync();
-    TL::store(a.bins_out, tile_o, s0, a.S, a.pitch, t * T, lane);
-    wave_lds_sync();
   }
   if (valid && a.status) {
     const uint8_t *p = a.payload + start;
@@ -665,63 +649,42 @@ __global__ void __launch_bounds__(256) k_synth(uint32_t seed, uint64_t s0, uint6
 // ------------------------------------------------------------------------------------------------
 uint64_t slot_stride_for(uint32_t nbins) {
   const uint64_t bound = (6ull * nbins + 9 + 7) / 8;
-  return (bound + 4 + 15) & ~15ull;
+  return (bound + 16 + 15) & ~15ull;  // the sink writes whole 16-byte pieces
 }
 
-static int tile_choice() {
-  static int t = [] {
-    const char *e = getenv("ISSCABAC_TILE");
-    const int v = e ? atoi(e) : 64;
-    return (v == 32 || v == 64 || v == 128) ? v : 64;
-  }();
-  return t;
-}
-
-template <int T, int CM>
+template <int CM>
 static size_t coder_lds_bytes() {
-  const size_t sb = CM == 0 ? 0 : (CM == 1 ? 4096 : 16384);
-  return kTabBytes + kWavesPerBlock * (sb + 2 * T * 64);
+  return kTabBytes + kWavesPerBlock * WaveLds<CM>::BYTES;
 }
 
-template <int T, int CM>
+template <int CM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<T, CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<T, CM>),
+  const size_t lds = coder_lds_bytes<CM>();
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-  hipLaunchKernelGGL((k_encode<T, CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_encode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 
-template <int T, int CM>
+template <int CM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<T, CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<T, CM>),
+  const size_t lds = coder_lds_bytes<CM>();
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-  hipLaunchKernelGGL((k_decode<T, CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((k_decode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 
-#define ISSCABAC_DISPATCH(FN, ARGS)                                                  \
-  do {                                                                               \
-    const int cm = sh.nctx <= 4 ? 0 : (sh.nctx <= 64 ? 1 : 2);                       \
-    const int t = tile_choice();                                                     \
-    if (t == 32) {                                                                   \
-      if (cm == 0) return FN<32, 0>(ARGS, stream);                                   \
-      if (cm == 1) return FN<32, 1>(ARGS, stream);                                   \
-      return FN<32, 2>(ARGS, stream);                                                \
-    } else if (t == 128) {                                                           \
-      if (cm == 0) return FN<128, 0>(ARGS, stream);                                  \
-      if (cm == 1) return FN<128, 1>(ARGS, stream);                                  \
-      return FN<128, 2>(ARGS, stream);                                               \
-    } else {                                                                         \
-      if (cm == 0) return FN<64, 0>(ARGS, stream);                                   \
-      if (cm == 1) return FN<64, 1>(ARGS, stream);                                   \
-      return FN<64, 2>(ARGS, stream);                                                \
-    }                                                                                \
+#define ISSCABAC_DISPATCH(FN, ARGS)                            \
+  do {                                                         \
+    const int cm = sh.nctx <= 4 ? 0 : (sh.nctx <= 64 ? 1 : 2); \
+    if (cm == 0) return FN<0>(ARGS, stream);                   \
+    if (cm == 1) return FN<1>(ARGS, stream);                   \
+    return FN<2>(ARGS, stream);                                \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,

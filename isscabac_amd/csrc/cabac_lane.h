@@ -34,6 +34,12 @@
 #define CABAC_HD inline
 #define CABAC_HD_RARE inline
 #endif
+// "does any lane of the wave see x": wave-uniform on the device, the lane itself on the host harness
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CABAC_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+#else
+#define CABAC_WAVE_ANY(x) (x)
+#endif
 
 namespace isscabac {
 
@@ -61,17 +67,26 @@ constexpr uint32_t kBypass = 0xFFu;
 
 CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 
+// Context states are kept "doubled": q = m_ucState << 1 = (state << 2) | (mps << 1).  q is directly the byte
+// address of entry `state` in a table of dwords (and the ds_bpermute address of lane `state`), and the
+// mps sits at bit 1 where one xor with a pre-shifted bin decides LPS/MPS.
+CABAC_HD uint32_t q_from_packed(uint32_t p) { return p << 1; }
+CABAC_HD uint32_t packed_from_q(uint32_t q) { return q >> 1; }
+
 // Next-state table entry of one state s, both transitions in one word so that a single lookup serves
-// ContextModel::updateLPS and updateMPS (ref: CABAC/ContextModel.cpp:107-123, tables :136-158):
-//   byte 0 = (transIdxLps[s] << 1) | (s == 0)   -- xor with the mps bit gives the packed LPS successor
-//                                                  (the MPS flips only when an LPS hits state 0)
-//   byte 1 = min(s + 1, 62) << 1                 -- xor with the mps bit gives the packed MPS successor
+// ContextModel::updateLPS and updateMPS (ref: CABAC/ContextModel.cpp:107-123, tables :136-158), in the
+// doubled representation and without the mps bit (xor the old mps bit back in):
+//   byte 0 = min(s + 1, 62) << 2                       -- MPS successor
+//   byte 1 = (transIdxLps[s] << 2) | (s == 0 ? 2 : 0)  -- LPS successor; the MPS flips only when an LPS hits state 0
 constexpr uint32_t next_state_entry(uint32_t s, uint32_t trans) {
-  return ((trans << 1) | (s == 0 ? 1u : 0u)) | (((s < 62 ? s + 1 : s) << 1) << 8);
+  return ((s < 62 ? s + 1 : s) << 2) | (((trans << 2) | (s == 0 ? 2u : 0u)) << 8);
 }
-CABAC_HD uint32_t next_state(uint32_t p, bool is_lps, uint32_t entry) {
-  return ((entry >> (is_lps ? 0u : 8u)) & 0xFFu) ^ (p & 1u);
+// lps_mask: 0 for an MPS, ~0 for an LPS.  Only the low byte of the result is meaningful (it is stored as a byte).
+CABAC_HD uint32_t next_state_q(uint32_t q, uint32_t lps_mask, uint32_t entry) {
+  return (entry >> (lps_mask & 8u)) ^ (q & 2u);
 }
+// ~0 if bit 1 of x is set, else 0
+CABAC_HD uint32_t mask_from_bit1(uint32_t x) { return (uint32_t)((int32_t)(x << 30) >> 31); }
 
 // ------------------------------------------------------------------------------------------------
 // Encoder
@@ -92,46 +107,89 @@ CABAC_HD void enc_start(EncCore &e) {  // ref: CABAC_ArithmeticEncoder.cpp:54-68
   e.nbuf = 0;
 }
 
-// States policy: load(ctx) -> packed state, store(ctx, p), lps_row(state), next_entry(state)
+// States policy: load(ctx) -> doubled state q, store(ctx, q) (stores the low byte), lps_row(q), next_entry(q)
+// (plus addr / load_at / store_at for the quad variants).  b1: any word whose bit 1 is the bin.
 template <class States>
-CABAC_HD void enc_bin(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
-  const uint32_t p = st.load(ctx);
-  const uint32_t row = st.lps_row(p >> 1);
-  const uint32_t nx = st.next_entry(p >> 1);  // unconditional: the lookup may be a cross-lane op
-  const uint32_t q8 = (e.range >> 3) & 0x18u;  // 8 * ((range >> 6) & 3)
-  const uint32_t lps = (row >> q8) & 0xFFu;
+CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
+  const uint32_t q = st.load(ctx);
+  const uint32_t row = st.lps_row(q);
+  const uint32_t nx = st.next_entry(q);  // unconditional: the lookup may be a cross-lane op
+  const uint32_t lps = (row >> ((e.range >> 3) & 0x18u)) & 0xFFu;  // column (range >> 6) & 3
   const uint32_t rmps = e.range - lps;
-  const bool is_lps = ((bin ^ p) & 1u) != 0;
+  const uint32_t m = mask_from_bit1(b1 ^ q);  // ~0: bin != mps
   // new range before renormalisation; its leading zeros give the shift for both paths:
   // LPS: clz32(lps) - 23 == sm_aucRenormTable[lps >> 3] (lps in 6..240); MPS: rmps in 128..510 -> 1 or 0
-  const uint32_t r = is_lps ? lps : rmps;
+  const uint32_t r = rmps ^ ((rmps ^ lps) & m);
   const uint32_t n = clz32(r) - 23u;
-  e.low = (e.low + (is_lps ? rmps : 0u)) << n;
+  e.low = (e.low + (rmps & m)) << n;
   e.range = r << n;
   e.W += (int32_t)n;
-  st.store(ctx, next_state(p, is_lps, nx));
+  st.store(ctx, next_state_q(q, m, nx));
+}
+
+// Four context bins of one stream at once, state bytes read up front and forwarded in registers where
+// contexts repeat inside the quad (more LDS/lookup overlap, ~4 more VALU per bin: pays only when the kernel is
+// latency- rather than issue-bound).  bw / cw: the quad's bin and ctx bytes (bin k in byte k).
+template <class States>
+CABAC_HD void enc_quad(EncCore &e, uint32_t bw, uint32_t cw, States &st) {
+  const uint32_t c0 = cw & 0xFFu, c1 = (cw >> 8) & 0xFFu, c2 = (cw >> 16) & 0xFFu, c3 = cw >> 24;
+  const auto a0 = st.addr(c0), a1 = st.addr(c1), a2 = st.addr(c2), a3 = st.addr(c3);
+  const uint32_t r0 = st.load_at(a0), r1 = st.load_at(a1), r2 = st.load_at(a2), r3 = st.load_at(a3);
+  const uint32_t q0 = r0;
+  const uint32_t row0 = st.lps_row(q0), nx0 = st.next_entry(q0);
+  const uint32_t m0 = mask_from_bit1((bw << 1) ^ q0);
+  const uint32_t qn0 = next_state_q(q0, m0, nx0) & 0xFFu;
+  const uint32_t q1 = c1 == c0 ? qn0 : r1;
+  const uint32_t row1 = st.lps_row(q1), nx1 = st.next_entry(q1);
+  const uint32_t m1 = mask_from_bit1((bw >> 7) ^ q1);
+  const uint32_t qn1 = next_state_q(q1, m1, nx1) & 0xFFu;
+  const uint32_t q2 = c2 == c1 ? qn1 : (c2 == c0 ? qn0 : r2);
+  const uint32_t row2 = st.lps_row(q2), nx2 = st.next_entry(q2);
+  const uint32_t m2 = mask_from_bit1((bw >> 15) ^ q2);
+  const uint32_t qn2 = next_state_q(q2, m2, nx2) & 0xFFu;
+  const uint32_t q3 = c3 == c2 ? qn2 : (c3 == c1 ? qn1 : (c3 == c0 ? qn0 : r3));
+  const uint32_t row3 = st.lps_row(q3), nx3 = st.next_entry(q3);
+  const uint32_t m3 = mask_from_bit1((bw >> 23) ^ q3);
+  const uint32_t qn3 = next_state_q(q3, m3, nx3) & 0xFFu;
+  st.store_at(a0, qn0);
+  st.store_at(a1, qn1);
+  st.store_at(a2, qn2);
+  st.store_at(a3, qn3);
+  const uint32_t rows[4] = {row0, row1, row2, row3};
+  const uint32_t ms[4] = {m0, m1, m2, m3};
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; k++) {
+    const uint32_t lps = (rows[k] >> ((e.range >> 3) & 0x18u)) & 0xFFu;
+    const uint32_t rmps = e.range - lps;
+    const uint32_t r = rmps ^ ((rmps ^ lps) & ms[k]);
+    const uint32_t n = clz32(r) - 23u;
+    e.low = (e.low + (rmps & ms[k])) << n;
+    e.range = r << n;
+    e.W += (int32_t)n;
+  }
 }
 
 // context-coded or bypass bin in one branch-free step (ctx == kBypass selects encodeBinEP); lets a wave
 // whose lanes mix both kinds stay convergent
 template <class States>
-CABAC_HD void enc_bin_any(EncCore &e, uint32_t bin, uint32_t ctx, States &st) {
+CABAC_HD void enc_bin_any(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   const bool ep = ctx == kBypass;
   const uint32_t c = ep ? 0u : ctx;
-  const uint32_t p = st.load(c);
-  const uint32_t row = st.lps_row(p >> 1);
-  const uint32_t nx = st.next_entry(p >> 1);
-  const uint32_t q8 = (e.range >> 3) & 0x18u;
-  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t q = st.load(c);
+  const uint32_t row = st.lps_row(q);
+  const uint32_t nx = st.next_entry(q);
+  const uint32_t lps = (row >> ((e.range >> 3) & 0x18u)) & 0xFFu;
   const uint32_t rmps = e.range - lps;
-  const bool is_lps = !ep && (((bin ^ p) & 1u) != 0);
-  const uint32_t r = ep ? e.range : (is_lps ? lps : rmps);
+  const uint32_t m = ep ? 0u : mask_from_bit1(b1 ^ q);
+  const uint32_t r = ep ? e.range : (rmps ^ ((rmps ^ lps) & m));
   const uint32_t n = ep ? 1u : clz32(r) - 23u;
-  e.low = ((e.low + (is_lps ? rmps : 0u)) << n) + ((ep && bin) ? e.range : 0u);
+  e.low = ((e.low + (rmps & m)) << n) + ((ep && (b1 & 2u)) ? e.range : 0u);
   e.range = ep ? e.range : (r << n);
   e.W += (int32_t)n;
-  const uint32_t pn = next_state(p, is_lps, nx);
-  st.store(c, ep ? p : pn);
+  const uint32_t qn = next_state_q(q, m, nx);
+  st.store(c, ep ? q : qn);
 }
 
 CABAC_HD void enc_bin_ep(EncCore &e, uint32_t bin) {  // ref: :250-270
@@ -250,44 +308,86 @@ CABAC_HD void dec_start(DecCore &d, Src &src) {  // ref: CABAC_ArithmeticDecoder
 
 template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
-  const uint32_t p = st.load(ctx);
-  const uint32_t row = st.lps_row(p >> 1);
-  const uint32_t nx = st.next_entry(p >> 1);
-  const uint32_t q8 = (d.range >> 3) & 0x18u;
-  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t q = st.load(ctx);
+  const uint32_t row = st.lps_row(q);
+  const uint32_t nx = st.next_entry(q);
+  const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;
   const uint32_t rmps = d.range - lps;
   const uint32_t scaled = rmps << d.sh;
-  const bool is_lps = d.v >= scaled;
-  const uint32_t r = is_lps ? lps : rmps;
+  const uint32_t m = d.v >= scaled ? ~0u : 0u;  // ~0: LPS
+  const uint32_t r = rmps ^ ((rmps ^ lps) & m);
   const uint32_t n = clz32(r) - 23u;
-  d.v -= is_lps ? scaled : 0u;
+  d.v -= scaled & m;
   d.range = r << n;
   d.sh -= (int32_t)n;
-  st.store(ctx, next_state(p, is_lps, nx));
-  return (p ^ (is_lps ? 1u : 0u)) & 1u;
+  st.store(ctx, next_state_q(q, m, nx));
+  return ((q >> 1) ^ m) & 1u;
+}
+
+// Four context bins at once, decoder side: state bytes read up front and forwarded like enc_quad.  The per-bin
+// look-ahead guard (sh >= 8) stays between the bins as a wave-uniform, rarely taken branch.  Returns the four
+// decoded bins, bin k in byte k.
+template <class States, class Src>
+CABAC_HD uint32_t dec_quad(DecCore &d, uint32_t cw, States &st, Src &src) {
+  const uint32_t c0 = cw & 0xFFu, c1 = (cw >> 8) & 0xFFu, c2 = (cw >> 16) & 0xFFu, c3 = cw >> 24;
+  const auto a0 = st.addr(c0), a1 = st.addr(c1), a2 = st.addr(c2), a3 = st.addr(c3);
+  const uint32_t r0 = st.load_at(a0), r1 = st.load_at(a1), r2 = st.load_at(a2), r3 = st.load_at(a3);
+  uint32_t out = 0;
+  uint32_t qn0, qn1, qn2, qn3;
+#define ISSCABAC_DEC_STEP(Q, QN, SHIFT)                              \
+  {                                                                  \
+    const uint32_t row = st.lps_row(Q), nx = st.next_entry(Q);       \
+    if (CABAC_WAVE_ANY(d.sh < 8)) {                                  \
+      if (d.sh < 8) dec_refill(d, src);                              \
+    }                                                                \
+    const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;  \
+    const uint32_t rmps = d.range - lps;                             \
+    const uint32_t scaled = rmps << d.sh;                            \
+    const uint32_t m = d.v >= scaled ? ~0u : 0u;                     \
+    const uint32_t r = rmps ^ ((rmps ^ lps) & m);                    \
+    const uint32_t n = clz32(r) - 23u;                               \
+    d.v -= scaled & m;                                               \
+    d.range = r << n;                                                \
+    d.sh -= (int32_t)n;                                              \
+    QN = next_state_q((Q), m, nx) & 0xFFu;                           \
+    out |= ((((Q) >> 1) ^ m) & 1u) << (SHIFT);                       \
+  }
+  const uint32_t q0 = r0;
+  ISSCABAC_DEC_STEP(q0, qn0, 0)
+  const uint32_t q1 = c1 == c0 ? qn0 : r1;
+  ISSCABAC_DEC_STEP(q1, qn1, 8)
+  const uint32_t q2 = c2 == c1 ? qn1 : (c2 == c0 ? qn0 : r2);
+  ISSCABAC_DEC_STEP(q2, qn2, 16)
+  const uint32_t q3 = c3 == c2 ? qn2 : (c3 == c1 ? qn1 : (c3 == c0 ? qn0 : r3));
+  ISSCABAC_DEC_STEP(q3, qn3, 24)
+#undef ISSCABAC_DEC_STEP
+  st.store_at(a0, qn0);
+  st.store_at(a1, qn1);
+  st.store_at(a2, qn2);
+  st.store_at(a3, qn3);
+  return out;
 }
 
 template <class States>
 CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
   const bool ep = ctx == kBypass;
   const uint32_t c = ep ? 0u : ctx;
-  const uint32_t p = st.load(c);
-  const uint32_t row = st.lps_row(p >> 1);
-  const uint32_t nx = st.next_entry(p >> 1);
-  const uint32_t q8 = (d.range >> 3) & 0x18u;
-  const uint32_t lps = (row >> q8) & 0xFFu;
+  const uint32_t q = st.load(c);
+  const uint32_t row = st.lps_row(q);
+  const uint32_t nx = st.next_entry(q);
+  const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;
   const uint32_t rmps = d.range - lps;
   const int32_t sh = d.sh - (ep ? 1 : 0);
   const uint32_t scaled = (ep ? d.range : rmps) << sh;
-  const bool hit = d.v >= scaled;  // LPS for a context bin, 1 for a bypass bin
-  const uint32_t r = hit ? lps : rmps;
+  const uint32_t m = d.v >= scaled ? ~0u : 0u;  // LPS for a context bin, 1 for a bypass bin
+  const uint32_t r = rmps ^ ((rmps ^ lps) & m);
   const uint32_t n = ep ? 0u : clz32(r) - 23u;
-  d.v -= hit ? scaled : 0u;
+  d.v -= scaled & m;
   d.range = ep ? d.range : (r << n);
   d.sh = sh - (int32_t)n;
-  const uint32_t pn = next_state(p, hit, nx);
-  st.store(c, ep ? p : pn);
-  return ep ? (hit ? 1u : 0u) : ((p ^ (hit ? 1u : 0u)) & 1u);
+  const uint32_t qn = next_state_q(q, m, nx);
+  st.store(c, ep ? q : qn);
+  return ep ? (m & 1u) : (((q >> 1) ^ m) & 1u);
 }
 
 CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331

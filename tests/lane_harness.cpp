@@ -25,11 +25,21 @@ struct NextTab {
 const NextTab kNext;
 
 struct HostStates {
-  uint8_t cm[256];
+  uint8_t cm[256];  // doubled states q, like the kernels keep them in LDS
+  void init(const uint8_t *packed, int nctx) {
+    std::memset(cm, q_from_packed(1), sizeof cm);  // ContextModel() default: (mps 1, state 0)
+    for (int c = 0; c < nctx; c++) cm[c] = (uint8_t)q_from_packed(packed[c]);
+  }
+  void final_packed(uint8_t *out, int nctx) const {
+    for (int c = 0; c < nctx; c++) out[c] = (uint8_t)packed_from_q(cm[c]);
+  }
   uint32_t load(uint32_t c) const { return cm[c]; }
-  void store(uint32_t c, uint32_t p) { cm[c] = (uint8_t)p; }
-  uint32_t lps_row(uint32_t s) const { return kLpsRow[s]; }
-  uint32_t next_entry(uint32_t s) const { return kNext.e[s]; }
+  void store(uint32_t c, uint32_t q) { cm[c] = (uint8_t)q; }
+  uint32_t addr(uint32_t c) const { return c; }
+  uint32_t load_at(uint32_t a) const { return cm[a]; }
+  void store_at(uint32_t a, uint32_t q) { cm[a] = (uint8_t)q; }
+  uint32_t lps_row(uint32_t q) const { return kLpsRow[q >> 2]; }
+  uint32_t next_entry(uint32_t q) const { return kNext.e[q >> 2]; }
 };
 
 struct HostSink {
@@ -70,23 +80,35 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
                         int flush_every, uint8_t *out, size_t cap, uint8_t *ctx_final, int *max_w) {
   const bool any = flush_every < 0;
   if (any) flush_every = -flush_every;
+  const bool quads = flush_every == 40;
+  if (quads) flush_every = 4;
   HostStates st;
-  std::memset(st.cm, 1, sizeof st.cm);
-  std::memcpy(st.cm, ctx_init, (size_t)nctx);
+  st.init(ctx_init, nctx);
   HostSink sink{out, 0, cap};
   EncCore e;
   enc_start(e);
   int mw = 0;
   for (uint32_t i = 0; i < n; i++) {
-    if (any) enc_bin_any(e, bins[i], ctx[i], st);
+    if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
+        ctx[i + 3] != kBypass) {
+      uint32_t bw, cw;
+      std::memcpy(&bw, bins + i, 4);
+      std::memcpy(&cw, ctx + i, 4);
+      enc_quad(e, bw, cw, st);
+      if (e.W > mw) mw = e.W;
+      i += 3;
+      enc_flush(e, sink);
+      continue;
+    }
+    if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);
     else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
-    else enc_bin(e, bins[i], ctx[i], st);
+    else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
     if (e.W > mw) mw = e.W;
     if ((i + 1) % (uint32_t)flush_every == 0) enc_flush(e, sink);
   }
   enc_flush(e, sink);
   enc_finish(e, sink);
-  if (ctx_final) std::memcpy(ctx_final, st.cm, (size_t)nctx);
+  if (ctx_final) st.final_packed(ctx_final, nctx);
   if (max_w) *max_w = mw;
   return sink.len <= cap ? (long)sink.len : -1;
 }
@@ -98,9 +120,11 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
                             uint8_t *ctx_final, uint32_t *counters /* [fast, slow, slow_refills] */) {
   const bool any = group < 0;
   if (any) group = -group;
+  const bool quads = group == 40;
+  if (quads) group = 4;
+  const bool noguard = group == 2;  // kernel fast path: top-up every 2 context bins, no per-bin guard
   HostStates st;
-  std::memset(st.cm, 1, sizeof st.cm);
-  std::memcpy(st.cm, ctx_init, (size_t)nctx);
+  st.init(ctx_init, nctx);
   uint32_t fast = 0, slow = 0, slow_refills = 0;
   // like the kernel: the window works from the 4-byte aligned address below the stream's first byte
   const uint64_t abase = start & ~3ull;
@@ -115,7 +139,18 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   for (uint32_t i = 0; i < n; i++) {
     if (i % (uint32_t)chunk == 0) src.boundary();
     if (i % (uint32_t)group == 0) dec_topup(d, src);
-    if (d.sh < 8) {
+    if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
+        ctx[i + 3] != kBypass) {
+      uint32_t cw;
+      std::memcpy(&cw, ctx + i, 4);
+      const uint32_t o = dec_quad(d, cw, st, src);
+      std::memcpy(bins_out + i, &o, 4);
+      i += 3;
+      continue;
+    }
+    if (noguard && ctx[i] != kBypass) {
+      if (d.sh < 7) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
+    } else if (d.sh < 8) {
       dec_refill(d, src);
       slow_refills++;
     }
@@ -124,7 +159,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   }
   const uint8_t *p = buf + start;
   uint32_t status = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
-  if (ctx_final) std::memcpy(ctx_final, st.cm, (size_t)nctx);
+  if (ctx_final) st.final_packed(ctx_final, nctx);
   if (counters) {
     counters[0] = fast;
     counters[1] = slow;
