@@ -119,6 +119,37 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
                           uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
                           uint8_t *bins_out, uint32_t *status);
 
+/* ---- single-stream handle: the reference's per-bin commands, kept working ---------------------------------
+ * One isscabac_stream = one reference handle (`class CABAC`, ref: CABAC/SimpleCABACMex.cpp:69-80): an encoder, a
+ * decoder and one set of context models for each (ref: :175-176), all resident on the device.  Every call below runs
+ * a (tiny, one-lane) HIP kernel on that state with the reference's exact write-out cadence, so getNumBits between
+ * bins reports what the reference reports.  This is the compatibility path (cabacWrapper.encodeBin / decodeBin one
+ * bin at a time, context chosen by the caller from already decoded bins); throughput lives in the batch calls.
+ *
+ *   SimpleCABACMex('initByProb'|'initByState', fn, ctxInit)  -> isscabac_init_by_* + isscabac_stream_open
+ *   ('encodeStart', h)        -> isscabac_stream_encode_start      (ref: :186-209)
+ *   ('encodeBin', h, bin, ctx)-> isscabac_stream_encode_bins(n=1)  (ref: :210-247; ctx 0xFF = bypass, additive)
+ *   ('getNumBits', h)         -> isscabac_stream_num_bits          (ref: :248-264)
+ *   ('encodeFinish', h)       -> isscabac_stream_encode_finish     (ref: :265-279; returns the file's bytes)
+ *   ('decodeStart', h)        -> isscabac_stream_decode_start      (ref: :280-300; caller passes the file's bytes)
+ *   ('decodeBin', h, ctx)     -> isscabac_stream_decode_bins(n=1)  (ref: :301-335)
+ *   ('decodeFinish', h)       -> isscabac_stream_decode_finish     (ref: :336-354; asserts become status flags)
+ */
+typedef struct isscabac_stream isscabac_stream;
+int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, isscabac_stream **out);
+void isscabac_stream_close(isscabac_stream *s);
+int isscabac_stream_encode_start(isscabac_stream *s);
+/* bins[i] in {0,1}; ctx[i] < nctx or ISSCABAC_BYPASS.  Bins are queued on the host and coded in order before any
+ * call that observes the encoder (num_bits, encode_finish). */
+int isscabac_stream_encode_bins(isscabac_stream *s, const uint8_t *bins, const uint8_t *ctx, uint32_t n);
+int isscabac_stream_num_bits(isscabac_stream *s, uint64_t *bits);
+/* terminate + flush; copies the complete bitstream (what the reference leaves in its file) to out; *nbytes = size.
+ * ISSCABAC_ERR_CAPACITY if cap is too small (call again with a bigger buffer). */
+int isscabac_stream_encode_finish(isscabac_stream *s, uint8_t *out, uint64_t cap, uint64_t *nbytes);
+int isscabac_stream_decode_start(isscabac_stream *s, const uint8_t *payload, uint64_t nbytes);
+int isscabac_stream_decode_bins(isscabac_stream *s, const uint8_t *ctx, uint32_t n, uint8_t *bins_out);
+int isscabac_stream_decode_finish(isscabac_stream *s, uint32_t *status);
+
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* when enabled, every batch call brackets each of its kernels with hipEvents on the engine's stream */
 int isscabac_set_profiling(isscabac_engine *e, int enabled);

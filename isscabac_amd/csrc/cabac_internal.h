@@ -6,6 +6,46 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
+#include "../../include/isscabac.h"
+
+// the engine handle of include/isscabac.h (host side only)
+struct isscabac_engine {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
+  std::string err;
+  // engine-owned device scratch, grow-only
+  uint8_t *slots = nullptr;
+  uint64_t slots_bytes = 0;
+  uint32_t *lens = nullptr;
+  uint64_t lens_bytes = 0;
+  void *scan_tmp = nullptr;
+  uint64_t scan_tmp_bytes = 0;
+  // staging for the host-buffer entry points
+  void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[8] = {};
+  bool ev_ready = false;
+  float last_ms[4] = {0, 0, 0, 0};
+};
+
+
+namespace isscabac {
+int engine_fail(isscabac_engine *e, int code, const char *fmt, ...);
+}
+
+#define HIP_TRY(e, call)                                                                                         \
+  do {                                                                                                           \
+    hipError_t _err = (call);                                                                                    \
+    if (_err != hipSuccess)                                                                                      \
+      return isscabac::engine_fail(e, _err == hipErrorOutOfMemory ? ISSCABAC_ERR_NOMEM : ISSCABAC_ERR_HIP, "%s: %s", \
+                                   #call, hipGetErrorString(_err));                                              \
+  } while (0)
+
 namespace isscabac {
 
 struct BatchShape {

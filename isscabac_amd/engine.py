@@ -62,6 +62,16 @@ def _load():
                                         _u8p, C.c_uint64, _u64p, _u64p]
     L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
                                         C.c_int, _u8p, _u32p]
+    L.isscabac_stream_open.argtypes = [_vp, _u8p, C.c_int, C.POINTER(_vp)]
+    L.isscabac_stream_close.argtypes = [_vp]
+    L.isscabac_stream_close.restype = None
+    L.isscabac_stream_encode_start.argtypes = [_vp]
+    L.isscabac_stream_encode_bins.argtypes = [_vp, _u8p, _u8p, C.c_uint32]
+    L.isscabac_stream_num_bits.argtypes = [_vp, _u64p]
+    L.isscabac_stream_encode_finish.argtypes = [_vp, _u8p, C.c_uint64, _u64p]
+    L.isscabac_stream_decode_start.argtypes = [_vp, _u8p, C.c_uint64]
+    L.isscabac_stream_decode_bins.argtypes = [_vp, _u8p, C.c_uint32, _u8p]
+    L.isscabac_stream_decode_finish.argtypes = [_vp, _u32p]
     L.isscabac_set_profiling.argtypes = [_vp, C.c_int]
     L.isscabac_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
     L.isscabac_synth_fill_dev.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -229,3 +239,65 @@ class Engine:
     def d2h(self, arr, d_src):
         assert arr.flags["C_CONTIGUOUS"]
         self._check(self._L.isscabac_copy_d2h(self._h, _vp(arr.ctypes.data), _vp(d_src), arr.nbytes))
+
+
+class Stream:
+    """One reference handle (`class CABAC`): per-bin encode / decode on device-resident state.
+    ref: CABAC/SimpleCABACMex.cpp:69-80, commands :186-354."""
+
+    def __init__(self, engine, ctx_init):
+        self._eng = engine
+        self._L = engine._L
+        ci = _np(ctx_init, np.uint8)
+        h = _vp()
+        engine._check(self._L.isscabac_stream_open(engine._h, _ptr(ci, _u8p), ci.size, C.byref(h)))
+        self._s = h
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.isscabac_stream_close(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode_start(self):
+        self._eng._check(self._L.isscabac_stream_encode_start(self._s))
+
+    def encode_bins(self, bins, ctx):
+        b, c = _np(bins, np.uint8).ravel(), _np(ctx, np.uint8).ravel()
+        assert b.size == c.size
+        self._eng._check(self._L.isscabac_stream_encode_bins(self._s, _ptr(b, _u8p), _ptr(c, _u8p), b.size))
+
+    def num_bits(self):
+        v = C.c_uint64(0)
+        self._eng._check(self._L.isscabac_stream_num_bits(self._s, C.byref(v)))
+        return int(v.value)
+
+    def encode_finish(self):
+        n = C.c_uint64(0)
+        buf = np.empty(1 << 12, np.uint8)
+        rc = self._L.isscabac_stream_encode_finish(self._s, _ptr(buf, _u8p), buf.size, C.byref(n))
+        if rc == 4:  # capacity: ask again with the reported size
+            buf = np.empty(int(n.value), np.uint8)
+            rc = self._L.isscabac_stream_encode_finish(self._s, _ptr(buf, _u8p), buf.size, C.byref(n))
+        self._eng._check(rc)
+        return buf[:int(n.value)].copy()
+
+    def decode_start(self, payload):
+        p = _np(payload, np.uint8).ravel()
+        self._eng._check(self._L.isscabac_stream_decode_start(self._s, _ptr(p, _u8p), p.size))
+
+    def decode_bins(self, ctx):
+        c = _np(ctx, np.uint8).ravel()
+        out = np.zeros(c.size, np.uint8)
+        self._eng._check(self._L.isscabac_stream_decode_bins(self._s, _ptr(c, _u8p), c.size, _ptr(out, _u8p)))
+        return out
+
+    def decode_finish(self):
+        st = C.c_uint32(0)
+        self._eng._check(self._L.isscabac_stream_decode_finish(self._s, C.byref(st)))
+        return int(st.value)

@@ -1,0 +1,63 @@
+"""Stream sharding across the GPUs of one node and the final bitstream gather.
+
+Streams are independent units (one reference handle = one stream, ref: CABAC/SimpleCABACMex.cpp:69-80), so rank r of
+N codes the contiguous block [lo, hi) of the global stream range and nothing is exchanged while coding.  The only
+communication is the gather of the per-rank payloads to the root at the end: sizes first (all_gather of one int64
+per rank), then every rank sends its payload straight to the root, which posts all receives at once -- on MI355X
+that keeps all seven xGMI links of the root busy concurrently instead of serialising a ring.  Works on any
+torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+
+def shard_range(n_streams, rank, world):
+    """Contiguous block of streams for `rank`; blocks differ by at most one stream and concatenate in rank order."""
+    base, rem = divmod(int(n_streams), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_offsets(shard_offsets, shard_sizes):
+    """Stitch per-rank offsets (each starting at 0, S_r + 1 entries) into the global S + 1 offsets array."""
+    out = [np.zeros(1, np.uint64)]
+    base = 0
+    for off, size in zip(shard_offsets, shard_sizes):
+        off = np.asarray(off, np.uint64)
+        assert int(off[-1]) == int(size)
+        out.append(off[1:] + np.uint64(base))
+        base += int(size)
+    return np.concatenate(out)
+
+
+def gather_payload(payload, offsets, dist, root=0):
+    """payload: 1-D uint8 torch tensor holding this rank's bitstreams, offsets: int64 tensor (S_r + 1).
+    Returns (payload_all, offsets_all) on the root (global stream order), (None, None) elsewhere."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = payload.device
+    n_local = offsets.numel() - 1
+    mine = torch.tensor([int(payload.numel()), n_local], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [s.cpu().tolist() for s in sizes]
+    if rank == root:
+        parts, offs, reqs = [], [], []
+        for r in range(world):
+            if r == root:
+                parts.append(payload)
+                offs.append(offsets)
+                continue
+            p = torch.empty(sizes[r][0], dtype=torch.uint8, device=dev)
+            o = torch.empty(sizes[r][1] + 1, dtype=torch.int64, device=dev)
+            reqs.append(dist.irecv(p, src=r))
+            reqs.append(dist.irecv(o, src=r))
+            parts.append(p)
+            offs.append(o)
+        for q in reqs:
+            q.wait()
+        all_off = global_offsets([o.cpu().numpy() for o in offs], [s[0] for s in sizes])
+        return torch.cat(parts), torch.from_numpy(all_off.astype(np.int64)).to(dev)
+    reqs = [dist.isend(payload, dst=root), dist.isend(offsets, dst=root)]
+    for q in reqs:
+        q.wait()
+    return None, None

@@ -1,0 +1,93 @@
+"""Python mirror of the reference's MATLAB handle class (ref: CABAC/cabacWrapper.m:15-77): same constructor,
+same method names and argument meaning, same error behaviour, on top of the HIP engine.  It is what
+matlab/cabacWrapper.m does through the MEX shim, written in Python so that the test-suite can drive the reference's
+own usage patterns (cabacDemo.m, +coder/cabacEncode.m) on the GPU box, where no MATLAB exists.
+
+Added on top of the reference surface: `encodeBatch` / `decodeBatch` (many independent streams per call).
+"""
+import numpy as np
+
+from . import engine as _engine
+
+_default_engine = None
+
+
+def _get_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = _engine.Engine(0)
+    return _default_engine
+
+
+class cabacWrapper:
+    def __init__(self, cm, fn, initByProb=1, engine=None):
+        # ref: cabacWrapper.m:15-30
+        if not isinstance(fn, str):
+            raise ValueError("bitStreamName should be string")
+        self.bitStreamName = fn
+        self.contextModelInitOptions = np.asarray(cm, np.float64)
+        if self.contextModelInitOptions.ndim > 2:
+            raise ValueError("context model initialization options should be like this: "
+                             "[ctxID mps probIndex, ctxID mps probIndex, ...]")
+        self._engine = engine or _get_engine()
+        self.cabac_handle = None
+        self.init(initByProb)
+
+    def init(self, initByProb=1):
+        # ref: cabacWrapper.m:31-39 -> SimpleCABACMex('initByProb' | 'initByState', fn, ctxInit), :120-185
+        flat = self.contextModelInitOptions.ravel(order="F")  # the MEX reads the MATLAB array column-major
+        self.ctx_init = _engine.init_by_prob(flat) if initByProb else _engine.init_by_state(flat)
+        self.cabac_handle = _engine.Stream(self._engine, self.ctx_init)
+
+    # ---- per-bin commands ----------------------------------------------------------------------------
+    def encodeStart(self):
+        # ref: SimpleCABACMex.cpp:186-209 opens fn for writing; the file is written at encodeFinish here
+        try:
+            open(self.bitStreamName, "wb").close()
+        except OSError:
+            raise RuntimeError("Error: bitstreamfile access error")
+        self.cabac_handle.encode_start()
+
+    def encodeBin(self, binValue, ctxID):
+        # ref: cabacWrapper.m:45-52 (client-side check) and SimpleCABACMex.cpp:210-247
+        if binValue not in (0, 1):
+            raise ValueError("bin value to be encoded should either be 1 or 0")
+        self.cabac_handle.encode_bins([int(binValue)], [int(ctxID)])
+
+    def getNumBits(self):
+        return self.cabac_handle.num_bits()  # ref: SimpleCABACMex.cpp:248-264
+
+    def encodeFinish(self):
+        payload = self.cabac_handle.encode_finish()  # ref: :265-279
+        with open(self.bitStreamName, "wb") as f:
+            f.write(payload.tobytes())
+
+    def decodeStart(self):
+        try:
+            with open(self.bitStreamName, "rb") as f:  # ref: :280-300
+                data = f.read()
+        except OSError:
+            raise RuntimeError("Error: bitstreamfile access error")
+        self.cabac_handle.decode_start(np.frombuffer(data, np.uint8))
+
+    def decodeBin(self, ctxID):
+        return int(self.cabac_handle.decode_bins([int(ctxID)])[0])  # ref: :301-335
+
+    def decodeFinish(self):
+        # ref: :336-354; the reference asserts on a broken stream, here the flags come back (0 = intact)
+        return self.cabac_handle.decode_finish()
+
+    def getEncoderStats(self, ctxID):
+        # compiled only into the Windows MEX (ref: CommonDef.h:39-43); on Linux the reference falls through to this
+        raise RuntimeError("Error: Invalid Command")
+
+    getDecoderStats = getEncoderStats
+
+    # ---- batch extension -------------------------------------------------------------------------------
+    def encodeBatch(self, bins, ctx, nbins=None):
+        """bins, ctx: [S, B] uint8, one independent stream per row (a MATLAB B x S matrix).  Every stream starts
+        from this wrapper's context initialisation.  Returns (payload, offsets)."""
+        return self._engine.encode(bins, ctx, self.ctx_init, nbins)
+
+    def decodeBatch(self, payload, offsets, ctx, nbins=None):
+        return self._engine.decode(payload, offsets, ctx, self.ctx_init, nbins)

@@ -209,3 +209,74 @@ def test_full_size_config3_round_trip(engine, oracle):
         want = oracle.encode_stream(hb[0], hc[0], init)
         got = payload[int(off[s]):int(off[s + 1])].cpu().numpy()
         assert got.tobytes() == want.tobytes(), s
+
+
+def test_single_stream_handle_per_bin_commands(engine, oracle, golden, tmp_path):
+    """The reference's per-bin command set (cabacWrapper methods) on the device-resident handle: payload, the
+    getNumBits value after every bin, decoded bins and the integrity word must equal the oracle's."""
+    import ctypes as C
+    from oracle.pyoracle import u8p
+    from isscabac_amd import Stream, cabacWrapper
+    rng = np.random.default_rng(1)
+    L = oracle.lib
+    for s in [x for x in golden["streams"] if x["n"] <= 600][:25]:
+        st = Stream(engine, s["ctx_init_a"])
+        st.encode_start()
+        # oracle incrementally, for getNumBits after every bin
+        cm = s["ctx_init_a"].copy()
+        out = np.zeros(oracle.stream_cap(s["n"]), np.uint8)
+        enc = (C.c_uint32 * 64)()
+        L.orc_enc_start(enc, out.ctypes.data_as(u8p), out.size)
+        i = 0
+        while i < s["n"]:
+            k = int(rng.integers(1, 9))
+            st.encode_bins(s["bins_a"][i:i + k], s["ctx_a"][i:i + k])
+            for j in range(i, min(i + k, s["n"])):
+                if s["ctx_a"][j] == 0xFF:
+                    L.orc_enc_bin_ep(enc, int(s["bins_a"][j]))
+                else:
+                    L.orc_enc_bin(enc, int(s["bins_a"][j]), C.cast(cm.ctypes.data + int(s["ctx_a"][j]), u8p))
+            i += k
+            assert st.num_bits() == L.orc_enc_bits(enc), s["name"]
+        assert st.num_bits() == s["bits_before_finish"], s["name"]
+        payload = st.encode_finish()
+        assert payload.tobytes() == s["payload_a"].tobytes(), s["name"]
+        st.decode_start(payload)
+        dec = np.concatenate([st.decode_bins(s["ctx_a"][j:j + 1]) for j in range(s["n"])]) if s["n"] else np.zeros(0)
+        assert (dec == s["bins_a"]).all(), s["name"]
+        assert st.decode_finish() == 0
+        st.close()
+    # cabacDemo.m-style use of the wrapper class: 3 contexts chosen from previously coded bins, file hand-off
+    fn = str(tmp_path / "test.bin")
+    sym = np.minimum(np.abs(rng.normal(size=400) * 1.3).astype(np.uint32), 3)
+    enc = cabacWrapper(0.5 * np.ones(3), fn)
+    enc.encodeStart()
+    prev_first = None
+    for v in sym:
+        g = oracle.binarize(int(v), "TU", nq=4)
+        for n, b in enumerate(g, 1):
+            ctx = (1 if prev_first == 1 else 2) if (n == 1 and prev_first is not None) else 0
+            enc.encodeBin(int(b), ctx)
+        prev_first = int(g[0])
+    enc.encodeFinish()
+    want, _ = oracle.demo_encode(sym, 4, oracle.init_by_prob([0.5] * 3))
+    assert open(fn, "rb").read() == want.tobytes()
+    dec = cabacWrapper(0.5 * np.ones(3), fn)
+    dec.decodeStart()
+    got, prev_first = [], None
+    for _ in sym:
+        g, n = [], 1
+        while True:
+            ctx = (1 if prev_first == 1 else 2) if (n == 1 and prev_first is not None) else 0
+            g.append(dec.decodeBin(ctx))
+            if g[-1] == 0 or n == 3:
+                break
+            n += 1
+        got.append(oracle.debinarize(g, "TU", nq=4))
+        prev_first = g[0]
+    assert dec.decodeFinish() == 0
+    assert got == sym.tolist()
+    with pytest.raises(ValueError):
+        enc.encodeBin(2, 0)
+    with pytest.raises(RuntimeError):
+        enc.getEncoderStats(0)

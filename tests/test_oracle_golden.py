@@ -114,3 +114,26 @@ def test_batch_helpers(oracle):
     assert (status == 0).all()
     for s in range(6):
         assert (dec[s][:nb[s]] == bins[s][:nb[s]]).all()
+
+
+def test_multi_ep_equals_single_ep(oracle, golden):
+    """encodeBinsEP(pattern, n) (ref: CABAC_ArithmeticEncoder.cpp:278-319) writes the same bytes as n calls of
+    encodeBinEP: the batch ABI therefore needs only the per-bin bypass marker.  Checked on the golden op scripts,
+    whose expected payloads come from the reference running the multi-bin form."""
+    for o in golden["ops"]:
+        bins, ctx = [], []
+        for k, v, a in zip(o["kind"], o["val"], o["arg"]):
+            if k == 0:
+                bins.append(v)
+                ctx.append(a)
+            elif k == 1:
+                bins.append(v)
+                ctx.append(0xFF)
+            else:
+                for i in range(a - 1, -1, -1):
+                    bins.append((v >> i) & 1)
+                    ctx.append(0xFF)
+        payload = oracle.encode_stream(bins, ctx, unhex(o["ctx_init"]))
+        assert payload.tobytes().hex() == o["payload"], o["name"]
+        dec, status = oracle.decode_stream(payload, ctx, unhex(o["ctx_init"]))
+        assert status == 0 and dec.tolist() == bins
