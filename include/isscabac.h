@@ -119,6 +119,53 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
                           uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
                           uint8_t *bins_out, uint32_t *status);
 
+/* ---- symbol-level batch coding: binariser + context selector fused into the coder kernels -----------------------
+ * A stream is a column of integer symbols 0..nq-1 (uint8, stream-major [S][pitch] like the bin arrays).  The kernel
+ * binarises (TU: ref CABAC/cabacBinarizer.m:30-37; EGk: :56-69), picks the context of every bin
+ *   ISSCABAC_SEL_DEMO: 3 contexts from the first bin of the previous symbol   (ref: CABAC/cabacDemo.m:113-121)
+ *   ISSCABAC_SEL_ISS : 7*nlbp+2 contexts from the bins of this symbol and of the symbol one row up
+ *                      (ref: ISS/+coder/cabacContextSelection.m:24-67; `iss_types` = 1 cond0 | 2 cond1 | 4 conds0 |
+ *                      8 conds1 | 16 condbinlft; the reference default is 15 with nlbp = 3, ISS/ISS.m:50-52)
+ * and codes it; the decoder runs the same selector on the bins it has just decoded, detects the end of each symbol
+ * (ref: CABAC/cabacDecodeSymbolFinished.m:12-30) and de-binarises (ref: CABAC/cabacDebinarizer.m:28-31,46-53).
+ * One stream here == one column walked like the inner loops of ISS/+coder/cabacEncode.m:45-70 / cabacDecode.m:29-55
+ * (the symbol "one row up" is the previous symbol of the same stream; the first symbol has none).
+ * Limits: nctx <= 64, at most 32 bins per symbol (TU: nq <= 33). */
+#define ISSCABAC_BIN_TU 0u
+#define ISSCABAC_BIN_EGK 1u
+#define ISSCABAC_SEL_DEMO 0u
+#define ISSCABAC_SEL_ISS 1u
+typedef struct {
+  uint32_t binarization; /* ISSCABAC_BIN_* */
+  uint32_t k;            /* EG order */
+  uint32_t nq;           /* symbols are 0..nq-1 */
+  uint32_t selector;     /* ISSCABAC_SEL_* */
+  uint32_t iss_types;
+  uint32_t nlbp;
+} isscabac_symbol_params;
+
+/* d_sym: device [S * pitch] uint8; d_nsym: per-stream symbol counts or NULL => nsym; d_nbins_out: optional S x u32,
+ * bins coded per stream.  Outputs as isscabac_encode_batch_dev. */
+int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
+                                uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
+                                uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out);
+int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
+                                const uint64_t *d_offsets, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
+                                uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
+                                int nctx, uint8_t *d_sym_out, uint32_t *d_status);
+/* host-buffer forms (H2D, kernels, D2H inside) */
+int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                            uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                            const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                            uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out);
+int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets,
+                            const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym, uint32_t pitch,
+                            const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                            uint8_t *sym_out, uint32_t *status);
+/* most bins one symbol can binarise to under `params` (0 if the parameters are not supported) */
+uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
+
 /* ---- single-stream handle: the reference's per-bin commands, kept working ---------------------------------
  * One isscabac_stream = one reference handle (`class CABAC`, ref: CABAC/SimpleCABACMex.cpp:69-80): an encoder, a
  * decoder and one set of context models for each (ref: :175-176), all resident on the device.  Every call below runs

@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libisscabac_hip.so")
-SOURCES = ["cabac_kernels.hip", "cabac_stream.hip", "cabac_capi.cpp"]
-HEADERS = ["cabac_lane.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
+SOURCES = ["cabac_kernels.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_capi.cpp"]
+HEADERS = ["cabac_lane.h", "cabac_symbols.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
 
 
 def hipcc():

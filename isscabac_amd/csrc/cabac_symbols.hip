@@ -1,0 +1,397 @@
+// cabac_symbols.hip -- symbol-level batch kernels: (de)binarisation and context selection fused with the coder
+// (cabac_symbols.h + cabac_lane.h).  One lane = one stream (one column of symbols); every loop iteration codes one
+// bin per lane, whichever symbol that lane is in, so lanes stay busy although symbols binarise to different lengths.
+// Used by BASELINE config 1 (cabacDemo: TU, 3 contexts) and config 4 (ISS W/H columns: EG0, 23 contexts).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "cabac_internal.h"
+#include "cabac_lane.h"
+#include "cabac_symbols.h"
+
+namespace isscabac {
+
+__device__ const uint32_t y_lps_rows[64] = {ISSCABAC_LPS_ROWS};
+struct SymNextTab {
+  uint32_t e[64];
+  constexpr SymNextTab() : e{} {
+    constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
+    for (uint32_t s = 0; s < 64; s++) e[s] = next_state_entry(s, trans[s]);
+  }
+};
+__device__ const SymNextTab y_next{};
+
+constexpr int kSymWaves = 4;
+constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024, kSymTab = 512;
+constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
+
+// states in LDS (same conflict-free layout as the bin kernels), tables in LDS memory (lanes finish at different times)
+struct SymStates {
+  uint8_t *base;
+  const uint32_t *tab;
+  __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
+  __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t q) const { *addr(c) = (uint8_t)q; }
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return tab[q >> 2]; }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return tab[64 + (q >> 2)]; }
+};
+
+struct SymSink {
+  uint8_t *stage, *slot;
+  uint32_t pos;
+  __device__ __forceinline__ void put(uint32_t b) {
+    stage[pos & 15u] = (uint8_t)b;
+    pos++;
+    if ((pos & 15u) == 0) *reinterpret_cast<uint4 *>(slot + pos - 16) = *reinterpret_cast<const uint4 *>(stage);
+  }
+  __device__ __forceinline__ void close() {
+    if (pos & 15u) *reinterpret_cast<uint4 *>(slot + (pos & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+  }
+};
+
+struct SymEncArgs {
+  const uint8_t *sym;
+  const uint32_t *nsym_per_stream;
+  uint8_t *slots;
+  uint32_t *lens, *nbins_out;
+  uint64_t S, slot_stride;
+  uint32_t nsym, pitch, nctx;
+  SymParams P;
+  uint32_t ctx_init[16];
+};
+
+__device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, uint8_t *&wbase, int tid) {
+  tab = reinterpret_cast<uint32_t *>(smem);
+  if (tid < 64) {
+    tab[tid] = y_lps_rows[tid];
+    tab[64 + tid] = y_next.e[tid];
+  }
+  __syncthreads();
+  wbase = smem + kSymTab + (tid >> 6) * kSymWaveBytes;
+}
+
+__global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t *tab;
+  uint8_t *wbase;
+  sym_init_common(smem, tab, wbase, tid);
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const bool valid = s < a.S;
+  uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
+  for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+  SymStates st{wbase + lane * 4, tab};
+  if (!valid) return;  // no cross-lane operation below
+  uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
+  const uint8_t *row = a.sym + s * a.pitch;
+  EncCore e;
+  enc_start(e);
+  SymSink sink{wbase + kSymStateBytes + lane * 16, a.slots + s * a.slot_stride, 0};
+  SymWalk w;
+  w.start();
+  uint32_t nbins = 0;
+  uint4 buf = make_uint4(0, 0, 0, 0);
+  while (w.idx < n_my) {
+    if (w.n == 1) {
+      if ((w.idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row + w.idx);
+      const uint32_t wi = (w.idx >> 2) & 3u;
+      const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
+      w.cur = binarize((word >> (8 * (w.idx & 3u))) & 0xFFu, a.P);
+    }
+    const uint32_t c = w.ctx(a.P);
+    enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
+    enc_flush(e, sink);
+    nbins++;
+    if (w.n == w.cur.len) w.next_symbol();
+    else w.n++;
+  }
+  enc_finish(e, sink);
+  sink.close();
+  a.lens[s] = sink.pos;
+  if (a.nbins_out) a.nbins_out[s] = nbins;
+}
+
+struct SymDevMem {
+  const uint8_t *base;
+  uint64_t avail;
+  struct alignas(4) Q4 { uint32_t w[4]; };
+  __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
+    if ((uint64_t)off + 16 <= avail) {
+      const Q4 q = *reinterpret_cast<const Q4 *>(base + off);
+      lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
+      hi = (uint64_t)q.w[2] | ((uint64_t)q.w[3] << 32);
+    } else {
+      lo = hi = 0;
+      for (uint32_t i = 0; i < 16; i++) {
+        const uint64_t b = (uint64_t)off + i < avail ? base[off + i] : 0;
+        if (i < 8) lo |= b << (8 * i);
+        else hi |= b << (8 * (i - 8));
+      }
+    }
+  }
+};
+
+struct SymDecArgs {
+  const uint8_t *payload;
+  const uint64_t *offsets;
+  const uint32_t *nsym_per_stream;
+  uint8_t *sym_out;
+  uint32_t *status;
+  uint64_t S, payload_bytes;
+  uint32_t nsym, pitch, nctx;
+  SymParams P;
+  uint32_t ctx_init[16];
+};
+
+__global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t *tab;
+  uint8_t *wbase;
+  sym_init_common(smem, tab, wbase, tid);
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const bool valid = s < a.S;
+  uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
+  for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+  SymStates st{wbase + lane * 4, tab};
+  if (!valid) return;
+  uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
+  const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
+  const uint32_t len = (uint32_t)(end - start);
+  const uint64_t abase = start & ~3ull;
+  const uint32_t skew = (uint32_t)(start - abase);
+  WindowSrc<SymDevMem> src;
+  src.mem.base = a.payload + abase;
+  src.mem.avail = a.payload_bytes > abase ? a.payload_bytes - abase : 0;
+  src.len = skew + len;
+  src.start(skew);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  uint8_t *row = a.sym_out + s * a.pitch;
+  SymWalk w;
+  w.start();
+  uint32_t it = 0;
+  while (w.idx < n_my) {
+    if ((it++ & 15u) == 0) src.boundary();
+    if (d.sh < 8) dec_refill(d, src);
+    const uint32_t c = w.ctx(a.P);
+    const uint32_t bin = dec_bin(d, c, st);
+    w.cur.bits |= bin << (w.n - 1);
+    w.cur.len = w.n;
+    if (symbol_finished(w.cur, a.P) || w.n == 32) {
+      row[w.idx] = (uint8_t)debinarize(w.cur, a.P);
+      w.next_symbol();
+    } else {
+      w.n++;
+    }
+  }
+  for (uint32_t i = n_my; i < a.nsym; i++) row[i] = 0;
+  if (a.status) {
+    const uint8_t *p = a.payload + start;
+    a.status[s] = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+  }
+}
+
+static uint32_t max_bins_of(const SymParams &P) {
+  if (P.nq < 2 || P.nq > 256) return 0;
+  uint32_t mx = 0;
+  for (uint32_t v = 0; v < P.nq; v++) {
+    uint32_t len;
+    if (P.method == 0) {
+      len = v == P.nq - 1 ? P.nq - 1 : v + 1;
+    } else {
+      const uint32_t t = (v >> P.k) + 1;
+      uint32_t n_p = 0;
+      while ((t >> n_p) != 0) n_p++;
+      len = n_p + P.k + n_p - 1;
+    }
+    mx = len > mx ? len : mx;
+  }
+  return mx;
+}
+
+}  // namespace isscabac
+
+using namespace isscabac;
+
+static int sym_check(isscabac_engine *e, const char *who, uint64_t S, uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *p,
+                     const uint8_t *ctx_init, int nctx, SymParams *P, uint32_t *init_words, uint32_t *maxbins) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!p || !ctx_init) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: null argument", who);
+  if (S == 0 || pitch == 0 || (pitch & 15u) || nsym > pitch) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: bad S / nsym / pitch", who);
+  if (p->binarization > 1 || p->selector > 1 || p->k > 4) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: unsupported binarisation / selector", who);
+  P->method = p->binarization;
+  P->k = p->k;
+  P->nq = p->nq;
+  P->selector = p->selector;
+  P->types = p->iss_types;
+  P->nlbp = p->nlbp;
+  *maxbins = max_bins_of(*P);
+  if (*maxbins == 0 || *maxbins > 32) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: nq = %u gives %u bins per symbol (supported: 1..32)", who, p->nq, *maxbins);
+  const int need = p->selector == ISSCABAC_SEL_DEMO ? 3 : (int)(7 * p->nlbp + 2);
+  if (p->selector == ISSCABAC_SEL_ISS && (p->nlbp < 1 || p->nlbp > 8)) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: nlbp must be 1..8", who);
+  if (nctx < need || nctx > 64) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: this selector uses %d contexts, nctx is %d (max 64)", who, need, nctx);
+  uint8_t init[64];
+  memset(init, 1, sizeof init);
+  for (int c = 0; c < nctx; c++) {
+    if ((ctx_init[c] >> 1) > 62) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63", who, c);
+    init[c] = ctx_init[c];
+  }
+  memcpy(init_words, init, 64);
+  return ISSCABAC_OK;
+}
+
+static int sym_grow(isscabac_engine *e, void **p, uint64_t *have, uint64_t need) {
+  if (*have >= need) return ISSCABAC_OK;
+  if (*p) HIP_TRY(e, hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(e, hipMalloc(p, need));
+  *have = need;
+  return ISSCABAC_OK;
+}
+
+extern "C" {
+
+uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *p) {
+  if (!p || p->binarization > 1) return 0;
+  SymParams P{p->binarization, p->k, p->nq, p->selector, p->iss_types, p->nlbp};
+  const uint32_t m = max_bins_of(P);
+  return m > 32 ? 0 : m;
+}
+
+int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
+                                uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                                uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes,
+                                uint32_t *d_nbins_out) {
+  SymEncArgs a;
+  uint32_t maxbins = 0;
+  int rc = sym_check(e, "isscabac_encode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins);
+  if (rc) return rc;
+  if (!d_sym || !d_payload || !d_offsets || (reinterpret_cast<uintptr_t>(d_sym) & 15u))
+    return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols_dev: null or misaligned buffer");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t stride = slot_stride_for(nsym * maxbins);
+  if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
+  if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
+  if ((rc = sym_grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
+  a.sym = d_sym;
+  a.nsym_per_stream = d_nsym;
+  a.slots = e->slots;
+  a.lens = e->lens;
+  a.nbins_out = d_nbins_out;
+  a.S = S;
+  a.slot_stride = stride;
+  a.nsym = nsym;
+  a.pitch = pitch;
+  a.nctx = (uint32_t)nctx;
+  const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
+  const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
+  hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
+  HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
+  uint64_t total = 0;
+  HIP_TRY(e, hipMemcpyAsync(&total, d_offsets + S, sizeof total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols_dev: payload needs %llu bytes, capacity is %llu",
+                       (unsigned long long)total, (unsigned long long)payload_cap);
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                                const uint32_t *d_nsym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *d_sym_out,
+                                uint32_t *d_status) {
+  SymDecArgs a;
+  uint32_t maxbins = 0;
+  int rc = sym_check(e, "isscabac_decode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins);
+  if (rc) return rc;
+  if (!d_payload || !d_offsets || !d_sym_out || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
+    return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols_dev: null or misaligned buffer");
+  HIP_TRY(e, hipSetDevice(e->device));
+  a.payload = d_payload;
+  a.offsets = d_offsets;
+  a.nsym_per_stream = d_nsym;
+  a.sym_out = d_sym_out;
+  a.status = d_status;
+  a.S = S;
+  a.payload_bytes = payload_bytes;
+  a.nsym = nsym;
+  a.pitch = pitch;
+  a.nctx = (uint32_t)nctx;
+  const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
+  const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
+  hipLaunchKernelGGL(k_decode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym,
+                            uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                            uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!sym || !payload || !offsets || !params) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols: null buffer");
+  const uint32_t maxbins = isscabac_symbol_max_bins(params);
+  if (maxbins == 0 || S == 0 || pitch == 0) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols: unsupported parameters");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t in_bytes = S * pitch, dev_cap = S * isscabac_stream_bound(nsym * maxbins);
+  int rc;
+  if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;
+  if ((rc = sym_grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
+  if ((rc = sym_grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = sym_grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, in_bytes, hipMemcpyHostToDevice, e->stream));
+  if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  uint64_t total = 0;
+  rc = isscabac_encode_symbols_dev(e, static_cast<uint8_t *>(e->stage[0]), nsym_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr,
+                                   S, nsym, pitch, params, ctx_init, nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap,
+                                   static_cast<uint64_t *>(e->stage[4]), &total, static_cast<uint32_t *>(e->stage[5]));
+  if (rc) return rc;
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols: payload needs %llu bytes, capacity is %llu",
+                       (unsigned long long)total, (unsigned long long)payload_cap);
+  HIP_TRY(e, hipMemcpyAsync(payload, e->stage[3], total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(offsets, e->stage[4], (S + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  if (nbins_out) HIP_TRY(e, hipMemcpyAsync(nbins_out, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint32_t *nsym_per_stream,
+                            uint64_t S, uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                            const uint8_t *ctx_init, int nctx, uint8_t *sym_out, uint32_t *status) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!payload || !offsets || !sym_out || !params || S == 0 || pitch == 0) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols: null buffer");
+  for (uint64_t s = 0; s < S; s++)
+    if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
+      return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols: offsets not monotone at stream %llu", (unsigned long long)s);
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t out_bytes = S * pitch, total = offsets[S];
+  int rc;
+  if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], out_bytes))) return rc;
+  if ((rc = sym_grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
+  if ((rc = sym_grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = sym_grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
+  if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[3], payload, total, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[4], offsets, (S + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  rc = isscabac_decode_symbols_dev(e, static_cast<uint8_t *>(e->stage[3]), total, static_cast<uint64_t *>(e->stage[4]),
+                                   nsym_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nsym, pitch, params, ctx_init,
+                                   nctx, static_cast<uint8_t *>(e->stage[0]), static_cast<uint32_t *>(e->stage[5]));
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(sym_out, e->stage[0], out_bytes, hipMemcpyDeviceToHost, e->stream));
+  if (status) HIP_TRY(e, hipMemcpyAsync(status, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+}  // extern "C"

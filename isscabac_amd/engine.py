@@ -24,6 +24,22 @@ _vp = C.c_void_p
 _lib = None
 
 
+class SymbolParams(C.Structure):
+    """isscabac_symbol_params: binarisation (0 TU, 1 EGk), k, nq, selector (0 demo, 1 ISS), iss_types, nlbp."""
+    _fields_ = [("binarization", C.c_uint32), ("k", C.c_uint32), ("nq", C.c_uint32), ("selector", C.c_uint32),
+                ("iss_types", C.c_uint32), ("nlbp", C.c_uint32)]
+
+    @classmethod
+    def demo(cls, nq):
+        """cabacDemo.m: TU binarisation, 3 contexts from the previous symbol's first bin."""
+        return cls(0, 0, nq, 0, 0, 0)
+
+    @classmethod
+    def iss(cls, nq, method="EG", k=0, types=15, nlbp=3):
+        """ISS defaults (ISS/ISS.m:49-53): EG0, {cond0, cond1, conds0, conds1}, Nlbp = 3 -> 23 contexts."""
+        return cls(0 if method == "TU" else 1, k, nq, 1, types, nlbp)
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("isscabac error %d: %s" % (code, msg))
@@ -62,6 +78,16 @@ def _load():
                                         _u8p, C.c_uint64, _u64p, _u64p]
     L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
                                         C.c_int, _u8p, _u32p]
+    L.isscabac_symbol_max_bins.argtypes = [C.POINTER(SymbolParams)]
+    L.isscabac_symbol_max_bins.restype = C.c_uint32
+    L.isscabac_encode_symbols_dev.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
+                                              _u8p, C.c_int, _vp, C.c_uint64, _vp, _u64p, _vp]
+    L.isscabac_decode_symbols_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                              C.POINTER(SymbolParams), _u8p, C.c_int, _vp, _vp]
+    L.isscabac_encode_symbols.argtypes = [_vp, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
+                                          _u8p, C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u32p]
+    L.isscabac_decode_symbols.argtypes = [_vp, _u8p, _u64p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                          C.POINTER(SymbolParams), _u8p, C.c_int, _u8p, _u32p]
     L.isscabac_stream_open.argtypes = [_vp, _u8p, C.c_int, C.POINTER(_vp)]
     L.isscabac_stream_close.argtypes = [_vp]
     L.isscabac_stream_close.restype = None
@@ -222,6 +248,43 @@ class Engine:
                                                   _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
                                                   _ptr(bins, _u8p), _ptr(status, _u32p)))
         return bins[:, :B].copy(), status
+
+    # ---- symbol-level batch calls (binariser + context selector fused on the device) --------------------
+    def encode_symbols(self, sym, params, ctx_init, nsym=None):
+        """sym: [S, R] uint8, one stream (column of symbols) per row.  Returns (payload, offsets, bins_per_stream)."""
+        sym = _np(sym, np.uint8)
+        S, R = sym.shape
+        pitch = max(16, (R + 15) // 16 * 16)
+        symp = self._pad_rows(sym, pitch)
+        ci = _np(ctx_init, np.uint8)
+        ns = None if nsym is None else _np(nsym, np.uint32)
+        mb = int(self._L.isscabac_symbol_max_bins(C.byref(params)))
+        if mb == 0:
+            raise EngineError(1, "unsupported symbol parameters")
+        cap = S * stream_bound(R * mb)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        nbins = np.zeros(S, np.uint32)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_symbols(self._h, _ptr(symp, _u8p), _ptr(ns, _u32p), S, R, pitch,
+                                                    C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
+                                                    _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p)))
+        return payload[:int(total.value)].copy(), offsets, nbins
+
+    def decode_symbols(self, payload, offsets, R, params, ctx_init, nsym=None):
+        """Returns (sym uint8[S, R], status uint32[S])."""
+        payload = _np(payload, np.uint8)
+        offsets = _np(offsets, np.uint64)
+        S = offsets.size - 1
+        pitch = max(16, (R + 15) // 16 * 16)
+        ci = _np(ctx_init, np.uint8)
+        ns = None if nsym is None else _np(nsym, np.uint32)
+        out = np.zeros((S, pitch), np.uint8)
+        status = np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_decode_symbols(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ns, _u32p), S,
+                                                    R, pitch, C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(out, _u8p),
+                                                    _ptr(status, _u32p)))
+        return out[:, :R].copy(), status
 
     # ---- raw device memory (for callers without torch) ---------------------------------------------------
     def alloc(self, nbytes):

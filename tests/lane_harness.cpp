@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "cabac_lane.h"
+#include "cabac_symbols.h"
 
 using namespace isscabac;
 
@@ -166,6 +167,65 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
     counters[2] = slow_refills;
   }
   return status;
+}
+
+
+// symbol-level front end (cabac_symbols.h): params = {method, k, nq, selector, types, nlbp}
+long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params, const uint8_t *ctx_init, int nctx,
+                       uint8_t *out, size_t cap, uint32_t *nbins_out) {
+  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5]};
+  HostStates st;
+  st.init(ctx_init, nctx);
+  HostSink sink{out, 0, cap};
+  EncCore e;
+  enc_start(e);
+  SymWalk w;
+  w.start();
+  uint32_t nbins = 0;
+  while (w.idx < nsym) {
+    if (w.n == 1) w.cur = binarize(sym[w.idx], P);
+    const uint32_t c = w.ctx(P);
+    enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
+    enc_flush(e, sink);
+    nbins++;
+    if (w.n == w.cur.len) w.next_symbol();
+    else w.n++;
+  }
+  enc_finish(e, sink);
+  if (nbins_out) *nbins_out = nbins;
+  return sink.len <= cap ? (long)sink.len : -1;
+}
+
+uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, const uint32_t *params,
+                           const uint8_t *ctx_init, int nctx, uint8_t *sym_out) {
+  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5]};
+  HostStates st;
+  st.init(ctx_init, nctx);
+  WindowSrc<HostMem> src;
+  src.mem = HostMem{payload, len, nullptr, nullptr};
+  src.len = len;
+  src.start(0);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  SymWalk w;
+  w.start();
+  uint32_t it = 0;
+  while (w.idx < nsym) {
+    if ((it++ & 15u) == 0) src.boundary();
+    if (d.sh < 8) dec_refill(d, src);
+    const uint32_t c = w.ctx(P);
+    const uint32_t bin = dec_bin(d, c, st);
+    w.cur.bits |= bin << (w.n - 1);
+    w.cur.len = w.n;
+    if (symbol_finished(w.cur, P) || w.n == 32) {
+      sym_out[w.idx] = (uint8_t)debinarize(w.cur, P);
+      w.next_symbol();
+    } else {
+      w.n++;
+    }
+  }
+  return dec_finish(d, len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
 }
 
 }  // extern "C"

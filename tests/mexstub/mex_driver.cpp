@@ -1,0 +1,69 @@
+// Test driver around matlab/SimpleCABACMex.cpp compiled against the stub mex.h: lets the Python tests build
+// argument arrays, call mexFunction with the reference's command strings and read results / error texts back.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mex.h"
+
+static std::string g_printed;
+static void (*g_atexit)(void) = nullptr;
+
+int mexPrintf(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  int n = vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_printed += buf;
+  return n;
+}
+int mexAtExit(void (*fn)(void)) {
+  g_atexit = fn;
+  return 0;
+}
+char *mxArrayToString(const mxArray *a) { return a->cls == mxCHAR_CLASS ? strdup(a->str.c_str()) : nullptr; }
+mxArray *mxCreateNumericMatrix(size_t m, size_t n, mxClassID cls, mxComplexity) {
+  mxArray *a = new mxArray;
+  a->cls = cls;
+  a->m = m;
+  a->n = n;
+  a->bytes.assign(m * n * mx_elsize(cls) + 8, 0);
+  return a;
+}
+
+extern "C" {
+void *drv_str(const char *s) {
+  mxArray *a = new mxArray;
+  a->cls = mxCHAR_CLASS;
+  a->m = 1;
+  a->n = strlen(s);
+  a->str = s;
+  return a;
+}
+void *drv_numeric(int cls, const void *data, size_t m, size_t n) {
+  mxArray *a = mxCreateNumericMatrix(m, n, (mxClassID)cls, mxREAL);
+  if (data) memcpy(a->bytes.data(), data, m * n * mx_elsize((mxClassID)cls));
+  return a;
+}
+void drv_free(void *a) { delete (mxArray *)a; }
+int drv_class(void *a) { return (int)((mxArray *)a)->cls; }
+size_t drv_m(void *a) { return ((mxArray *)a)->m; }
+size_t drv_n(void *a) { return ((mxArray *)a)->n; }
+void *drv_data(void *a) { return ((mxArray *)a)->bytes.data(); }
+// returns 0 on success, 1 if the gateway raised a MATLAB error (text in err)
+int drv_mex(int nlhs, void **plhs, int nrhs, void **prhs, char *err, int cap) {
+  try {
+    mexFunction(nlhs, (mxArray **)plhs, nrhs, (const mxArray **)prhs);
+  } catch (const MexError &e) {
+    snprintf(err, cap, "%s", e.what());
+    return 1;
+  }
+  return 0;
+}
+const char *drv_printed() { return g_printed.c_str(); }
+void drv_shutdown() {
+  if (g_atexit) g_atexit();
+  g_atexit = nullptr;
+}
+}

@@ -280,3 +280,67 @@ def test_single_stream_handle_per_bin_commands(engine, oracle, golden, tmp_path)
         enc.encodeBin(2, 0)
     with pytest.raises(RuntimeError):
         enc.getEncoderStats(0)
+
+
+def _quantised_matrix(rng, rows, cols, nq):
+    """stand-in for the quantiser output of ISS.m (group indices 0..nq-1, smooth along the rows like W/H columns)"""
+    x = np.abs(rng.normal(size=(rows, cols)))
+    for r in range(1, rows):
+        x[r] = 0.7 * x[r - 1] + 0.3 * x[r]
+    q = np.quantile(x, 0.99)
+    return np.minimum(np.floor(x / q * nq), nq - 1).astype(np.uint8)
+
+
+def test_config4_iss_columns_as_streams(engine, oracle):
+    """BASELINE config 4: quantised W (400 x 20) and H (109 x 20) columns as independent streams, Nq = 8, EG0
+    binarisation, ISS context selection (23 contexts) fused on the device.  Parity per column against the oracle's
+    restatement of ISS/+coder/cabacEncode.m:45-70 / cabacDecode.m:29-55 run on that column alone."""
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(2018)
+    for rows, cols, method, k, nq, types, nlbp in [(400, 20, "EG", 0, 8, 15, 3), (109, 20, "EG", 0, 8, 15, 3),
+                                                    (400, 20, "TU", 0, 8, 15, 3), (64, 130, "EG", 1, 16, 31, 2),
+                                                    (33, 70, "EG", 0, 200, 5, 4)]:
+        G = _quantised_matrix(rng, rows, cols, nq)
+        nctx = 7 * nlbp + 2
+        p0 = np.round(rng.uniform(0.05, 0.95, nctx) * 255) / 255  # uint8-quantised p(0), cabacEncode.m:30-31
+        init = init_by_prob(p0)
+        params = SymbolParams.iss(nq, method, k, types, nlbp)
+        payload, offsets, nbins = engine.encode_symbols(G.T.copy(), params, init)
+        for c in range(cols):
+            want, want_nb = oracle.iss_encode_column(G[:, c], nq, method, k, types, nlbp, init)
+            assert payload[int(offsets[c]):int(offsets[c + 1])].tobytes() == want.tobytes(), (rows, cols, method, c)
+            assert nbins[c] == want_nb
+        sym, status = engine.decode_symbols(payload, offsets, rows, params, init)
+        assert (status == 0).all()
+        assert (sym.T == G).all()
+
+
+def test_config1_demo_single_stream_and_ragged(engine, oracle):
+    """BASELINE config 1: cabacDemo.m -- one stream, TU-binarised symbols (Nq = 4), 3 contexts from the previous
+    symbol's first bin, initByProb(0.5).  Plus a ragged many-stream variant."""
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(0)
+    N, nq = 10000, 4
+    x = np.abs(rng.normal(size=N))
+    x[1:] += 0.8 * x[:-1]  # AR(1), cabacDemo.m:29-30
+    sym = np.minimum(np.floor(x / (np.quantile(x, 0.99) / nq) + 0.5), nq - 1).astype(np.uint8)
+    init = init_by_prob([0.5, 0.5, 0.5])
+    params = SymbolParams.demo(nq)
+    payload, offsets, nbins = engine.encode_symbols(sym[None, :], params, init)
+    want, want_nb = oracle.demo_encode(sym, nq, init)
+    assert payload.tobytes() == want.tobytes() and nbins[0] == want_nb
+    dec, status = engine.decode_symbols(payload, offsets, N, params, init)
+    assert status[0] == 0 and (dec[0] == sym).all()
+    S, R = 150, 333
+    syms = rng.integers(0, nq, (S, R)).astype(np.uint8)
+    ns = rng.integers(0, R + 1, S).astype(np.uint32)
+    ns[:3] = [0, 1, R]
+    payload, offsets, nbins = engine.encode_symbols(syms, params, init, ns)
+    for s in range(S):
+        want, want_nb = oracle.demo_encode(syms[s, :ns[s]], nq, init)
+        assert payload[int(offsets[s]):int(offsets[s + 1])].tobytes() == want.tobytes()
+        assert nbins[s] == want_nb
+    dec, status = engine.decode_symbols(payload, offsets, R, params, init, ns)
+    assert (status == 0).all()
+    for s in range(S):
+        assert (dec[s, :ns[s]] == syms[s, :ns[s]]).all() and (dec[s, ns[s]:] == 0).all()

@@ -11,6 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "lane_harness.cpp")
 HDR = os.path.join(ROOT, "isscabac_amd", "csrc", "cabac_lane.h")
+HDR2 = os.path.join(ROOT, "isscabac_amd", "csrc", "cabac_symbols.h")
 OUT = os.path.join(ROOT, "tests", "_build", "liblane_harness.so")
 u8p = C.POINTER(C.c_uint8)
 
@@ -18,7 +19,7 @@ u8p = C.POINTER(C.c_uint8)
 @pytest.fixture(scope="module")
 def lane():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=undefined",
                                "-fno-sanitize-recover=undefined", "-I", os.path.dirname(HDR), SRC, "-o", OUT])
     L = C.CDLL(OUT)
@@ -28,6 +29,11 @@ def lane():
     L.lane_decode_stream.restype = C.c_uint32
     L.lane_decode_stream.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
                                      C.c_int, u8p, u8p, C.POINTER(C.c_uint32)]
+    L.sym_encode_stream.restype = C.c_long
+    L.sym_encode_stream.argtypes = [u8p, C.c_uint32, C.POINTER(C.c_uint32), u8p, C.c_int, u8p, C.c_size_t,
+                                    C.POINTER(C.c_uint32)]
+    L.sym_decode_stream.restype = C.c_uint32
+    L.sym_decode_stream.argtypes = [u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), u8p, C.c_int, u8p]
     return L
 
 
@@ -136,3 +142,47 @@ def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
         assert st == st_want
         flagged += st != 0
     assert flagged > 100
+
+
+def _sym_roundtrip(L, sym, params, init):
+    sym = np.ascontiguousarray(sym, np.uint8)
+    init = np.ascontiguousarray(init, np.uint8)
+    par = (C.c_uint32 * 6)(*params)
+    out = np.zeros(sym.size * 8 + 64, np.uint8)
+    nb = C.c_uint32(0)
+    n = L.sym_encode_stream(_p(sym), sym.size, par, _p(init), init.size, _p(out), out.size, C.byref(nb))
+    assert n > 0
+    dec = np.zeros(max(1, sym.size), np.uint8)
+    st = L.sym_decode_stream(_p(out), n, sym.size, par, _p(init), init.size, _p(dec))
+    return out[:n], nb.value, dec[:sym.size], st
+
+
+def test_symbol_front_end_vs_oracle(lane, oracle):
+    """binariser + context selectors + coder, host build of cabac_symbols.h, against the oracle's restatement of
+    cabacDemo.m (TU, 3 contexts) and of one column of +coder/cabacEncode.m / cabacDecode.m (ISS selector)."""
+    rng = np.random.default_rng(17)
+    for it in range(60):
+        nq = int(rng.choice([2, 3, 4, 8]))
+        sym = np.minimum(np.abs(rng.normal(size=int(rng.integers(1, 500))) * nq / 2).astype(np.uint32), nq - 1)
+        init = rng.integers(0, 126, 3).astype(np.uint8)
+        want, want_nb = oracle.demo_encode(sym, nq, init)
+        got, nb, dec, st = _sym_roundtrip(lane, sym, (0, 0, nq, 0, 0, 0), init)
+        assert got.tobytes() == want.tobytes() and nb == want_nb
+        assert st == 0 and (dec == sym).all()
+    for it in range(120):
+        nq = int(rng.choice([2, 4, 8, 16, 200]))
+        method = "TU" if (it % 3 == 0 and nq <= 16) else "EG"
+        k = 0 if method == "TU" else int(rng.choice([0, 0, 1, 2]))
+        nlbp = int(rng.choice([1, 2, 3, 4]))
+        types = int(rng.choice([15, 0, 1, 2, 4, 8, 31, 5, 26]))
+        nctx = 7 * nlbp + 2
+        rows = int(rng.integers(1, 420))
+        sym = np.minimum(np.abs(rng.normal(size=rows) * nq / 3).astype(np.uint32), nq - 1)
+        init = rng.integers(0, 126, nctx).astype(np.uint8)
+        want, want_nb = oracle.iss_encode_column(sym, nq, method, k, types, nlbp, init)
+        got, nb, dec, st = _sym_roundtrip(lane, sym, (0 if method == "TU" else 1, k, nq, 1, types, nlbp), init)
+        assert got.tobytes() == want.tobytes(), (it, nq, method, k, nlbp, types)
+        assert nb == want_nb
+        assert st == 0 and (dec == sym).all()
+        back, st2 = oracle.iss_decode_column(want, rows, nq, method, k, types, nlbp, init)
+        assert st2 == 0 and (back == sym).all()
