@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "lib", "libisscabac_hip.so")
+# ISSCABAC_LIB selects another build of the same ABI (A/B experiments: tools/ab_bench.py)
+LIB = os.environ.get("ISSCABAC_LIB") or os.path.join(HERE, "lib", "libisscabac_hip.so")
 SOURCES = ["cabac_kernels.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_capi.cpp"]
 HEADERS = ["cabac_lane.h", "cabac_symbols.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
 
@@ -36,6 +37,15 @@ def build_lib(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+def build_variant(tag, defines):
+    """Same sources with extra -D flags -> lib/variant_<tag>.so (A/B experiments, see tools/ab_bench.py)."""
+    out = os.path.join(HERE, "lib", "variant_%s.so" % tag)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
+          ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES]
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

@@ -41,6 +41,16 @@ struct NextTab {
 };
 __device__ const NextTab c_next{};
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the nontemporal builtins accept
+__device__ __forceinline__ uint4 nt_load16(const uint8_t *p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
+  u32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
+}
+
 constexpr int kWavesPerBlock = 4;
 constexpr int kTabBytes = 512;
 
@@ -91,7 +101,11 @@ struct Tile {
       uint64_t s = s0 + row_of(k, lane);
       s = s < S ? s : S - 1;
       const uint32_t boff = off + ch_of(lane) * 16;
+#ifdef ISSCABAC_NT_STREAMS
+      r[k] = boff < pitch ? nt_load16(base + s * pitch + boff) : make_uint4(0, 0, 0, 0);
+#else
       r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(base + s * pitch + boff) : make_uint4(0, 0, 0, 0);
+#endif
     }
   }
   // half h (0: bytes 0..31 of the round, 1: bytes 32..63) of the registers -> LDS
@@ -143,15 +157,25 @@ struct LdsStates {
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
+#ifdef ISSCABAC_ABL_NO_STATE_LDS
+  __device__ __forceinline__ uint32_t load(uint32_t c) const { return (c * 37u) & 0xFCu; }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { asm volatile("" ::"v"(c), "v"(p)); }
+#else
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
+#endif
   // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
+#ifdef ISSCABAC_ABL_NO_BPERM
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return row_tab ^ (q * 0x01010101u & 0x0F0F0F0Fu) | 0x10101010u; }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return next_tab + q; }
+#else
   __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
   }
   __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
   }
+#endif
 };
 // <= 4 contexts: the four state bytes live in one VGPR
 template <bool XBAR>
@@ -340,7 +364,7 @@ struct DevMem {
   struct alignas(4) Q4 { uint32_t w[4]; };
   struct Pair { uint64_t lo, hi; };
   // the last few bytes of the whole payload buffer: never read past its end
-  static __device__ __noinline__ Pair load16_tail(const uint8_t *base, uint64_t avail, uint32_t off) {
+  static __device__ __forceinline__ Pair load16_tail(const uint8_t *base, uint64_t avail, uint32_t off) {
     Pair r{0, 0};
     for (uint32_t i = 0; i < 16; i++) {
       const uint64_t b = (uint64_t)off + i < avail ? base[off + i] : 0;
@@ -373,8 +397,17 @@ struct DecArgs {
   uint32_t ctx_init[64];
 };
 
+// experiment knobs (tools/ab_bench.py builds variants with -D...).  ISSCABAC_ABL_* builds are TIMING-ONLY: they drop
+// one piece of work to price it, their results are wrong.
+#ifndef ISSCABAC_DEC_OCC
+#define ISSCABAC_DEC_OCC 3  // waves per SIMD the decode kernel is register-limited to (3 vs 4 measured equal)
+#endif
+#ifndef ISSCABAC_DEC_ROLLED
+#define ISSCABAC_DEC_ROLLED 1  // 1: loop over the chunk's four words, 0: all 16 bins unrolled
+#endif
+
 template <int CM>
-__global__ void __launch_bounds__(256, 3) k_decode(DecArgs a) {
+__global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -427,68 +460,116 @@ __global__ void __launch_bounds__(256, 3) k_decode(DecArgs a) {
   DecCore d;
   dec_start(d, src);
 
+  // decoded bins are kept as BITS in LDS, 128 bins (16 bytes) per stream, and leave as full 128-byte row segments:
+  // 32-byte segment stores were measured at 1.35 TB/s, 128-byte ones at 4 TB/s (tools/ubench/tile_bw.hip)
+  uint16_t *obits = reinterpret_cast<uint16_t *>(tile_o);  // [8 chunks][64 lanes]
+  auto store_out = [&](uint32_t off) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t row = k * 8 + (lane >> 3), c = lane & 7;
+      const uint32_t bits = obits[c * 64 + row];
+      uint4 v;
+      v.x = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;  // 4 bits -> 4 bytes of 0/1
+      v.y = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+      v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+      v.w = ((bits >> 12) * 0x00204081u) & 0x01010101u;
+      const uint64_t s_row = s0 + row;
+      const uint32_t boff = off + c * 16;
+#ifndef ISSCABAC_ABL_NO_STORE
+#ifdef ISSCABAC_NT_STREAMS
+      if (s_row < a.S && boff < a.pitch) nt_store16(a.bins_out + s_row * a.pitch + boff, v);
+#else
+      if (s_row < a.S && boff < a.pitch) *reinterpret_cast<uint4 *>(a.bins_out + s_row * a.pitch + boff) = v;
+#endif
+#endif
+    }
+  };
+
   const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
   uint4 pc[Tile::NLD];
   if (nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
   wave_lds_sync();
+  bool have_out = false;
+  uint32_t out_off = 0;
   for (uint32_t t = 0; t < nrounds; t++) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       Tile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-      if (h == 1 && t + 1 < nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
-        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-        if (i0 < a.nbins) {
+        const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output tile
+        uint32_t ob = 0;
+        const bool live = i0 < a.nbins;
+#ifndef ISSCABAC_ABL_NO_PAYLOAD
+        if (live) src.boundary();
+#else
+        src.cnt = 8;
+#endif
+        if (j == 0) {
+          // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
+          // anything issued just before the boundary's wait for the payload piece would be waited for as well
+          if (have_out) {
+            store_out(out_off);
+            wave_lds_sync();  // the bit tile is rewritten from here on
+            have_out = false;
+          }
+          if (h == 1 && t + 1 < nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+        }
+        if (live) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
           const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
-          src.boundary();
           if (full && !hi) {
-            // context bins only: a top-up leaves sh >= 16 and a context bin takes at most 6 bits, so two bins
-            // per top-up never see sh < 7 and need no look-ahead guard
-            uint32_t o[4] = {0, 0, 0, 0};
+            // context bins only: a top-up leaves sh >= 16 and a context bin takes at most 6 bits, so two bins per
+            // top-up never see sh < 7 and need no look-ahead guard; the window is re-based every 8 bins, which
+            // covers the 4 x 2 bytes four top-ups can take
+#if ISSCABAC_DEC_ROLLED
+#pragma unroll 1
+#else
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-              if ((k & 1) == 0) dec_topup(d, src);
-              o[k >> 2] |= dec_bin(d, byte_of(wc, k), stx) << (8 * (k & 3));
-            }
-            o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
-          } else if (full) {
-            uint32_t o[4] = {0, 0, 0, 0};
+#endif
+            for (int g = 0; g < 4; g++) {  // rolled over the four words: keeps the live register set small
+#ifndef ISSCABAC_ABL_NO_PAYLOAD
+              if (g == 2) src.rebase();
+#else
+              src.cnt = 8;
+#endif
+              const uint32_t cw = word_of(wc, g);
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-              if ((k & 3) == 0) dec_topup(d, src);
-              if (wave_any(d.sh < 8)) {
-                if (d.sh < 8) dec_refill(d, src);
+              for (int k = 0; k < 4; k++) {
+                if ((k & 1) == 0) dec_topup_nocheck(d, src);
+                ob |= dec_bin(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
               }
-              o[k >> 2] |= dec_bin_any(d, byte_of(wc, k), stx) << (8 * (k & 3));
             }
-            o0 = o[0], o1 = o[1], o2 = o[2], o3 = o[3];
           } else {
-#pragma unroll 4
+            // bypass bins / contexts >= 128 somewhere in the wave, or ragged end: one rolled loop, per-bin guard;
+            // tables from LDS memory when lanes have dropped out (bpermute cannot read inactive lanes)
+#pragma unroll 1
             for (int k = 0; k < 16; k++) {
-              if ((k & 3) == 0) dec_topup(d, src);
               if (i0 + k < n) {
                 if (d.sh < 8) dec_refill(d, src);
                 const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-                const uint32_t sel = dec_bin_any(d, cx, stm) << (8 * (k & 3));
-                if ((k >> 2) == 0) o0 |= sel;
-                else if ((k >> 2) == 1) o1 |= sel;
-                else if ((k >> 2) == 2) o2 |= sel;
-                else o3 |= sel;
+                ob |= (full ? dec_bin_any(d, cx, stx) : dec_bin_any(d, cx, stm)) << k;
               }
             }
           }
         }
-        Tile::put_row_chunk(tile_o, lane, j, make_uint4(o0, o1, o2, o3));
+        obits[cidx * 64 + lane] = (uint16_t)ob;
       }
       wave_lds_sync();
-      Tile::store_half(a.bins_out, tile_o, s0, a.S, a.pitch, t * Tile::T + h * Tile::H, lane);
-      wave_lds_sync();
+    }
+    if ((t & 1u) == 1u || t + 1 == nrounds) {  // a 128-bin output tile is complete (or the stream ends)
+      have_out = true;
+      out_off = (t & ~1u) * Tile::T;
+      if (t + 1 == nrounds && (t & 1u) == 0) {
+        // odd number of rounds: the upper half of the last tile was never written
+        for (int c = 4; c < 8; c++) obits[c * 64 + lane] = 0;
+        wave_lds_sync();
+      }
     }
   }
+  if (have_out) store_out(out_off);
   if (valid && a.status) {
     const uint8_t *p = a.payload + start;
     a.status[s] = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });

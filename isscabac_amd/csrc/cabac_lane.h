@@ -29,7 +29,7 @@
 
 #if defined(__HIPCC__)
 #define CABAC_HD __host__ __device__ __forceinline__
-#define CABAC_HD_RARE __host__ __device__ __noinline__
+#define CABAC_HD_RARE __host__ __device__ __forceinline__
 #else
 #define CABAC_HD inline
 #define CABAC_HD_RARE inline
@@ -296,6 +296,16 @@ CABAC_HD void dec_topup(DecCore &d, Src &src) {
   d.nread += k;
 }
 
+// the same when the caller knows the window holds at least two bytes (the kernels' fast path re-bases the window
+// every 8 bins = 4 top-ups of <= 2 bytes): no availability test, no branch
+template <class Src>
+CABAC_HD void dec_topup_nocheck(DecCore &d, Src &src) {
+  const uint32_t k = (uint32_t)(23 - d.sh) >> 3;
+  d.v = (d.v << (8u * k)) | src.take_nocheck(k);
+  d.sh += (int32_t)(8u * k);
+  d.nread += k;
+}
+
 template <class Src>
 CABAC_HD void dec_start(DecCore &d, Src &src) {  // ref: CABAC_ArithmeticDecoder.cpp:54-71
   d.range = 510;
@@ -432,8 +442,12 @@ struct WindowSrc {
   uint32_t pos;   // offset of the next byte to hand out
   uint64_t cur;   // next bytes, big endian (next byte in bits 63..56)
   int32_t cnt;    // valid bytes in cur
+  // piece in use: bytes [ppos, ppos + 16), complete (no load pending on these registers)
+  uint64_t plo, phi;
+  uint32_t ppos;
+  // piece in flight: bytes [npos, npos + 16), written by the most recent prefetch()
   uint64_t nlo, nhi;
-  uint32_t npos;  // nlo/nhi hold bytes [npos, npos + 16)
+  uint32_t npos;
 
   CABAC_HD void prefetch() {
     npos = pos & ~3u;
@@ -463,20 +477,30 @@ struct WindowSrc {
     cnt = 0;
     cur = 0;
     prefetch();
+    plo = phi = 0;
+    ppos = npos;
   }
-  // re-base cur on the prefetched piece; fetch a new piece only once 4 of its bytes are used up, so that
-  // on average every payload byte is requested ~2x instead of ~10x (the re-reads were missing in L2)
-  CABAC_HD void boundary() {
-    const uint32_t d = pos - npos;
+  // re-base cur on the piece in use: cur = the 8 bytes at pos.  Touches no register with a load in flight.
+  CABAC_HD void rebase() {
+    const uint32_t d = pos - ppos;
     if (d <= 8u) {
-      const uint64_t x = d == 0 ? nlo : (d == 8u ? nhi : (nlo >> (8u * d)) | (nhi << (64u - 8u * d)));
+      const uint64_t x = d == 0 ? plo : (d == 8u ? phi : (plo >> (8u * d)) | (phi << (64u - 8u * d)));
       cur = __builtin_bswap64(x);
       cnt = 8;
       eof_fill();
     } else {
       reload_blocking();  // more than 8 bytes into the piece: rare
     }
-    if (d >= 4u) prefetch();
+  }
+  // every 16 bins: adopt the piece fetched one boundary ago (the only point that waits for a payload load), re-base,
+  // and fetch a new piece once 4 bytes of the current one are used up -- on average every payload byte is requested
+  // ~2x instead of ~10x (the re-reads were missing in L2)
+  CABAC_HD void boundary() {
+    plo = nlo;
+    phi = nhi;
+    ppos = npos;
+    rebase();
+    if (pos - npos >= 4u) prefetch();
   }
   CABAC_HD uint32_t next() {
     if (cnt == 0) reload_blocking();
@@ -486,17 +510,20 @@ struct WindowSrc {
     pos++;
     return b;
   }
+  CABAC_HD uint32_t take_nocheck(uint32_t k) {  // k in 0..2, cnt >= k guaranteed by the caller
+    const uint32_t x = (uint32_t)(cur >> 48) >> (16u - 8u * k);
+    cur <<= 8u * k;
+    cnt -= (int32_t)k;
+    pos += k;
+    return x;
+  }
   CABAC_HD uint32_t take(uint32_t k) {  // k in 0..2
     if ((int32_t)k > cnt) {
       uint32_t x = 0;
       for (uint32_t i = 0; i < k; i++) x = (x << 8) | next();
       return x;
     }
-    const uint32_t x = (uint32_t)(cur >> 48) >> (16u - 8u * k);
-    cur <<= 8u * k;
-    cnt -= (int32_t)k;
-    pos += k;
-    return x;
+    return take_nocheck(k);
   }
 };
 

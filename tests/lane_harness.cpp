@@ -139,7 +139,15 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   dec_start(d, src);
   for (uint32_t i = 0; i < n; i++) {
     if (i % (uint32_t)chunk == 0) src.boundary();
-    if (i % (uint32_t)group == 0) dec_topup(d, src);
+    else if (noguard && i % 8 == 0) src.rebase();
+    if (i % (uint32_t)group == 0) {
+      if (noguard) {
+        if (src.cnt < 2) return 0xDEAD1000u | i;  // the no-check top-up would be wrong
+        dec_topup_nocheck(d, src);
+      } else {
+        dec_topup(d, src);
+      }
+    }
     if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
         ctx[i + 3] != kBypass) {
       uint32_t cw;
