@@ -212,7 +212,11 @@ struct SlotSink {
     pos++;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
+#ifndef ISSCABAC_ABL_NO_SLOT_STORE
       if (on) *reinterpret_cast<uint4 *>(slot + pos - 16) = v;
+#else
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
     }
   }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
@@ -324,7 +328,11 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             enc_bin(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+#ifndef ISSCABAC_ABL_NO_FLUSH
             if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
+#else
+            if ((k & 3) == 3) { e.W &= 15; }
+#endif
           }
         } else if (full) {
           // bypass bins (or contexts >= 128) somewhere in the wave: combined step, still convergent
