@@ -142,6 +142,10 @@ typedef struct {
   uint32_t selector;     /* ISSCABAC_SEL_* */
   uint32_t iss_types;
   uint32_t nlbp;
+  uint32_t col_rows;     /* 0: each stream is one column.  > 0: each stream is a whole matrix stored column after column
+                            with col_rows rows; the "one row up" neighbour restarts at every column while coder and
+                            context states carry on -- the reference's one-file-per-matrix mode,
+                            ref: ISS/+coder/cabacEncode.m:45-70 */
 } isscabac_symbol_params;
 
 /* d_sym: device [S * pitch] uint8; d_nsym: per-stream symbol counts or NULL => nsym; d_nbins_out: optional S x u32,
@@ -163,6 +167,18 @@ int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const ui
                             const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym, uint32_t pitch,
                             const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
                             uint8_t *sym_out, uint32_t *status);
+/* Empirical context initialisation for the ISS selector: p(0) of every one of the 7*nlbp+2 contexts, counted over the
+ * binarised symbol matrix (one column per stream, all columns together) -- a histogram reduction on the device,
+ * ratios in double on the host exactly as the reference forms them.
+ * ref: ISS/+coder/cabacInitContextModel.m:1-130; p0_bytes_out = uint8(p0 * 255) as ISS/+coder/cabacEncode.m:30-31
+ * transmits it (feed p0_bytes_out[c] / 255.0 to isscabac_init_by_prob, as cabacEncode.m:31 / cabacDecode.m:13 do).
+ * Either output may be NULL. */
+int isscabac_iss_init_context_model_dev(isscabac_engine *e, const uint8_t *d_sym, uint64_t S, uint32_t nsym,
+                                        uint32_t pitch, const isscabac_symbol_params *params, double *p0_out,
+                                        uint8_t *p0_bytes_out);
+int isscabac_iss_init_context_model(isscabac_engine *e, const uint8_t *sym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                    const isscabac_symbol_params *params, double *p0_out, uint8_t *p0_bytes_out);
+
 /* most bins one symbol can binarise to under `params` (0 if the parameters are not supported) */
 uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
 

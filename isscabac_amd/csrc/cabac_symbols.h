@@ -24,6 +24,9 @@ struct SymParams {
   uint32_t selector;  // 0 = demo (3 contexts), 1 = ISS (7*nlbp+2 contexts)
   uint32_t types;     // ISS: 1 cond0, 2 cond1, 4 conds0, 8 conds1, 16 condbinlft
   uint32_t nlbp;
+  uint32_t col_rows;  // > 0: the stream is a whole matrix walked column by column (rows = col_rows); the symbol "one
+                      // row up" does not exist for the first symbol of every column (ref: cabacEncode.m:52), while
+                      // the coder and the adaptive context states run on across columns.  0: one column per stream.
 };
 
 struct BinString {
@@ -133,12 +136,13 @@ struct SymWalk {
   CABAC_HD uint32_t ctx(const SymParams &P) const {
     return P.selector == 0 ? demo_ctx(n, idx > 0, prev_first) : iss_ctx(n, cur, up, P);
   }
-  CABAC_HD void next_symbol() {
+  CABAC_HD void next_symbol(const SymParams &P) {
     up = cur;
     prev_first = cur.bits & 1u;
     idx++;
     n = 1;
     cur.bits = cur.len = 0;
+    if (P.col_rows && idx % P.col_rows == 0) up.bits = up.len = 0;  // first row of the next column
   }
 };
 

@@ -4,6 +4,7 @@
 // Used by BASELINE config 1 (cabacDemo: TU, 3 contexts) and config 4 (ISS W/H columns: EG0, 23 contexts).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "cabac_internal.h"
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
     enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
     enc_flush(e, sink);
     nbins++;
-    if (w.n == w.cur.len) w.next_symbol();
+    if (w.n == w.cur.len) w.next_symbol(a.P);
     else w.n++;
   }
   enc_finish(e, sink);
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     w.cur.len = w.n;
     if (symbol_finished(w.cur, a.P) || w.n == 32) {
       row[w.idx] = (uint8_t)debinarize(w.cur, a.P);
-      w.next_symbol();
+      w.next_symbol(a.P);
     } else {
       w.n++;
     }
@@ -192,6 +193,90 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     const uint8_t *p = a.payload + start;
     a.status[s] = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
+}
+
+// ---- empirical context initialisation (ISS/+coder/cabacInitContextModel.m) -----------------------------------------
+// per bin position n = 1..nlbp: 17 counters, then 4 for the two "rest" contexts
+enum { ST_A_PRE, ST_Z_PRE, ST_D_C, ST_J_C0, ST_Y0_C, ST_J_C1, ST_Y1_C, ST_D_B, ST_J_B, ST_X1_B, ST_D_S, ST_Z_S, ST_D_CS,
+       ST_J_CS0, ST_Y0_CS, ST_J_CS1, ST_Y1_CS, ST_PER_N };
+constexpr int kMaxStat = 8 * ST_PER_N + 4;
+
+__global__ void __launch_bounds__(256) k_iss_ctx_stats(const uint8_t *sym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                                       SymParams P, unsigned long long *counts) {
+  __shared__ unsigned int hist[kMaxStat];
+  const int nstat = (int)P.nlbp * ST_PER_N + 4;
+  for (int i = threadIdx.x; i < nstat; i += 256) hist[i] = 0;
+  __syncthreads();
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid < S * nsym) {
+    const uint64_t col = gid / nsym;
+    const uint32_t d = (uint32_t)(gid % nsym);
+    const uint8_t *row = sym + col * pitch;
+    const BinString cur = binarize(row[d], P);
+    uint32_t np = first_zero_1based(cur.bits, cur.len);
+    if (!np) np = cur.len;
+    // the cell above the first row is a NaN in the reference: length 1, np_up1 = 0, equal to neither 0 nor 1
+    BinString up{0, 1};
+    uint32_t np_up = 0;
+    const bool nan_up = d == 0;
+    if (!nan_up) {
+      up = binarize(row[d - 1], P);
+      np_up = first_zero_1based(up.bits, up.len);
+      if (!np_up) np_up = up.len;
+    }
+    auto bit = [](BinString g, uint32_t i) { return (g.bits >> (i - 1)) & 1u; };  // 1-based
+    for (uint32_t n = 1; n <= P.nlbp; n++) {
+      unsigned int *h = hist + (n - 1) * ST_PER_N;
+      if (n <= np) {
+        atomicAdd(&h[ST_A_PRE], 1u);
+        if (bit(cur, n) == 0) atomicAdd(&h[ST_Z_PRE], 1u);
+      }
+      if (n <= np && n <= np_up) {  // np_up == 0 on the first row
+        const uint32_t y = bit(up, n), x = bit(cur, n);
+        atomicAdd(&h[ST_D_C], 1u);
+        if (y == 0) atomicAdd(&h[ST_Y0_C], 1u);
+        else atomicAdd(&h[ST_Y1_C], 1u);
+        if (x == 0 && y == 0) atomicAdd(&h[ST_J_C0], 1u);
+        if (x == 0 && y == 1) atomicAdd(&h[ST_J_C1], 1u);
+      }
+      if (n + 1 <= np && np_up < n + 1) {
+        atomicAdd(&h[ST_D_B], 1u);
+        if (bit(cur, n) == 1) {
+          atomicAdd(&h[ST_X1_B], 1u);
+          if (bit(cur, n + 1) == 0) atomicAdd(&h[ST_J_B], 1u);
+        }
+      }
+      if (n + np <= cur.len) {
+        atomicAdd(&h[ST_D_S], 1u);
+        if (bit(cur, n + np) == 0) atomicAdd(&h[ST_Z_S], 1u);
+        if (n + np_up <= up.len) {
+          atomicAdd(&h[ST_D_CS], 1u);
+          if (!nan_up) {
+            const uint32_t ys = bit(up, n + np_up), yn = bit(up, n), x = bit(cur, n + np);
+            if (x == 0 && ys == 0) atomicAdd(&h[ST_J_CS0], 1u);
+            if (x == 0 && ys == 1) atomicAdd(&h[ST_J_CS1], 1u);
+            if (yn == 0) atomicAdd(&h[ST_Y0_CS], 1u);  // the reference normalises with y(n), not y(n + np_up1) (:96,:108)
+            else atomicAdd(&h[ST_Y1_CS], 1u);
+          }
+        }
+      }
+    }
+    unsigned int *r = hist + P.nlbp * ST_PER_N;
+    const uint32_t n = P.nlbp + 1;
+    if (n <= np) {
+      const uint32_t cnt = np - n + 1, seg = (cur.bits >> (n - 1)) & low_mask(cnt);
+      atomicAdd(&r[0], cnt);
+      atomicAdd(&r[1], cnt - (uint32_t)__popc(seg));
+    }
+    if (n > np && n <= cur.len) {
+      const uint32_t cnt = cur.len - n + 1, seg = (cur.bits >> (n - 1)) & low_mask(cnt);
+      atomicAdd(&r[2], cnt);
+      atomicAdd(&r[3], cnt - (uint32_t)__popc(seg));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nstat; i += 256)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }
 
 static uint32_t max_bins_of(const SymParams &P) {
@@ -228,6 +313,7 @@ static int sym_check(isscabac_engine *e, const char *who, uint64_t S, uint32_t n
   P->selector = p->selector;
   P->types = p->iss_types;
   P->nlbp = p->nlbp;
+  P->col_rows = p->col_rows;
   *maxbins = max_bins_of(*P);
   if (*maxbins == 0 || *maxbins > 32) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: nq = %u gives %u bins per symbol (supported: 1..32)", who, p->nq, *maxbins);
   const int need = p->selector == ISSCABAC_SEL_DEMO ? 3 : (int)(7 * p->nlbp + 2);
@@ -253,11 +339,77 @@ static int sym_grow(isscabac_engine *e, void **p, uint64_t *have, uint64_t need)
   return ISSCABAC_OK;
 }
 
+// counts -> p(0) exactly as cabacInitContextModel.m forms them (joint / norm in double), and uint8(p * 255)
+static void finalize_ctx_stats(const SymParams &P, const unsigned long long *cnt, double *p0, uint8_t *bytes) {
+  const int N = (int)P.nlbp, total = 7 * N + 2;
+  double tmp[7 * 8 + 2];
+  for (int i = 0; i < total; i++) tmp[i] = 0.0;
+  auto ratio = [](unsigned long long a, unsigned long long b) { return b ? (double)a / (double)b : 0.0; };
+  auto cond = [&](unsigned long long joint, unsigned long long den, unsigned long long ycount) {
+    const double norm = (den && ycount) ? (double)ycount / (double)den : 1.0;
+    return ratio(joint, den) / norm;
+  };
+  for (int n = 0; n < N; n++) {
+    const unsigned long long *h = cnt + n * ST_PER_N;
+    tmp[n] = ratio(h[ST_Z_PRE], h[ST_A_PRE]);
+    if (P.types & 1u) tmp[N + n] = cond(h[ST_J_C0], h[ST_D_C], h[ST_Y0_C]);
+    if (P.types & 2u) tmp[2 * N + n] = cond(h[ST_J_C1], h[ST_D_C], h[ST_Y1_C]);
+    if (P.types & 16u) tmp[3 * N + n] = cond(h[ST_J_B], h[ST_D_B], h[ST_X1_B]);
+    tmp[4 * N + n] = ratio(h[ST_Z_S], h[ST_D_S]);
+    if (P.types & 4u) tmp[5 * N + n] = cond(h[ST_J_CS0], h[ST_D_CS], h[ST_Y0_CS]);
+    if (P.types & 8u) tmp[6 * N + n] = cond(h[ST_J_CS1], h[ST_D_CS], h[ST_Y1_CS]);
+  }
+  const unsigned long long *r = cnt + N * ST_PER_N;
+  tmp[7 * N] = ratio(r[1], r[0]);
+  tmp[7 * N + 1] = ratio(r[3], r[2]);
+  for (int i = 0; i < total; i++) {
+    if (p0) p0[i] = tmp[i];
+    if (bytes) {
+      double x = std::floor(tmp[i] * 255.0 + 0.5);  // MATLAB uint8(): nearest, ties away from zero, saturating
+      bytes[i] = (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
+    }
+  }
+}
+
 extern "C" {
+
+int isscabac_iss_init_context_model_dev(isscabac_engine *e, const uint8_t *d_sym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                        const isscabac_symbol_params *p, double *p0_out, uint8_t *p0_bytes_out) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!d_sym || !p || S == 0 || nsym == 0 || nsym > pitch) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model_dev: bad argument");
+  if (p->nlbp < 1 || p->nlbp > 8 || p->binarization > 1 || p->k > 4) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model_dev: unsupported parameters");
+  SymParams P{p->binarization, p->k, p->nq, 1u, p->iss_types, p->nlbp, 0u};
+  const uint32_t mb = max_bins_of(P);
+  if (mb == 0 || mb > 32) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model_dev: nq = %u not supported", p->nq);
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = sym_grow(e, &e->scan_tmp, &e->scan_tmp_bytes, kMaxStat * sizeof(unsigned long long));
+  if (rc) return rc;
+  unsigned long long *d_counts = static_cast<unsigned long long *>(e->scan_tmp);
+  HIP_TRY(e, hipMemsetAsync(d_counts, 0, kMaxStat * sizeof(unsigned long long), e->stream));
+  const uint64_t nblk = (S * nsym + 255) / 256;
+  hipLaunchKernelGGL(k_iss_ctx_stats, dim3((unsigned)nblk), dim3(256), 0, e->stream, d_sym, S, nsym, pitch, P, d_counts);
+  HIP_TRY(e, hipGetLastError());
+  unsigned long long counts[kMaxStat];
+  HIP_TRY(e, hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  finalize_ctx_stats(P, counts, p0_out, p0_bytes_out);
+  return ISSCABAC_OK;
+}
+
+int isscabac_iss_init_context_model(isscabac_engine *e, const uint8_t *sym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                    const isscabac_symbol_params *p, double *p0_out, uint8_t *p0_bytes_out) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!sym || S == 0 || pitch == 0) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model: bad argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], S * pitch);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, S * pitch, hipMemcpyHostToDevice, e->stream));
+  return isscabac_iss_init_context_model_dev(e, static_cast<uint8_t *>(e->stage[0]), S, nsym, pitch, p, p0_out, p0_bytes_out);
+}
 
 uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *p) {
   if (!p || p->binarization > 1) return 0;
-  SymParams P{p->binarization, p->k, p->nq, p->selector, p->iss_types, p->nlbp};
+  SymParams P{p->binarization, p->k, p->nq, p->selector, p->iss_types, p->nlbp, p->col_rows};
   const uint32_t m = max_bins_of(P);
   return m > 32 ? 0 : m;
 }

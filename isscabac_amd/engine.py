@@ -27,17 +27,18 @@ _lib = None
 class SymbolParams(C.Structure):
     """isscabac_symbol_params: binarisation (0 TU, 1 EGk), k, nq, selector (0 demo, 1 ISS), iss_types, nlbp."""
     _fields_ = [("binarization", C.c_uint32), ("k", C.c_uint32), ("nq", C.c_uint32), ("selector", C.c_uint32),
-                ("iss_types", C.c_uint32), ("nlbp", C.c_uint32)]
+                ("iss_types", C.c_uint32), ("nlbp", C.c_uint32), ("col_rows", C.c_uint32)]
 
     @classmethod
     def demo(cls, nq):
         """cabacDemo.m: TU binarisation, 3 contexts from the previous symbol's first bin."""
-        return cls(0, 0, nq, 0, 0, 0)
+        return cls(0, 0, nq, 0, 0, 0, 0)
 
     @classmethod
-    def iss(cls, nq, method="EG", k=0, types=15, nlbp=3):
-        """ISS defaults (ISS/ISS.m:49-53): EG0, {cond0, cond1, conds0, conds1}, Nlbp = 3 -> 23 contexts."""
-        return cls(0 if method == "TU" else 1, k, nq, 1, types, nlbp)
+    def iss(cls, nq, method="EG", k=0, types=15, nlbp=3, col_rows=0):
+        """ISS defaults (ISS/ISS.m:49-53): EG0, {cond0, cond1, conds0, conds1}, Nlbp = 3 -> 23 contexts.
+        col_rows > 0: whole-matrix stream (columns back to back), the reference's one-file-per-matrix mode."""
+        return cls(0 if method == "TU" else 1, k, nq, 1, types, nlbp, col_rows)
 
 
 class EngineError(RuntimeError):
@@ -88,6 +89,10 @@ def _load():
                                           _u8p, C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u32p]
     L.isscabac_decode_symbols.argtypes = [_vp, _u8p, _u64p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(SymbolParams), _u8p, C.c_int, _u8p, _u32p]
+    L.isscabac_iss_init_context_model.argtypes = [_vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
+                                                  _f64p, _u8p]
+    L.isscabac_iss_init_context_model_dev.argtypes = [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                      C.POINTER(SymbolParams), _f64p, _u8p]
     L.isscabac_stream_open.argtypes = [_vp, _u8p, C.c_int, C.POINTER(_vp)]
     L.isscabac_stream_close.argtypes = [_vp]
     L.isscabac_stream_close.restype = None
@@ -285,6 +290,20 @@ class Engine:
                                                     R, pitch, C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(out, _u8p),
                                                     _ptr(status, _u32p)))
         return out[:, :R].copy(), status
+
+    def iss_init_context_model(self, sym, params):
+        """Empirical p(0) of the ISS contexts over all columns (ref: +coder/cabacInitContextModel.m).
+        sym: [S, R] uint8, one column per row.  Returns (p0 float64[7*nlbp+2], uint8(p0*255))."""
+        sym = _np(sym, np.uint8)
+        S, R = sym.shape
+        pitch = max(16, (R + 15) // 16 * 16)
+        symp = self._pad_rows(sym, pitch)
+        n = 7 * params.nlbp + 2
+        p0 = np.zeros(n, np.float64)
+        b = np.zeros(n, np.uint8)
+        self._check(self._L.isscabac_iss_init_context_model(self._h, _ptr(symp, _u8p), S, R, pitch, C.byref(params),
+                                                            _ptr(p0, _f64p), _ptr(b, _u8p)))
+        return p0, b
 
     # ---- raw device memory (for callers without torch) ---------------------------------------------------
     def alloc(self, nbytes):

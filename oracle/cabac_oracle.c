@@ -629,6 +629,64 @@ uint32_t orc_iss_decode_column(const uint8_t *payload, size_t len, int rows, uin
   return orc_dec_finish(&dec);
 }
 
+/* whole matrix as ONE stream: cabacEncode.m:34-70 / cabacDecode.m:29-55 (k outer, d inner); sym is column-major */
+size_t orc_iss_encode_matrix(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                             unsigned types, int nlbp, const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
+                             uint32_t *nbins_out) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  memcpy(cm, ctx_init, (size_t)nctx);
+  uint8_t g[ORC_MAX_SYM_BINS], up[ORC_MAX_SYM_BINS];
+  uint32_t total = 0;
+  orc_encoder e;
+  orc_enc_start(&e, out, cap);
+  for (int c = 0; c < cols; c++) {
+    int len_up = 0; /* d == 1: no upper neighbour, cabacEncode.m:52 */
+    for (int d = 0; d < rows; d++) {
+      int len = binarize(sym[(size_t)c * rows + d], nq, method, k, g);
+      for (int cnt = 1; cnt <= len; cnt++) {
+        int id = orc_iss_ctx(cnt, g, up, len_up, types, nlbp);
+        orc_enc_bin(&e, g[cnt - 1], &cm[id - 1]);
+        total++;
+      }
+      memcpy(up, g, (size_t)len);
+      len_up = len;
+    }
+  }
+  orc_enc_finish(&e);
+  if (nbins_out) *nbins_out = total;
+  return e.sink.overflow ? 0 : e.sink.len;
+}
+
+uint32_t orc_iss_decode_matrix(const uint8_t *payload, size_t len, int rows, int cols, uint32_t nq, int method,
+                               uint32_t k, unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
+                               uint32_t *sym_out) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  memcpy(cm, ctx_init, (size_t)nctx);
+  uint8_t g[ORC_MAX_SYM_BINS], up[ORC_MAX_SYM_BINS];
+  orc_decoder dec;
+  orc_dec_start(&dec, payload, len);
+  for (int c = 0; c < cols; c++) {
+    int len_up = 0;
+    for (int d = 0; d < rows; d++) {
+      sym_state st = {0, -1};
+      int n = 1, done = 0;
+      while (!done && n <= ORC_MAX_SYM_BINS) {
+        int id = orc_iss_ctx(n, g, up, len_up, types, nlbp);
+        g[n - 1] = (uint8_t)orc_dec_bin(&dec, &cm[id - 1]);
+        done = symbol_finished(g, n, nq, method, k, &st);
+        n++;
+      }
+      int glen = n - 1;
+      sym_out[(size_t)c * rows + d] = method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
+      memcpy(up, g, (size_t)glen);
+      len_up = glen;
+    }
+  }
+  return orc_dec_finish(&dec);
+}
+
 /* cabacDemo.m:113-121 (and :158-166): bin 1 of symbol it>1 uses ctx 1 / 2 when the first bin
  * of the previous symbol was 1 / 0; everything else uses ctx 0. */
 static int demo_ctx(int n, int have_prev, uint8_t prev_first) {
@@ -676,6 +734,98 @@ uint32_t orc_demo_decode(const uint8_t *payload, size_t len, int nsym, uint32_t 
     prev_first = g[0];
   }
   return orc_dec_finish(&d);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Empirical context initialisation, ISS/+coder/cabacInitContextModel.m:1-130 (MATLAB only: restated from the source
+ * text, not pinned against a run of the reference -- there is no MATLAB here).  sym is the column-major rows x cols
+ * matrix; out has 7*nlbp+2 entries in the order of the reference's "Concatenate" line (:128).
+ * MATLAB details kept: the row above the first row is a NaN cell (length 1, np_up1 = 0, compares false with 0 and 1);
+ * np = position of the first zero, or the string length if there is none; the norms of pcs0/pcs1 test y(n), not
+ * y(n + np_up1) (:96,:108); empty selections give 0, a zero norm count gives norm = 1.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { uint8_t b[ORC_MAX_SYM_BINS]; int len, np; int is_nan; } bin_cell;
+
+static double ratio_or_zero(uint64_t num, uint64_t den) { return den ? (double)num / (double)den : 0.0; }
+
+void orc_iss_init_context_model(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                                unsigned types, int N, double *out) {
+  const int total = 7 * N + 2;
+  for (int i = 0; i < total; i++) out[i] = 0.0;
+  double *p_pre = out, *pc0 = out + N, *pc1 = out + 2 * N, *p_lft = out + 3 * N, *p_suf = out + 4 * N,
+         *pcs0 = out + 5 * N, *pcs1 = out + 6 * N;
+  for (int n = 1; n <= N; n++) {
+    uint64_t a_pre = 0, z_pre = 0, d_c = 0, j_c0 = 0, y0_c = 0, j_c1 = 0, y1_c = 0, d_b = 0, j_b = 0, x1_b = 0,
+             d_s = 0, z_s = 0, d_cs = 0, j_cs0 = 0, y0_cs = 0, j_cs1 = 0, y1_cs = 0;
+    for (int c = 0; c < cols; c++) {
+      bin_cell up, cur;
+      up.is_nan = 1; up.len = 1; up.np = 0; up.b[0] = 0xEE;
+      for (int d = 0; d < rows; d++) {
+        cur.is_nan = 0;
+        cur.len = binarize(sym[(size_t)c * rows + d], nq, method, k, cur.b);
+        cur.np = first_zero_1based(cur.b, cur.len);
+        if (!cur.np) cur.np = cur.len;
+        /* y(i) of the upper cell: NaN compares false with everything */
+#define UPBIT_IS(i, val) (!up.is_nan && up.b[(i) - 1] == (val))
+        if (n <= cur.np) { a_pre++; z_pre += cur.b[n - 1] == 0; }
+        if (n <= cur.np && n <= up.np) {
+          d_c++;
+          j_c0 += cur.b[n - 1] == 0 && UPBIT_IS(n, 0);
+          y0_c += UPBIT_IS(n, 0);
+          j_c1 += cur.b[n - 1] == 0 && UPBIT_IS(n, 1);
+          y1_c += UPBIT_IS(n, 1);
+        }
+        if (n + 1 <= cur.np && up.np < n + 1) {
+          d_b++;
+          j_b += cur.b[n] == 0 && cur.b[n - 1] == 1;
+          x1_b += cur.b[n - 1] == 1;
+        }
+        if (n + cur.np <= cur.len) { d_s++; z_s += cur.b[n + cur.np - 1] == 0; }
+        if (n + cur.np <= cur.len && n + up.np <= up.len) {
+          d_cs++;
+          j_cs0 += cur.b[n + cur.np - 1] == 0 && UPBIT_IS(n + up.np, 0);
+          y0_cs += UPBIT_IS(n, 0);
+          j_cs1 += cur.b[n + cur.np - 1] == 0 && UPBIT_IS(n + up.np, 1);
+          y1_cs += UPBIT_IS(n, 1);
+        }
+#undef UPBIT_IS
+        up = cur;
+      }
+    }
+    p_pre[n - 1] = ratio_or_zero(z_pre, a_pre);
+    if (types & 1) pc0[n - 1] = ratio_or_zero(j_c0, d_c) / ((d_c && y0_c) ? (double)y0_c / (double)d_c : 1.0);
+    if (types & 2) pc1[n - 1] = ratio_or_zero(j_c1, d_c) / ((d_c && y1_c) ? (double)y1_c / (double)d_c : 1.0);
+    if (types & 16) p_lft[n - 1] = ratio_or_zero(j_b, d_b) / ((d_b && x1_b) ? (double)x1_b / (double)d_b : 1.0);
+    p_suf[n - 1] = ratio_or_zero(z_s, d_s);
+    if (types & 4) pcs0[n - 1] = ratio_or_zero(j_cs0, d_cs) / ((d_cs && y0_cs) ? (double)y0_cs / (double)d_cs : 1.0);
+    if (types & 8) pcs1[n - 1] = ratio_or_zero(j_cs1, d_cs) / ((d_cs && y1_cs) ? (double)y1_cs / (double)d_cs : 1.0);
+  }
+  /* the rest contexts, :112-126 */
+  uint64_t t_rp = 0, z_rp = 0, t_rs = 0, z_rs = 0;
+  const int n = N + 1;
+  for (int c = 0; c < cols; c++)
+    for (int d = 0; d < rows; d++) {
+      uint8_t g[ORC_MAX_SYM_BINS];
+      int len = binarize(sym[(size_t)c * rows + d], nq, method, k, g);
+      int np = first_zero_1based(g, len);
+      if (!np) np = len;
+      if (n <= np)
+        for (int i = n; i <= np; i++) { t_rp++; z_rp += g[i - 1] == 0; }
+      if (n > np && n <= len)
+        for (int i = n; i <= len; i++) { t_rs++; z_rs += g[i - 1] == 0; }
+    }
+  out[7 * N] = ratio_or_zero(z_rp, t_rp);
+  out[7 * N + 1] = ratio_or_zero(z_rs, t_rs);
+}
+
+/* uint8(x * 255) as MATLAB converts: round to nearest, ties away from zero, saturate (cabacEncode.m:30) */
+uint8_t orc_matlab_uint8_of_p(double p) {
+  double x = p * 255.0;
+  if (!(x == x)) return 0;
+  double r = floor(x + 0.5);
+  if (r < 0) r = 0;
+  if (r > 255) r = 255;
+  return (uint8_t)r;
 }
 
 /* ------------------------------------------------------------------------------------------

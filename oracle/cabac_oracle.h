@@ -148,6 +148,20 @@ uint32_t orc_iss_decode_column(const uint8_t *payload, size_t len, int rows, uin
                                int method, uint32_t k, unsigned types, int nlbp,
                                const uint8_t *ctx_init, int nctx, uint32_t *sym_out);
 
+/* the same loops over a whole column-major matrix coded as ONE stream (the reference's actual ISS mode) */
+size_t orc_iss_encode_matrix(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                             unsigned types, int nlbp, const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
+                             uint32_t *nbins_out);
+uint32_t orc_iss_decode_matrix(const uint8_t *payload, size_t len, int rows, int cols, uint32_t nq, int method,
+                               uint32_t k, unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
+                               uint32_t *sym_out);
+
+/* empirical p(0) per ISS context from the binarised matrix: ISS/+coder/cabacInitContextModel.m:1-130 (restated from
+ * the MATLAB text; unpinned: no MATLAB available).  out: 7*nlbp+2 doubles. */
+void orc_iss_init_context_model(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                                unsigned types, int nlbp, double *out);
+uint8_t orc_matlab_uint8_of_p(double p); /* uint8(p*255), cabacEncode.m:30 */
+
 /* demo selector + TU: CABAC/cabacDemo.m:92-131 (encode), :148-176 (decode) */
 size_t orc_demo_encode(const uint32_t *sym, int nsym, uint32_t nq, const uint8_t *ctx_init,
                        uint8_t *out, size_t cap, uint32_t *nbins_out);

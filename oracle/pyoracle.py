@@ -87,6 +87,17 @@ class Oracle:
         L.orc_iss_decode_column.restype = C.c_uint32
         L.orc_iss_decode_column.argtypes = [u8p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint,
                                             C.c_int, u8p, C.c_int, u32p]
+        L.orc_iss_encode_matrix.restype = C.c_size_t
+        L.orc_iss_encode_matrix.argtypes = [u32p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint, C.c_int,
+                                            u8p, C.c_int, u8p, C.c_size_t, u32p]
+        L.orc_iss_decode_matrix.restype = C.c_uint32
+        L.orc_iss_decode_matrix.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint,
+                                            C.c_int, u8p, C.c_int, u32p]
+        L.orc_iss_init_context_model.restype = None
+        L.orc_iss_init_context_model.argtypes = [u32p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint,
+                                                 C.c_int, f64p]
+        L.orc_matlab_uint8_of_p.restype = C.c_uint8
+        L.orc_matlab_uint8_of_p.argtypes = [C.c_double]
         L.orc_demo_encode.restype = C.c_size_t
         L.orc_demo_encode.argtypes = [u32p, C.c_int, C.c_uint32, u8p, u8p, C.c_size_t, u32p]
         L.orc_demo_decode.restype = C.c_uint32
@@ -269,6 +280,37 @@ class Oracle:
         st = self.lib.orc_iss_decode_column(_p(payload, u8p), payload.size, rows, nq, 0 if method == "TU" else 1, k,
                                             types, nlbp, _p(ctx_init, u8p), ctx_init.size, _p(sym, u32p))
         return sym, int(st)
+
+    def iss_encode_matrix(self, G, nq, method, k, types, nlbp, ctx_init):
+        """G: [rows, cols]; coded column by column as ONE stream (cabacEncode.m:45-70)."""
+        G = np.asarray(G)
+        rows, cols = G.shape
+        sym = np.ascontiguousarray(G.T, np.uint32).ravel()
+        ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
+        cap = self.stream_cap(sym.size * 96)
+        out = np.zeros(cap, np.uint8)
+        nb = C.c_uint32(0)
+        n = self.lib.orc_iss_encode_matrix(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp,
+                                           _p(ctx_init, u8p), ctx_init.size, _p(out, u8p), cap, C.byref(nb))
+        return out[:n].copy(), int(nb.value)
+
+    def iss_decode_matrix(self, payload, rows, cols, nq, method, k, types, nlbp, ctx_init):
+        payload = np.ascontiguousarray(payload, np.uint8)
+        ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
+        sym = np.zeros(rows * cols, np.uint32)
+        st = self.lib.orc_iss_decode_matrix(_p(payload, u8p), payload.size, rows, cols, nq, 0 if method == "TU" else 1,
+                                            k, types, nlbp, _p(ctx_init, u8p), ctx_init.size, _p(sym, u32p))
+        return sym.reshape(cols, rows).T.copy(), int(st)
+
+    def iss_init_context_model(self, G, nq, method, k, types, nlbp):
+        """cabacInitContextModel.m on the rows x cols matrix G -> (p0 doubles, uint8(p0*255) bytes)."""
+        G = np.asarray(G)
+        rows, cols = G.shape
+        sym = np.ascontiguousarray(G.T, np.uint32).ravel()
+        out = np.zeros(7 * nlbp + 2, np.float64)
+        self.lib.orc_iss_init_context_model(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp,
+                                            _p(out, f64p))
+        return out, np.array([self.lib.orc_matlab_uint8_of_p(float(v)) for v in out], np.uint8)
 
     def demo_encode(self, sym, nq, ctx_init):
         sym = np.ascontiguousarray(sym, np.uint32)

@@ -178,10 +178,10 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
 }
 
 
-// symbol-level front end (cabac_symbols.h): params = {method, k, nq, selector, types, nlbp}
+// symbol-level front end (cabac_symbols.h): params = {method, k, nq, selector, types, nlbp, col_rows}
 long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params, const uint8_t *ctx_init, int nctx,
                        uint8_t *out, size_t cap, uint32_t *nbins_out) {
-  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5]};
+  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5], params[6]};
   HostStates st;
   st.init(ctx_init, nctx);
   HostSink sink{out, 0, cap};
@@ -196,7 +196,7 @@ long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params
     enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
     enc_flush(e, sink);
     nbins++;
-    if (w.n == w.cur.len) w.next_symbol();
+    if (w.n == w.cur.len) w.next_symbol(P);
     else w.n++;
   }
   enc_finish(e, sink);
@@ -206,7 +206,7 @@ long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params
 
 uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, const uint32_t *params,
                            const uint8_t *ctx_init, int nctx, uint8_t *sym_out) {
-  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5]};
+  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5], params[6]};
   HostStates st;
   st.init(ctx_init, nctx);
   WindowSrc<HostMem> src;
@@ -228,7 +228,7 @@ uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, 
     w.cur.len = w.n;
     if (symbol_finished(w.cur, P) || w.n == 32) {
       sym_out[w.idx] = (uint8_t)debinarize(w.cur, P);
-      w.next_symbol();
+      w.next_symbol(P);
     } else {
       w.n++;
     }

@@ -46,3 +46,17 @@ def test_engine_fails_loudly_without_gpu():
     import isscabac_amd as ia
     with pytest.raises(ia.EngineError):
         ia.Engine(0)
+
+
+def test_stream_file_container_round_trip(oracle, tmp_path):
+    """one-file-per-stream <-> packed payload+offsets; the files are what the reference writes"""
+    from isscabac_amd.wrapper import read_stream_files, write_stream_files
+    bins, ctx = oracle.synth(0xCABAC002, 0, 5, 300, 3)
+    payload, offsets = oracle.encode_batch(bins, ctx, np.zeros(3, np.uint8))
+    paths = [str(tmp_path / ("s%d.bin" % i)) for i in range(5)]
+    sizes = write_stream_files(payload, offsets, paths)
+    assert sizes == np.diff(offsets.astype(np.int64)).tolist()
+    for i, p in enumerate(paths):
+        assert open(p, "rb").read() == oracle.encode_stream(bins[i], ctx[i], np.zeros(3, np.uint8)).tobytes()
+    p2, o2 = read_stream_files(paths)
+    assert p2.tobytes() == payload.tobytes() and (o2 == offsets).all()

@@ -344,3 +344,43 @@ def test_config1_demo_single_stream_and_ragged(engine, oracle):
     assert (status == 0).all()
     for s in range(S):
         assert (dec[s, :ns[s]] == syms[s, :ns[s]]).all() and (dec[s, ns[s]:] == 0).all()
+
+
+def test_whole_matrix_single_stream_mode_on_device(engine, oracle):
+    """one stream per whole matrix (what ISS.m actually writes, one file per matrix)."""
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(77)
+    mats = [_quantised_matrix(rng, 400, 20, 8), _quantised_matrix(rng, 109, 20, 8)]
+    p0 = np.round(rng.uniform(0.05, 0.95, 23) * 255) / 255
+    init = init_by_prob(p0)
+    for G in mats:
+        rows, cols = G.shape
+        params = SymbolParams.iss(8, "EG", 0, 15, 3, col_rows=rows)
+        payload, offsets, nbins = engine.encode_symbols(G.T.reshape(1, -1).copy(), params, init)
+        want, want_nb = oracle.iss_encode_matrix(G, 8, "EG", 0, 15, 3, init)
+        assert payload.tobytes() == want.tobytes() and nbins[0] == want_nb
+        sym, status = engine.decode_symbols(payload, offsets, rows * cols, params, init)
+        assert status[0] == 0 and (sym.reshape(cols, rows).T == G).all()
+
+
+def test_iss_context_init_statistics_and_full_iss_flow(engine, oracle):
+    """the empirical context initialisation (cabacInitContextModel.m) as a device histogram, and with it
+    the complete ISS getBits('CABAC') flow of ISS.m:184-214 for one matrix: statistics -> uint8 side information ->
+    initByProb -> encode -> decode, every stage equal to the oracle."""
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(5)
+    for rows, cols, nq, method, k, types, nlbp in [(400, 20, 8, "EG", 0, 15, 3), (109, 20, 8, "EG", 0, 15, 3),
+                                                    (57, 9, 8, "TU", 0, 31, 2), (300, 5, 64, "EG", 1, 10, 4), (1, 1, 8, "EG", 0, 15, 3)]:
+        G = _quantised_matrix(rng, rows, cols, nq)
+        params = SymbolParams.iss(nq, method, k, types, nlbp)
+        p0, b = engine.iss_init_context_model(G.T.copy(), params)
+        want_p0, want_b = oracle.iss_init_context_model(G, nq, method, k, types, nlbp)
+        assert (p0 == want_p0).all(), (rows, cols, p0, want_p0)
+        assert (b == want_b).all()
+        init = init_by_prob(b / 255.0)  # cabacEncode.m:31 / cabacDecode.m:13
+        mparams = SymbolParams.iss(nq, method, k, types, nlbp, col_rows=rows)
+        payload, offsets, _ = engine.encode_symbols(G.T.reshape(1, -1).copy(), mparams, init)
+        want, _ = oracle.iss_encode_matrix(G, nq, method, k, types, nlbp, oracle.init_by_prob(want_b / 255.0))
+        assert payload.tobytes() == want.tobytes()
+        sym, status = engine.decode_symbols(payload, offsets, rows * cols, mparams, init)
+        assert status[0] == 0 and (sym.reshape(cols, rows).T == G).all()

@@ -147,7 +147,7 @@ def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
 def _sym_roundtrip(L, sym, params, init):
     sym = np.ascontiguousarray(sym, np.uint8)
     init = np.ascontiguousarray(init, np.uint8)
-    par = (C.c_uint32 * 6)(*params)
+    par = (C.c_uint32 * 7)(*(tuple(params) + (0,) * (7 - len(params))))
     out = np.zeros(sym.size * 8 + 64, np.uint8)
     nb = C.c_uint32(0)
     n = L.sym_encode_stream(_p(sym), sym.size, par, _p(init), init.size, _p(out), out.size, C.byref(nb))
@@ -186,3 +186,22 @@ def test_symbol_front_end_vs_oracle(lane, oracle):
         assert st == 0 and (dec == sym).all()
         back, st2 = oracle.iss_decode_column(want, rows, nq, method, k, types, nlbp, init)
         assert st2 == 0 and (back == sym).all()
+
+
+def test_whole_matrix_single_stream_mode(lane, oracle):
+    """the reference's actual ISS mode: a whole matrix as ONE stream, columns back to back, upper neighbour
+    restarting at every column (cabacEncode.m:45-70) -- host build of cabac_symbols.h with col_rows set."""
+    rng = np.random.default_rng(23)
+    for rows, cols, nq, method, k in [(40, 7, 8, "EG", 0), (109, 20, 8, "EG", 0), (13, 31, 4, "TU", 0), (5, 3, 16, "EG", 1)]:
+        G = np.minimum(np.abs(rng.normal(size=(rows, cols)) * nq / 3).astype(np.uint32), nq - 1)
+        init = rng.integers(0, 126, 23).astype(np.uint8)
+        want, want_nb = oracle.iss_encode_matrix(G, nq, method, k, 15, 3, init)
+        sym = G.T.ravel().astype(np.uint8)
+        got, nb, dec, st = _sym_roundtrip(lane, sym, (0 if method == "TU" else 1, k, nq, 1, 15, 3, rows), init)
+        assert got.tobytes() == want.tobytes() and nb == want_nb
+        assert st == 0 and (dec == sym).all()
+        back, st2 = oracle.iss_decode_matrix(want, rows, cols, nq, method, k, 15, 3, init)
+        assert st2 == 0 and (back == G).all()
+        if cols > 1:  # and it is NOT the concatenation of independently coded columns
+            per_col, _ = oracle.iss_encode_column(G[:, 0], nq, method, k, 15, 3, init)
+            assert got[:len(per_col)].tobytes() != per_col.tobytes() or len(got) != len(per_col)
