@@ -183,21 +183,19 @@ def main():
     # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
     gather_ms = None
     if world > 1:
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        mine = torch.tensor([total], dtype=torch.int64, device=dev)
-        fence()
-        g0 = time.perf_counter()
-        dist.all_gather_into_tensor(sizes, mine)
-        hs = sizes.cpu().tolist()
-        if rank == 0:
-            parts = [torch.empty(n, dtype=torch.uint8, device=dev) for n in hs]
-            reqs = [dist.irecv(parts[r], src=r) for r in range(1, world)]
-            for r in reqs:
-                r.wait()
-        else:
-            dist.send(payload[:total], dst=0)
-        fence()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        try:
+            from isscabac_amd import sharding
+            fence()
+            g0 = time.perf_counter()
+            p_all, o_all = sharding.gather_payload(payload[:total], offsets, dist)
+            fence()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                assert int(o_all[-1]) == p_all.numel() and o_all.numel() == world * S + 1
+            del p_all, o_all
+        except Exception as exc:  # the gather is reported apart from `value`; never let it take the run down
+            sys.stderr.write("bitstream gather failed: %r\n" % (exc,))
+            gather_ms = None
 
     if rank == 0:
         bins_total = float(S) * B * world * args.steps

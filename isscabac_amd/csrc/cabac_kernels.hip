@@ -219,6 +219,19 @@ struct SlotSink {
 #endif
     }
   }
+  // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
+  __device__ __forceinline__ void put16(uint32_t x) {
+    *reinterpret_cast<uint16_t *>(stage + (pos & 15u)) = (uint16_t)((x >> 8) | (x << 8));
+    pos += 2;
+    if ((pos & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage);
+#ifndef ISSCABAC_ABL_NO_SLOT_STORE
+      if (on) *reinterpret_cast<uint4 *>(slot + pos - 16) = v;
+#else
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
+    }
+  }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
   __device__ __forceinline__ void close() {
     if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slot + (pos & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
@@ -329,7 +342,17 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
           for (int k = 0; k < 16; k++) {
             enc_bin(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
 #ifndef ISSCABAC_ABL_NO_FLUSH
-            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
+#ifdef ISSCABAC_FLUSH4
+            if ((k & 3) == 3 && wave_any(e.W >= 29)) enc_flush16(e, sink);
+#else
+            // digits leave `low` every 8 bins; half way only if some lane could otherwise overflow it
+            // (W < 39 here => W <= 62 four bins later), which ordinary data never triggers
+            if ((k & 7) == 7) {
+              if (wave_any(e.W >= 29)) enc_flush16(e, sink);
+            } else if ((k & 7) == 3) {
+              if (wave_any(e.W >= 39)) enc_flush16(e, sink);
+            }
+#endif
 #else
             if ((k & 3) == 3) { e.W &= 15; }
 #endif
@@ -339,7 +362,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
-            if ((k & 3) == 3 && wave_any(e.W >= 21)) enc_flush(e, sink);
+            if ((k & 3) == 3 && wave_any(e.W >= 29)) enc_flush16(e, sink);
           }
         } else {
           // ragged end: lanes drop out one by one, tables from LDS memory
@@ -350,15 +373,15 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
               const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
               enc_bin_any(e, b1, cx, stm);
             }
-            if ((k & 3) == 3) enc_flush(e, sink);
+            if ((k & 3) == 3) enc_flush16(e, sink);
           }
         }
       }
       wave_lds_sync();
     }
   }
-  enc_flush(e, sink);
-  enc_finish(e, sink);
+  enc_flush16(e, sink);
+  enc_finish16(e, sink);
   sink.close();
   if (valid) a.lens[s] = sink.bytes();
 }
@@ -382,6 +405,9 @@ struct DevMem {
     return r;
   }
   __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
+#ifdef ISSCABAC_ABL_HOT_PAYLOAD
+    off &= 60u;  // timing only: every fetch hits the same hot line
+#endif
     if ((uint64_t)off + 16 <= avail) {
       const Q4 q = *reinterpret_cast<const Q4 *>(base + off);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
@@ -484,7 +510,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       const uint64_t s_row = s0 + row;
       const uint32_t boff = off + c * 16;
 #ifndef ISSCABAC_ABL_NO_STORE
-#ifdef ISSCABAC_NT_STREAMS
+#if defined(ISSCABAC_NT_STREAMS) || defined(ISSCABAC_NT_STORES)
       if (s_row < a.S && boff < a.pitch) nt_store16(a.bins_out + s_row * a.pitch + boff, v);
 #else
       if (s_row < a.S && boff < a.pitch) *reinterpret_cast<uint4 *>(a.bins_out + s_row * a.pitch + boff) = v;

@@ -265,6 +265,93 @@ CABAC_HD void enc_finish(EncCore &e, Sink &out) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Encoder output in 16-bit digits (used by the batch bin kernel)
+// ------------------------------------------------------------------------------------------------
+// Same outstanding-digit logic as writeOut, on 16-bit digits: `buffered` holds the last digit that may still take a
+// carry, `nbuf` - 1 the number of 0xFFFF digits behind it.  A lane then moves output every ~20 bins instead of every
+// ~10, and a 4-bin check almost never needs a second pass.  The byte stream is the same big number; enc_finish16
+// converts the pending digits to the byte-granular state and ends exactly like the reference's finish().
+// Sink additionally provides put16(x): the two bytes of x, high byte first.
+template <class Sink>
+CABAC_HD void enc_lead16(EncCore &e, uint32_t lead, Sink &out) {
+  if (lead == 0xFFFFu) {
+    e.nbuf++;
+  } else if (e.nbuf > 0) {
+    const uint32_t carry = lead >> 16;
+    out.put16((e.buffered + carry) & 0xFFFFu);
+    const uint32_t fill = (0xFFFFu + carry) & 0xFFFFu;
+    while (e.nbuf > 1) {
+      out.put16(fill);
+      e.nbuf--;
+    }
+    e.buffered = lead & 0xFFFFu;
+  } else {
+    e.nbuf = 1;
+    e.buffered = lead;  // the very first digit cannot carry
+  }
+}
+
+// keeps 13 <= W' after every digit (W' >= 9 is what bounds the carry to one bit); W must stay below 63
+template <class Sink>
+CABAC_HD void enc_flush16(EncCore &e, Sink &out) {
+  while (e.W >= 29) {
+    e.W -= 16;
+    const uint32_t lead = (uint32_t)(e.low >> e.W) & 0x1FFFFu;
+    e.low &= (1ull << e.W) - 1ull;
+    enc_lead16(e, lead, out);
+  }
+}
+
+template <class Sink>
+CABAC_HD void enc_finish16(EncCore &e, Sink &out) {
+  // encodeBinTrm(1), ref: :326-341
+  e.range -= 2;
+  e.low = (e.low + e.range) << 7;
+  e.range = 256;
+  e.W += 7;
+  enc_flush16(e, out);  // 13 <= W <= 28
+  // pending digits [buffered][0xFFFF x (nbuf-1)] -> pending bytes [b][0xFF x (n-1)] of the byte-granular machine
+  if (e.nbuf == 0) {
+    e.buffered = 0xFFu;
+  } else {
+    const uint32_t hi = e.buffered >> 8, lo = e.buffered & 0xFFu;
+    if (lo == 0xFFu) {
+      e.buffered = hi;
+      e.nbuf = 2 * e.nbuf;
+    } else {
+      out.put(hi);  // a carry into `lo` cannot reach it any more
+      e.buffered = lo;
+      e.nbuf = 2 * e.nbuf - 1;
+    }
+  }
+  enc_flush(e, out);  // at most one more byte: 13 <= W <= 20, as in the reference after its testAndWriteOut
+  // finish(), ref: :76-104
+  if ((e.low >> e.W) & 1ull) {
+    out.put((e.buffered + 1u) & 0xFFu);
+    while (e.nbuf > 1) {
+      out.put(0x00u);
+      e.nbuf--;
+    }
+    e.low -= 1ull << e.W;
+  } else {
+    if (e.nbuf > 0) out.put(e.buffered & 0xFFu);
+    while (e.nbuf > 1) {
+      out.put(0xFFu);
+      e.nbuf--;
+    }
+  }
+  const uint32_t nb = (uint32_t)e.W - 8u;
+  uint32_t tail = ((((uint32_t)(e.low >> 8)) & ((1u << nb) - 1u)) << 1) | 1u;
+  if (nb + 1u <= 8u) {
+    out.put((tail << (8u - (nb + 1u))) & 0xFFu);
+  } else {
+    tail <<= 16u - (nb + 1u);
+    out.put(tail >> 8);
+    out.put(tail & 0xFFu);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decoder
 // ------------------------------------------------------------------------------------------------
 // v holds the code value with (sh) fraction bits below the 9-bit range: the reference's m_uiValue is

@@ -41,7 +41,7 @@ def gather_payload(payload, offsets, dist, root=0):
     dist.all_gather(sizes, mine)
     sizes = [s.cpu().tolist() for s in sizes]
     if rank == root:
-        parts, offs, reqs = [], [], []
+        parts, offs, ops = [], [], []
         for r in range(world):
             if r == root:
                 parts.append(payload)
@@ -49,15 +49,16 @@ def gather_payload(payload, offsets, dist, root=0):
                 continue
             p = torch.empty(sizes[r][0], dtype=torch.uint8, device=dev)
             o = torch.empty(sizes[r][1] + 1, dtype=torch.int64, device=dev)
-            reqs.append(dist.irecv(p, src=r))
-            reqs.append(dist.irecv(o, src=r))
+            ops.append(dist.P2POp(dist.irecv, p, r))
+            ops.append(dist.P2POp(dist.irecv, o, r))
             parts.append(p)
             offs.append(o)
-        for q in reqs:
+        # one batched group: with RCCL this is a single ncclGroupStart/End, all peers' links in flight together
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
             q.wait()
         all_off = global_offsets([o.cpu().numpy() for o in offs], [s[0] for s in sizes])
         return torch.cat(parts), torch.from_numpy(all_off.astype(np.int64)).to(dev)
-    reqs = [dist.isend(payload, dst=root), dist.isend(offsets, dst=root)]
-    for q in reqs:
+    ops = [dist.P2POp(dist.isend, payload, root), dist.P2POp(dist.isend, offsets, root)]
+    for q in dist.batch_isend_irecv(ops):
         q.wait()
     return None, None

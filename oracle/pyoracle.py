@@ -27,12 +27,11 @@ def _p(a, t):
 
 
 def build(force=False):
-    """Compile the C restatement (and, when /root/reference exists, the reference shim)."""
-    if force or not os.path.exists(ORACLE_SO) or (
-        os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "cabac_oracle.c"))
-    ):
+    """Compile the C restatement (and, when /root/reference exists, the reference shim) if they are missing.
+    Never rebuilds an existing library implicitly: several bench ranks may import this at once."""
+    if force or not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", HERE, "libcabac_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/CABAC"):
+    if (force or not os.path.exists(REF_SO)) and os.path.isdir("/root/reference/CABAC"):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
 

@@ -50,6 +50,10 @@ struct HostSink {
     if (len < cap) buf[len] = (uint8_t)b;
     len++;
   }
+  void put16(uint32_t x) {
+    put(x >> 8);
+    put(x & 0xFFu);
+  }
 };
 
 // payload bytes of one stream inside a bigger buffer, with the device's bounds rule
@@ -83,6 +87,8 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   if (any) flush_every = -flush_every;
   const bool quads = flush_every == 40;
   if (quads) flush_every = 4;
+  const bool digits16 = flush_every == 16;  // the batch kernel's output path: 16-bit digits, checked every 4 bins
+  if (digits16) flush_every = 4;
   HostStates st;
   st.init(ctx_init, nctx);
   HostSink sink{out, 0, cap};
@@ -105,10 +111,22 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
     else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
     if (e.W > mw) mw = e.W;
-    if ((i + 1) % (uint32_t)flush_every == 0) enc_flush(e, sink);
+    if ((i + 1) % (uint32_t)flush_every == 0) {
+      if (digits16) {  // the batch kernel's cadence: every 8 bins, half way only when W >= 39
+        if ((i + 1) % 8 == 0 || e.W >= 39) enc_flush16(e, sink);
+        if (e.W > 62) return -2;
+      } else {
+        enc_flush(e, sink);
+      }
+    }
   }
-  enc_flush(e, sink);
-  enc_finish(e, sink);
+  if (digits16) {
+    enc_flush16(e, sink);
+    enc_finish16(e, sink);
+  } else {
+    enc_flush(e, sink);
+    enc_finish(e, sink);
+  }
   if (ctx_final) st.final_packed(ctx_final, nctx);
   if (max_w) *max_w = mw;
   return sink.len <= cap ? (long)sink.len : -1;

@@ -67,13 +67,13 @@ def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
-@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40])
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40, 16])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
         out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
         assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
-        assert mw <= 20 + 6 * min(abs(flush_every), 4) + 1
+        assert mw <= (62 if flush_every == 16 else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
 @pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2)])
@@ -99,7 +99,7 @@ def test_fuzz_vs_oracle(lane, oracle):
         skew = rng.random(Cn + 1) ** (1 + it % 4)
         bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        got, fin, _ = lane_encode(lane, bins, ctx, init, 40 if it % 2 else 4)
+        got, fin, _ = lane_encode(lane, bins, ctx, init, (40, 4, 16)[it % 3])
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
@@ -113,6 +113,14 @@ def test_all_lps_worst_case_width(lane, oracle, golden):
     s = {x["name"]: x for x in golden["streams"]}["all_lps_4ctx"]
     _out, _fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], 4)
     assert mw <= 44
+    # the 8-bin cadence of the batch kernel at its worst: 64 contexts all at state 62, every bin an LPS (6-bit shifts)
+    n = 64 * 8
+    ctx = np.arange(n) % 64
+    init = np.full(64, 124, np.uint8)
+    bins = np.ones(n, np.uint8)  # mps is 0 -> the first LPS of every context shifts by 6
+    want = oracle.encode_stream(bins, ctx, init)
+    got, _fin, mw = lane_encode(lane, bins, ctx, init, 16)
+    assert got.tobytes() == want.tobytes() and 50 <= mw <= 62
 
 
 def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
