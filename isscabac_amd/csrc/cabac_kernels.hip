@@ -362,7 +362,11 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
-            if ((k & 3) == 3 && wave_any(e.W >= 29)) enc_flush16(e, sink);
+            if ((k & 7) == 7) {
+              if (wave_any(e.W >= 29)) enc_flush16(e, sink);
+            } else if ((k & 7) == 3) {
+              if (wave_any(e.W >= 39)) enc_flush16(e, sink);
+            }
           }
         } else {
           // ragged end: lanes drop out one by one, tables from LDS memory
@@ -554,10 +558,11 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
           const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
-          if (full && !hi) {
-            // context bins only: a top-up leaves sh >= 16 and a context bin takes at most 6 bits, so two bins per
-            // top-up never see sh < 7 and need no look-ahead guard; the window is re-based every 8 bins, which
-            // covers the 4 x 2 bytes four top-ups can take
+          if (full) {
+            // every lane decodes 16 bins: convergent, tables through the crossbar.  A top-up leaves sh >= 16, a context
+            // bin takes at most 6 bits and needs sh >= 7, a bypass bin takes 1 and needs sh >= 8: two bins per top-up
+            // never run short, so there is no per-bin look-ahead test; the window is re-based every 8 bins, which
+            // covers the 4 x 2 bytes four top-ups can take.  `hi` (wave-uniform) picks the bypass-capable step.
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #else
@@ -570,21 +575,29 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               src.cnt = 8;
 #endif
               const uint32_t cw = word_of(wc, g);
+              if (!hi) {
 #pragma unroll
-              for (int k = 0; k < 4; k++) {
-                if ((k & 1) == 0) dec_topup_nocheck(d, src);
-                ob |= dec_bin(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
+                for (int k = 0; k < 4; k++) {
+                  if ((k & 1) == 0) dec_topup_nocheck(d, src);
+                  ob |= dec_bin(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  if ((k & 1) == 0) dec_topup_nocheck(d, src);
+                  ob |= dec_bin_any(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
+                }
               }
             }
           } else {
-            // bypass bins / contexts >= 128 somewhere in the wave, or ragged end: one rolled loop, per-bin guard;
-            // tables from LDS memory when lanes have dropped out (bpermute cannot read inactive lanes)
+            // ragged end: lanes drop out one by one, per-bin guard, tables from LDS memory (bpermute cannot read
+            // inactive lanes)
 #pragma unroll 1
             for (int k = 0; k < 16; k++) {
               if (i0 + k < n) {
                 if (d.sh < 8) dec_refill(d, src);
                 const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-                ob |= (full ? dec_bin_any(d, cx, stx) : dec_bin_any(d, cx, stm)) << k;
+                ob |= dec_bin_any(d, cx, stm) << k;
               }
             }
           }

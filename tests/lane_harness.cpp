@@ -175,8 +175,8 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       i += 3;
       continue;
     }
-    if (noguard && ctx[i] != kBypass) {
-      if (d.sh < 7) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
+    if (noguard) {
+      if (d.sh < (ctx[i] == kBypass ? 8 : 7)) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
     } else if (d.sh < 8) {
       dec_refill(d, src);
       slow_refills++;

@@ -76,7 +76,7 @@ def test_encode_golden(lane, golden, flush_every):
         assert mw <= (62 if flush_every == 16 else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
-@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2)])
+@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2), (1, 7, -2)])
 def test_decode_golden(lane, golden, pads):
     for s in golden["streams"]:
         bins, st, fin, _ = lane_decode(lane, s["payload_a"], s["ctx_a"], s["ctx_init_a"], pad_front=pads[0],
@@ -145,7 +145,7 @@ def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
             bad = np.concatenate([bad, rng.integers(0, 256, 3).astype(np.uint8)])
         want, st_want = oracle.decode_stream(bad, ctx, init)
         got, st, _, _ = lane_decode(lane, bad, ctx, init, pad_front=2, pad_back=int(rng.integers(0, 30)),
-                                    group=int(rng.choice([2, 4])))
+                                    group=int(rng.choice([2, 4, -2])))
         assert (got == want).all()
         assert st == st_want
         flagged += st != 0
