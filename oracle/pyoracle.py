@@ -337,7 +337,7 @@ class Oracle:
 class Reference:
     """The real reference classes (oracle/_ref/libcabac_ref.so)."""
 
-    def __init__(self):
+    def __init__(self, tag="ref"):
         if not have_reference():
             build()
         if not have_reference():
@@ -354,7 +354,7 @@ class Reference:
                                           f64p, f64p]
         L.ref_next_state.restype = C.c_uint8
         L.ref_next_state.argtypes = [C.c_uint8, C.c_int]
-        self.scratch = scratch_path("ref").encode()
+        self.scratch = scratch_path(tag).encode()
 
     def __del__(self):
         try:
