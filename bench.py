@@ -14,7 +14,9 @@ kernels), its duration measured with HIP events on the launch stream inside the 
 follow SURVEY.md 8(d): encode reads 2 B/bin and writes P + 8 B/stream, decode reads 1 B/bin + P + 8 B/stream
 and writes 1 B/bin (P = measured payload bytes).  `cpu_baseline` times the real reference classes
 (oracle/_ref, kind "reference") or, where that build is absent, the C restatement (kind "port") on a bounded
-sample of the same workload on the host cores of this box.
+sample of the same workload on the host cores of this box, and -- the only place bench.py touches oracle/ -- checks
+the GPU payload of the sampled streams byte for byte against the CPU coder.  The always-on gate is the device-side
+round trip: decoded bins == input bins for every stream, decoder integrity flags all zero.
 """
 import argparse
 import json
@@ -65,12 +67,24 @@ def _cpu_worker(seed, B, C, ep, budget_s, s_first, s_step, tag, out):
     out.append((done, t_enc, t_dec, time.perf_counter() - t_start))
 
 
-def cpu_baseline(seed, B, C, ep, budget_s):
+def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None):
     """Reference (or port) round trip on a bounded sample of the same synthetic workload: one host core (the headline
-    `value`, like the single-threaded reference), then all host cores with the streams split evenly."""
+    `value`, like the single-threaded reference), then all host cores with the streams split evenly.
+    gpu_payload_of(s) -> bytes of GPU-coded stream s: the first 256 streams of the sample are also coded by the CPU
+    restatement here and must match the GPU payload byte for byte (the oracle stays inside this leg)."""
     import threading
+    import numpy as np
     from oracle import pyoracle
     use_ref = pyoracle.have_reference()
+    checked = 0
+    if gpu_payload_of is not None:
+        orc = pyoracle.Oracle()
+        hb, hc = orc.synth(seed, 0, 256, B, C, ep)
+        init = np.zeros(C, np.uint8)
+        for s in range(256):
+            want = orc.encode_stream(hb[s], hc[s], init).tobytes()
+            assert gpu_payload_of(s) == want, "GPU payload of stream %d differs from the CPU coder" % s
+            checked += 1
     res = []
     _cpu_worker(seed, B, C, ep, budget_s * 0.5, 0, 256, "ref1", res)
     done, t_enc, t_dec, _wall = res[0]
@@ -85,6 +99,7 @@ def cpu_baseline(seed, B, C, ep, budget_s):
                           if use_ref else "C restatement, in-memory sink"),
         "encode_Gbin_s": total_bins / t_enc / 1e9,
         "decode_Gbin_s": total_bins / t_dec / 1e9,
+        "gpu_streams_checked_byte_exact": checked,
     }
     ncores = os.cpu_count() or 1
     if ncores > 1:
@@ -181,19 +196,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- correctness gate (outside the timed region) ---------------------------------------------------
+    # ---- correctness gate (outside the timed region): the round trip must reproduce every bin of every stream --------
     verified = None
     if not args.no_verify:
         assert int(status.abs().sum()) == 0, "decoder integrity flags set"
         assert torch.equal(out, bins), "decoded bins differ from the input"
-        from oracle.pyoracle import Oracle
-        orc = Oracle()
-        off = offsets.cpu().numpy().astype(np.uint64)
-        for s in list(range(0, S, max(1, S // 48))) + [S - 1]:
-            hb, hc = orc.synth(seed, s0 + s, 1, B, C, ep)
-            want = orc.encode_stream(hb[0], hc[0], init)
-            got = payload[int(off[s]):int(off[s + 1])].cpu().numpy()
-            assert got.tobytes() == want.tobytes(), "payload of stream %d differs from the oracle" % s
         verified = True
 
     # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
@@ -261,7 +268,13 @@ def main():
             "gather_ms": gather_ms,
         }
         if args.cpu_seconds > 0 and world == 1:
-            line["cpu_baseline"] = cpu_baseline(seed, B, C, ep, args.cpu_seconds)
+            off = offsets.cpu().numpy().astype(np.uint64)
+
+            def gpu_payload_of(s):
+                return payload[int(off[s]):int(off[s + 1])].cpu().numpy().tobytes()
+
+            line["cpu_baseline"] = cpu_baseline(seed, B, C, ep, args.cpu_seconds,
+                                                None if args.no_verify else gpu_payload_of)
         elif args.cpu_seconds > 0:
             line["cpu_baseline"] = None
         print(json.dumps(line))
