@@ -56,6 +56,12 @@ def _load():
     if _lib is not None:
         return _lib
     path = lib_path()
+    if not os.path.exists(path) and not os.environ.get("ISSCABAC_LIB"):
+        try:  # a source checkout without the built library: compile it now (hipcc cross-compiles gfx950 anywhere)
+            _build.build_lib()
+        except Exception as exc:
+            raise RuntimeError("%s is missing and could not be built (%s); there is no CPU fallback for the coding "
+                               "path" % (path, exc))
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -m isscabac_amd.build` (needs hipcc); there is no CPU "
                            "fallback for the coding path" % path)
@@ -247,12 +253,12 @@ class Engine:
         ctxp = self._pad_rows(ctx, pitch)
         ci = _np(ctx_init, np.uint8)
         nb = None if nbins is None else _np(nbins, np.uint32)
-        bins = np.zeros((S, pitch), np.uint8)
+        bins = np.empty((S, pitch), np.uint8)
         status = np.zeros(S, np.uint32)
         self._check(self._L.isscabac_decode_batch(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ctxp, _u8p),
                                                   _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
                                                   _ptr(bins, _u8p), _ptr(status, _u32p)))
-        return bins[:, :B].copy(), status
+        return (bins if pitch == B else bins[:, :B].copy()), status
 
     # ---- symbol-level batch calls (binariser + context selector fused on the device) --------------------
     def encode_symbols(self, sym, params, ctx_init, nsym=None):
