@@ -384,3 +384,59 @@ def test_iss_context_init_statistics_and_full_iss_flow(engine, oracle):
         assert payload.tobytes() == want.tobytes()
         sym, status = engine.decode_symbols(payload, offsets, rows * cols, mparams, init)
         assert status[0] == 0 and (sym.reshape(cols, rows).T == G).all()
+
+
+def test_c_abi_argument_errors_do_not_crash(engine):
+    """bad arguments come back as error codes with a message (the reference would assert or read out of bounds)"""
+    import isscabac_amd
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S, B = 64, 64
+    bins = torch.zeros((S, B), dtype=torch.uint8, device=dev)
+    ctx = torch.zeros((S, B), dtype=torch.uint8, device=dev)
+    payload = torch.empty(S * 64, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    init = np.zeros(3, np.uint8)
+
+    def enc(**kw):
+        a = dict(d_bins=bins.data_ptr(), d_ctx=ctx.data_ptr(), S=S, nbins=B, pitch=B, ctx_init=init,
+                 d_payload=payload.data_ptr(), payload_cap=payload.numel(), d_offsets=offsets.data_ptr())
+        a.update(kw)
+        return engine.encode_dev(a["d_bins"], a["d_ctx"], a["S"], a["nbins"], a["pitch"], a["ctx_init"], a["d_payload"],
+                                 a["payload_cap"], a["d_offsets"])
+
+    assert enc() > 0
+    for bad in (dict(pitch=40), dict(nbins=B + 16), dict(S=0), dict(d_bins=bins.data_ptr() + 4), dict(d_bins=0),
+                dict(ctx_init=np.zeros(0, np.uint8)), dict(ctx_init=np.full(3, 127, np.uint8))):
+        with pytest.raises(isscabac_amd.EngineError) as ei:
+            enc(**bad)
+        assert ei.value.code == 1, bad
+    out = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    with pytest.raises(isscabac_amd.EngineError):
+        engine.decode_dev(payload.data_ptr() + 1, 10, offsets.data_ptr(), ctx.data_ptr(), S, B, B, init, out.data_ptr())
+    with pytest.raises(isscabac_amd.EngineError):
+        engine.decode_dev(payload.data_ptr(), 10, offsets.data_ptr(), ctx.data_ptr(), S, B, 24, init, out.data_ptr())
+
+
+def test_device_side_per_stream_lengths_and_null_status(engine, oracle):
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S, B, C = 500, 640, 23
+    hb, hc = oracle.synth(0xABCD, 7, S, B, C)
+    nb = (np.arange(S, dtype=np.uint32) * 131) % (B + 1)
+    init = (np.arange(C) * 5 % 126).astype(np.uint8)
+    bins, ctx = torch.from_numpy(hb).to(dev), torch.from_numpy(hc).to(dev)
+    d_nb = torch.from_numpy(nb.astype(np.int32)).to(dev)
+    cap = S * ((6 * B + 9 + 7) // 8)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    total = engine.encode_dev(bins.data_ptr(), ctx.data_ptr(), S, B, B, init, payload.data_ptr(), cap, offsets.data_ptr(),
+                              d_nbins=d_nb.data_ptr())
+    want_payload, want_off = oracle.encode_batch(hb, hc, init, nb)
+    assert total == want_payload.size and payload[:total].cpu().numpy().tobytes() == want_payload.tobytes()
+    out = torch.full((S, B), 9, dtype=torch.uint8, device=dev)
+    engine.decode_dev(payload.data_ptr(), total, offsets.data_ptr(), ctx.data_ptr(), S, B, B, init, out.data_ptr(),
+                      d_status=0, d_nbins=d_nb.data_ptr())
+    got = out.cpu().numpy()
+    for s in range(S):
+        assert (got[s, :nb[s]] == hb[s, :nb[s]]).all() and (got[s, nb[s]:] == 0).all()
