@@ -142,7 +142,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from isscabac_amd import Engine
+    from isscabac_amd import Engine, stream_bound
     S, B, C, seed, ep = WORKLOADS[args.workload]
     if args.streams:
         S = args.streams
@@ -157,6 +157,8 @@ def main():
     eng.synth_dev(seed, s0, S, B, B, C, ep, bins.data_ptr(), ctx.data_ptr())
     init = np.zeros(C, np.uint8)  # (mps 0, state 0) == initByProb(0.5), cabacDemo.m:49
     cap = S * (B // 8 + B // 16 + 64)  # 1.5 bit/bin: EP-heavy streams stay below ~1.01
+    if os.environ.get("ISSCABAC_BENCH_FULL_CAP"):  # timing-only ablation builds emit garbage of any size
+        cap = S * stream_bound(B)
     payload = torch.empty(cap, dtype=torch.uint8, device=dev)
     offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
     out = torch.empty((S, B), dtype=torch.uint8, device=dev)

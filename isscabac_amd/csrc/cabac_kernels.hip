@@ -155,6 +155,9 @@ struct LdsStates {
   const uint32_t *tab;  // LDS: [0..63] rangeTabLps rows, [64..127] next-state entries
   uint32_t row_tab, next_tab;
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
+  // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
+  __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
+  __device__ __forceinline__ uint8_t *addr_of(const CtxQuad &z, int k) const { return base + quad_field(z, k); }
   __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
 #ifdef ISSCABAC_ABL_NO_STATE_LDS
@@ -184,6 +187,8 @@ struct RegStates {
   const uint32_t *tab;
   uint32_t row_tab, next_tab;
   __device__ __forceinline__ uint32_t addr(uint32_t c) const { return 8u * (c & 3u); }
+  __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return CtxQuad{(cw & 0x03030303u) << 3, 0u}; }
+  __device__ __forceinline__ uint32_t addr_of(const CtxQuad &z, int k) const { return (z.z01 >> (8 * k)) & 0xFFu; }
   __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return (*packed >> a) & 0xFFu; }
   // only the low byte of q is meaningful (next_state_q leaves garbage above it)
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *packed = (*packed & ~(0xFFu << a)) | ((q & 0xFFu) << a); }
@@ -340,7 +345,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
           // every lane codes 16 context bins: convergent, tables through the crossbar
 #pragma unroll
           for (int k = 0; k < 16; k++) {
-            enc_bin(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+            const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
+            enc_bin_at(e, bin_at_bit1(wb, k), stx.addr_of(z, k & 3), stx);
 #ifndef ISSCABAC_ABL_NO_FLUSH
 #ifdef ISSCABAC_FLUSH4
             if ((k & 3) == 3 && wave_any(e.W >= 29)) enc_flush16(e, sink);
@@ -500,17 +506,18 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 
   // decoded bins are kept as BITS in LDS, 128 bins (16 bytes) per stream, and leave as full 128-byte row segments:
   // 32-byte segment stores were measured at 1.35 TB/s, 128-byte ones at 4 TB/s (tools/ubench/tile_bw.hip)
-  uint16_t *obits = reinterpret_cast<uint16_t *>(tile_o);  // [8 chunks][64 lanes]
+  // (two bits per bin as collect_bin() leaves them: bin j of a 16-bin chunk at bit 2j + 1 of the chunk's dword)
+  uint32_t *obits = reinterpret_cast<uint32_t *>(tile_o);  // [8 chunks][64 lanes]
   auto store_out = [&](uint32_t off) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint32_t row = k * 8 + (lane >> 3), c = lane & 7;
       const uint32_t bits = obits[c * 64 + row];
       uint4 v;
-      v.x = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;  // 4 bits -> 4 bytes of 0/1
-      v.y = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
-      v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
-      v.w = ((bits >> 12) * 0x00204081u) & 0x01010101u;
+      v.x = collected_bytes(bits, 0);
+      v.y = collected_bytes(bits, 1);
+      v.z = collected_bytes(bits, 2);
+      v.w = collected_bytes(bits, 3);
       const uint64_t s_row = s0 + row;
       const uint32_t boff = off + c * 16;
 #ifndef ISSCABAC_ABL_NO_STORE
@@ -576,16 +583,17 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
               const uint32_t cw = word_of(wc, g);
               if (!hi) {
+                const CtxQuad z = stx.prep4(cw);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if ((k & 1) == 0) dec_topup_nocheck(d, src);
-                  ob |= dec_bin(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
+                  ob = collect_bin(ob, dec_bin_at_b1(d, stx.addr_of(z, k), stx));
                 }
               } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if ((k & 1) == 0) dec_topup_nocheck(d, src);
-                  ob |= dec_bin_any(d, (cw >> (8 * k)) & 0xFFu, stx) << (4 * g + k);
+                  ob = collect_bin(ob, dec_bin_any_b1(d, (cw >> (8 * k)) & 0xFFu, stx));
                 }
               }
             }
@@ -594,15 +602,17 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             // inactive lanes)
 #pragma unroll 1
             for (int k = 0; k < 16; k++) {
+              uint32_t w = 0;
               if (i0 + k < n) {
                 if (d.sh < 8) dec_refill(d, src);
                 const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-                ob |= dec_bin_any(d, cx, stm) << k;
+                w = dec_bin_any_b1(d, cx, stm);
               }
+              ob = collect_bin(ob, w);
             }
           }
         }
-        obits[cidx * 64 + lane] = (uint16_t)ob;
+        obits[cidx * 64 + lane] = ob;
       }
       wave_lds_sync();
     }

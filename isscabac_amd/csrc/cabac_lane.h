@@ -73,17 +73,79 @@ CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 CABAC_HD uint32_t q_from_packed(uint32_t p) { return p << 1; }
 CABAC_HD uint32_t packed_from_q(uint32_t q) { return q >> 1; }
 
+// rangeTabLps[state][(range >> 6) & 3] out of the state's table row (range is 256..510)
+CABAC_HD uint32_t lps_of(uint32_t row, uint32_t range) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ISSCABAC_NO_ALIGNBYTE)
+  // v_alignbyte_b32 shifts {row, row} right by (range >> 6) bytes; whether the hardware takes 2 or more bits of the
+  // byte count (range >> 6 is 4..7), the low byte of the result is byte (range >> 6) & 3 of row
+  return __builtin_amdgcn_alignbyte(row, row, range >> 6) & 0xFFu;
+#else
+  return (row >> ((range >> 3) & 0x18u)) & 0xFFu;
+#endif
+}
+
 // Next-state table entry of one state s, both transitions in one word so that a single lookup serves
 // ContextModel::updateLPS and updateMPS (ref: CABAC/ContextModel.cpp:107-123, tables :136-158), in the
 // doubled representation and without the mps bit (xor the old mps bit back in):
-//   byte 0 = min(s + 1, 62) << 2                       -- MPS successor
-//   byte 1 = (transIdxLps[s] << 2) | (s == 0 ? 2 : 0)  -- LPS successor; the MPS flips only when an LPS hits state 0
+//   bits 0..7   = min(s + 1, 62) << 2                       -- MPS successor
+//   bits 10..17 = (transIdxLps[s] << 2) | (s == 0 ? 2 : 0)  -- LPS successor; the MPS flips only when an LPS hits state 0
+// The LPS field sits at bit 10 (not 8) so that the shift amount `lps_mask & 10` doubles as "bit 1 = this bin was an
+// LPS": q ^ (lps_mask & 10) then carries the decoded bin (mps ^ lps) at bit 1 (bin_word_b1).
+constexpr uint32_t kLpsShift = 10;
 constexpr uint32_t next_state_entry(uint32_t s, uint32_t trans) {
-  return ((s < 62 ? s + 1 : s) << 2) | (((trans << 2) | (s == 0 ? 2u : 0u)) << 8);
+  return ((s < 62 ? s + 1 : s) << 2) | (((trans << 2) | (s == 0 ? 2u : 0u)) << kLpsShift);
 }
 // lps_mask: 0 for an MPS, ~0 for an LPS.  Only the low byte of the result is meaningful (it is stored as a byte).
 CABAC_HD uint32_t next_state_q(uint32_t q, uint32_t lps_mask, uint32_t entry) {
-  return (entry >> (lps_mask & 8u)) ^ (q & 2u);
+  return (entry >> (lps_mask & kLpsShift)) ^ (q & 2u);
+}
+// a word whose bit 1 is the value of the bin just coded with state q (bit 0 is 0, the rest is garbage)
+CABAC_HD uint32_t bin_word_b1(uint32_t q, uint32_t lps_mask) { return q ^ (lps_mask & kLpsShift); }
+
+// v_perm_b32: byte i of the result = byte number sel.byte[i] of the eight bytes {hi, lo} (0..3 = lo, 4..7 = hi)
+CABAC_HD uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t x = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) r |= (uint32_t)((x >> (8u * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+  return r;
+#endif
+}
+// v_alignbit_b32: the low 32 bits of {hi, lo} >> s
+CABAC_HD uint32_t alignbit_b32(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31u));
+#endif
+}
+// Decoded bins are collected two bits per bin: one v_alignbit moves bits 1:0 of a bin word into bits 31:30 of the
+// accumulator and everything older two places down.  After 16 bins, bin j of the 16 sits at bit 2j + 1.
+CABAC_HD uint32_t collect_bin(uint32_t acc, uint32_t bin_word) { return alignbit_b32(bin_word, acc, 2); }
+// bins 4w .. 4w+3 of a collected 16-bin word as four bytes of 0/1 (bin 4w in byte 0): the bins sit at bits 1,3,5,7 of
+// byte w; (1 + 2^6 + 2^12 + 2^18) moves bit 2i to bit 8i and no carry of the product reaches those positions
+CABAC_HD uint32_t collected_bytes(uint32_t acc, int w) {
+  return (((acc >> (8 * w + 1)) & 0x55u) * 0x00041041u) & 0x01010101u;
+}
+
+// Offsets of four contexts' state bytes in the kernels' LDS state image, from the four ctx bytes of one input word:
+// context c lives at (c / 4) * 256 + lane * 4 + c % 4 (see LdsStates), i.e. offset X(c) = ((c >> 2) << 8) | (c & 3)
+// before the lane term.  z01 = X(c0) | X(c1) << 16, z23 = X(c2) | X(c3) << 16: 3 + 2 instructions per four bins
+// instead of 4 per bin, and the per-bin address is one add with a 16-bit operand select.
+struct CtxQuad {
+  uint32_t z01, z23;
+};
+CABAC_HD CtxQuad lds_ctx_quad(uint32_t cw) {
+  const uint32_t lo2 = cw & 0x03030303u, hi6 = (cw >> 2) & 0x3F3F3F3Fu;
+  CtxQuad z;
+  z.z01 = perm_b32(hi6, lo2, 0x05010400u);
+  z.z23 = perm_b32(hi6, lo2, 0x07030602u);
+  return z;
+}
+CABAC_HD uint32_t quad_field(const CtxQuad &z, int k) {
+  return k == 0 ? (z.z01 & 0xFFFFu) : k == 1 ? (z.z01 >> 16) : k == 2 ? (z.z23 & 0xFFFFu) : (z.z23 >> 16);
 }
 // ~0 if bit 1 of x is set, else 0
 CABAC_HD uint32_t mask_from_bit1(uint32_t x) { return (uint32_t)((int32_t)(x << 30) >> 31); }
@@ -109,12 +171,12 @@ CABAC_HD void enc_start(EncCore &e) {  // ref: CABAC_ArithmeticEncoder.cpp:54-68
 
 // States policy: load(ctx) -> doubled state q, store(ctx, q) (stores the low byte), lps_row(q), next_entry(q)
 // (plus addr / load_at / store_at for the quad variants).  b1: any word whose bit 1 is the bin.
-template <class States>
-CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
-  const uint32_t q = st.load(ctx);
+template <class States, class Addr>
+CABAC_HD void enc_bin_at(EncCore &e, uint32_t b1, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
   const uint32_t row = st.lps_row(q);
   const uint32_t nx = st.next_entry(q);  // unconditional: the lookup may be a cross-lane op
-  const uint32_t lps = (row >> ((e.range >> 3) & 0x18u)) & 0xFFu;  // column (range >> 6) & 3
+  const uint32_t lps = lps_of(row, e.range);  // column (range >> 6) & 3
   const uint32_t rmps = e.range - lps;
   const uint32_t m = mask_from_bit1(b1 ^ q);  // ~0: bin != mps
   // new range before renormalisation; its leading zeros give the shift for both paths:
@@ -124,7 +186,11 @@ CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   e.low = (e.low + (rmps & m)) << n;
   e.range = r << n;
   e.W += (int32_t)n;
-  st.store(ctx, next_state_q(q, m, nx));
+  st.store_at(at, next_state_q(q, m, nx));
+}
+template <class States>
+CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
+  enc_bin_at(e, b1, st.addr(ctx), st);
 }
 
 // Four context bins of one stream at once, state bytes read up front and forwarded in registers where
@@ -161,7 +227,7 @@ CABAC_HD void enc_quad(EncCore &e, uint32_t bw, uint32_t cw, States &st) {
 #pragma unroll
 #endif
   for (int k = 0; k < 4; k++) {
-    const uint32_t lps = (rows[k] >> ((e.range >> 3) & 0x18u)) & 0xFFu;
+    const uint32_t lps = lps_of(rows[k], e.range);
     const uint32_t rmps = e.range - lps;
     const uint32_t r = rmps ^ ((rmps ^ lps) & ms[k]);
     const uint32_t n = clz32(r) - 23u;
@@ -180,7 +246,7 @@ CABAC_HD void enc_bin_any(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   const uint32_t q = st.load(c);
   const uint32_t row = st.lps_row(q);
   const uint32_t nx = st.next_entry(q);
-  const uint32_t lps = (row >> ((e.range >> 3) & 0x18u)) & 0xFFu;
+  const uint32_t lps = lps_of(row, e.range);
   const uint32_t rmps = e.range - lps;
   const uint32_t m = ep ? 0u : mask_from_bit1(b1 ^ q);
   const uint32_t r = ep ? e.range : (rmps ^ ((rmps ^ lps) & m));
@@ -403,12 +469,13 @@ CABAC_HD void dec_start(DecCore &d, Src &src) {  // ref: CABAC_ArithmeticDecoder
   dec_refill(d, src);
 }
 
-template <class States>
-CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
-  const uint32_t q = st.load(ctx);
+// returns a word whose bit 1 is the decoded bin (bit 0 is 0): what collect_bin() takes
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_at_b1(DecCore &d, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
   const uint32_t row = st.lps_row(q);
   const uint32_t nx = st.next_entry(q);
-  const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;
+  const uint32_t lps = lps_of(row, d.range);
   const uint32_t rmps = d.range - lps;
   const uint32_t scaled = rmps << d.sh;
   const uint32_t m = d.v >= scaled ? ~0u : 0u;  // ~0: LPS
@@ -417,8 +484,12 @@ CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
   d.v -= scaled & m;
   d.range = r << n;
   d.sh -= (int32_t)n;
-  st.store(ctx, next_state_q(q, m, nx));
-  return ((q >> 1) ^ m) & 1u;
+  st.store_at(at, next_state_q(q, m, nx));
+  return bin_word_b1(q, m);
+}
+template <class States>
+CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
+  return (dec_bin_at_b1(d, st.addr(ctx), st) >> 1) & 1u;
 }
 
 // Four context bins at once, decoder side: state bytes read up front and forwarded like enc_quad.  The per-bin
@@ -437,7 +508,7 @@ CABAC_HD uint32_t dec_quad(DecCore &d, uint32_t cw, States &st, Src &src) {
     if (CABAC_WAVE_ANY(d.sh < 8)) {                                  \
       if (d.sh < 8) dec_refill(d, src);                              \
     }                                                                \
-    const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;  \
+    const uint32_t lps = lps_of(row, d.range);  \
     const uint32_t rmps = d.range - lps;                             \
     const uint32_t scaled = rmps << d.sh;                            \
     const uint32_t m = d.v >= scaled ? ~0u : 0u;                     \
@@ -466,13 +537,13 @@ CABAC_HD uint32_t dec_quad(DecCore &d, uint32_t cw, States &st, Src &src) {
 }
 
 template <class States>
-CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
+CABAC_HD uint32_t dec_bin_any_b1(DecCore &d, uint32_t ctx, States &st) {  // bin at bit 1, bit 0 = 0
   const bool ep = ctx == kBypass;
   const uint32_t c = ep ? 0u : ctx;
   const uint32_t q = st.load(c);
   const uint32_t row = st.lps_row(q);
   const uint32_t nx = st.next_entry(q);
-  const uint32_t lps = (row >> ((d.range >> 3) & 0x18u)) & 0xFFu;
+  const uint32_t lps = lps_of(row, d.range);
   const uint32_t rmps = d.range - lps;
   const int32_t sh = d.sh - (ep ? 1 : 0);
   const uint32_t scaled = (ep ? d.range : rmps) << sh;
@@ -484,7 +555,11 @@ CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
   d.sh = sh - (int32_t)n;
   const uint32_t qn = next_state_q(q, m, nx);
   st.store(c, ep ? q : qn);
-  return ep ? (m & 1u) : (((q >> 1) ^ m) & 1u);
+  return ep ? (m & 2u) : bin_word_b1(q, m);
+}
+template <class States>
+CABAC_HD uint32_t dec_bin_any(DecCore &d, uint32_t ctx, States &st) {
+  return (dec_bin_any_b1(d, ctx, st) >> 1) & 1u;
 }
 
 CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331

@@ -37,6 +37,9 @@ struct GlobalStates {
   uint8_t *q;
   __device__ uint32_t load(uint32_t c) const { return q[c]; }
   __device__ void store(uint32_t c, uint32_t v) const { q[c] = (uint8_t)v; }
+  __device__ uint32_t addr(uint32_t c) const { return c; }
+  __device__ uint32_t load_at(uint32_t a) const { return q[a]; }
+  __device__ void store_at(uint32_t a, uint32_t v) const { q[a] = (uint8_t)v; }
   __device__ uint32_t lps_row(uint32_t v) const { return s_lps_rows[v >> 2]; }
   __device__ uint32_t next_entry(uint32_t v) const { return s_next.e[v >> 2]; }
 };

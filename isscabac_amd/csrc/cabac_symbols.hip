@@ -34,6 +34,8 @@ struct SymStates {
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t q) const { *addr(c) = (uint8_t)q; }
+  __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
+  __device__ __forceinline__ void store_at(uint8_t *a, uint32_t q) const { *a = (uint8_t)q; }
   __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return tab[q >> 2]; }
   __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return tab[64 + (q >> 2)]; }
 };

@@ -196,6 +196,20 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
 }
 
 
+// the kernels' packed helpers: state-byte offsets of four contexts, and 16 decoded bins collected two bits apiece
+void lane_ctx_quad(uint32_t cw, uint32_t *out4) {
+  const CtxQuad z = lds_ctx_quad(cw);
+  for (int k = 0; k < 4; k++) out4[k] = quad_field(z, k);
+}
+void lane_collect16(const uint32_t *bin_words, uint8_t *bytes16) {
+  uint32_t acc = 0xDEADBEEFu;
+  for (int j = 0; j < 16; j++) acc = collect_bin(acc, bin_words[j]);
+  for (int w = 0; w < 4; w++) {
+    const uint32_t b = collected_bytes(acc, w);
+    std::memcpy(bytes16 + 4 * w, &b, 4);
+  }
+}
+
 // symbol-level front end (cabac_symbols.h): params = {method, k, nq, selector, types, nlbp, col_rows}
 long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params, const uint8_t *ctx_init, int nctx,
                        uint8_t *out, size_t cap, uint32_t *nbins_out) {

@@ -213,3 +213,23 @@ def test_whole_matrix_single_stream_mode(lane, oracle):
         if cols > 1:  # and it is NOT the concatenation of independently coded columns
             per_col, _ = oracle.iss_encode_column(G[:, 0], nq, method, k, 15, 3, init)
             assert got[:len(per_col)].tobytes() != per_col.tobytes() or len(got) != len(per_col)
+
+
+def test_packed_helpers_ctx_quad_and_bin_collection(lane):
+    """lds_ctx_quad: four state-byte offsets per ctx word; collect_bin/collected_bytes: 16 bins, two bits apiece."""
+    rng = np.random.default_rng(5)
+    out4 = (C.c_uint32 * 4)()
+    for cw in [0, 0x7F7F7F7F, 0x03020100, 0x3F3E3D3C] + [int(x) & 0x7F7F7F7F for x in rng.integers(0, 2**32, 200)]:
+        lane.lane_ctx_quad.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+        lane.lane_ctx_quad(cw, out4)
+        for k in range(4):
+            c = (cw >> (8 * k)) & 0xFF
+            assert out4[k] == ((c >> 2) << 8) | (c & 3)
+    lane.lane_collect16.argtypes = [C.POINTER(C.c_uint32), u8p]
+    for _ in range(200):
+        bins = rng.integers(0, 2, 16)
+        garbage = [int(g) for g in rng.integers(0, 2**32, 16, dtype=np.uint64)]
+        words = (C.c_uint32 * 16)(*[(g & 0xFFFFFFFC) | (int(b) << 1) for g, b in zip(garbage, bins)])
+        got = np.zeros(16, np.uint8)
+        lane.lane_collect16(words, _p(got))
+        assert got.tolist() == bins.tolist()

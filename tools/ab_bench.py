@@ -15,7 +15,7 @@ if "--rounds" in sys.argv:
 res = {l: {"encode": [], "decode": [], "value": []} for l in libs}
 for r in range(rounds):
     for l in libs:
-        env = dict(os.environ, ISSCABAC_LIB=os.path.abspath(l))
+        env = dict(os.environ, ISSCABAC_LIB=os.path.abspath(l), ISSCABAC_BENCH_FULL_CAP="1")
         out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--no-verify"],
                              env=env, capture_output=True, text=True)
         try:
