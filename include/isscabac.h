@@ -15,7 +15,8 @@
  *     file, ref: CABAC/SimpleCABACMex.cpp:69-80).  A *batch* is S streams coded in one call.
  *   - bins / ctx arrays are stream-major: element i of stream s lives at [s * pitch + i]
  *     (a MATLAB B x S uint8 matrix, column-major, is exactly this with pitch = B).
- *     pitch must be a multiple of 16 and the base pointers 16-byte aligned.
+ *     pitch must be a multiple of 16, at most ISSCABAC_MAX_PITCH, and the base pointers 16-byte aligned
+ *     (the kernels address a wave's 64 rows with 32-bit offsets; one longer stream goes through a stream handle).
  *   - ctx[i] = context index 0..nctx-1, or ISSCABAC_BYPASS (0xFF) for an equiprobable bin
  *     (ref: encodeBinEP, CABAC/CABAC_ArithmeticEncoder.cpp:250-270 -- not reachable through the
  *     reference MEX; additive).
@@ -40,6 +41,7 @@ extern "C" {
 
 #define ISSCABAC_BYPASS 0xFFu
 #define ISSCABAC_MAX_CTX 255
+#define ISSCABAC_MAX_PITCH (1u << 25) /* bins per stream in one batch call */
 
 enum {
   ISSCABAC_OK = 0,

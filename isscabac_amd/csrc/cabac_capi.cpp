@@ -131,6 +131,9 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   if (S == 0) return fail(e, ISSCABAC_ERR_ARG, "%s: S must be > 0", who);
   if (pitch == 0 || (pitch & 15u)) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) must be a positive multiple of 16", who, pitch);
   if (nbins > pitch) return fail(e, ISSCABAC_ERR_ARG, "%s: nbins (%u) exceeds pitch (%u)", who, nbins, pitch);
+  if (pitch > ISSCABAC_MAX_PITCH)
+    return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) exceeds %u bins per stream (use a stream handle for longer streams)", who,
+                pitch, (unsigned)ISSCABAC_MAX_PITCH);
   if (nctx < 1 || nctx > ISSCABAC_MAX_CTX) return fail(e, ISSCABAC_ERR_ARG, "%s: nctx (%d) must be 1..%d", who, nctx, ISSCABAC_MAX_CTX);
   if (!ctx_init) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init is null", who);
   if (S > (1ull << 38)) return fail(e, ISSCABAC_ERR_ARG, "%s: S too large", who);

@@ -94,17 +94,20 @@ struct Tile {
   __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * 16 + (lane >> 2); }
   __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane & 3; }
 
-  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *base, uint64_t s0, uint64_t S, uint32_t pitch,
+  // rows = this wave's first row in the [S][pitch] array (wave-uniform pointer), nrows = how many of the wave's 64 rows
+  // exist (wave-uniform); the per-lane part of the address is a 32-bit offset (pitch <= 2^25, checked by the C ABI), so
+  // the row addresses cost one VGPR each instead of hoisted 64-bit pointers
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch,
                                               uint32_t off, int lane) {
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-      uint64_t s = s0 + row_of(k, lane);
-      s = s < S ? s : S - 1;
+      const uint32_t row = min(row_of(k, lane), nrows - 1u);
       const uint32_t boff = off + ch_of(lane) * 16;
+      const uint32_t voff = row * pitch + boff;
 #ifdef ISSCABAC_NT_STREAMS
-      r[k] = boff < pitch ? nt_load16(base + s * pitch + boff) : make_uint4(0, 0, 0, 0);
+      r[k] = boff < pitch ? nt_load16(rows + voff) : make_uint4(0, 0, 0, 0);
 #else
-      r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(base + s * pitch + boff) : make_uint4(0, 0, 0, 0);
+      r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(rows + voff) : make_uint4(0, 0, 0, 0);
 #endif
     }
   }
@@ -120,18 +123,6 @@ struct Tile {
   }
   __device__ static __forceinline__ void put_row_chunk(uint8_t *tile, int lane, int j, uint4 v) {
     *reinterpret_cast<uint4 *>(tile + lds_off(lane, j)) = v;
-  }
-  // LDS half image -> global, 32 contiguous bytes per stream: 2 lanes per row, 32 rows per instruction
-  __device__ static __forceinline__ void store_half(uint8_t *base, const uint8_t *tile, uint64_t s0, uint64_t S, uint32_t pitch,
-                                                    uint32_t off, int lane) {
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-      const uint32_t row = k * 32 + (lane >> 1), c = lane & 1;
-      const uint64_t s = s0 + row;
-      const uint32_t boff = off + c * 16;
-      if (s < S && boff < pitch)
-        *reinterpret_cast<uint4 *>(base + s * pitch + boff) = *reinterpret_cast<const uint4 *>(tile + lds_off(row, c));
-    }
   }
 };
 
@@ -208,8 +199,9 @@ struct RegStates {
 // (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
 // ------------------------------------------------------------------------------------------------
 struct SlotSink {
-  uint8_t *stage;  // LDS, this lane's 16 bytes
-  uint8_t *slot;   // HBM, this stream's slot (16-byte aligned)
+  uint8_t *stage;   // LDS, this lane's 16 bytes
+  uint8_t *slots;   // HBM, the wave's first slot (wave-uniform, 16-byte aligned)
+  uint32_t mine;    // byte offset of this stream's slot from there (64 slots stay far below 4 GiB)
   uint32_t pos;
   bool on;
   __device__ __forceinline__ void put(uint32_t b) {
@@ -218,7 +210,7 @@ struct SlotSink {
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
 #ifndef ISSCABAC_ABL_NO_SLOT_STORE
-      if (on) *reinterpret_cast<uint4 *>(slot + pos - 16) = v;
+      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
 #else
       asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #endif
@@ -231,7 +223,7 @@ struct SlotSink {
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
 #ifndef ISSCABAC_ABL_NO_SLOT_STORE
-      if (on) *reinterpret_cast<uint4 *>(slot + pos - 16) = v;
+      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
 #else
       asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #endif
@@ -239,7 +231,7 @@ struct SlotSink {
   }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
   __device__ __forceinline__ void close() {
-    if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slot + (pos & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+    if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slots + (mine + (pos & ~15u))) = *reinterpret_cast<const uint4 *>(stage);
   }
 };
 
@@ -271,7 +263,8 @@ using StatesFor = typename std::conditional<CM == 0, RegStates<XBAR>, LdsStates<
 template <int CM>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
@@ -313,15 +306,18 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   enc_start(e);
   SlotSink sink;
   sink.stage = stage + lane * 16;
-  sink.slot = a.slots + s * a.slot_stride;
+  sink.slots = a.slots + s0 * a.slot_stride;
+  sink.mine = (uint32_t)(s - s0) * (uint32_t)a.slot_stride;
   sink.pos = 0;
   sink.on = valid;
 
   const uint32_t nrounds = (nmax + Tile::T - 1) / Tile::T;
+  const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
+  const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
   uint4 pb[Tile::NLD], pc[Tile::NLD];
   if (nrounds) {
-    Tile::load(pb, a.bins, s0, a.S, a.pitch, 0, lane);
-    Tile::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
+    Tile::load(pb, bins_w, nrows, a.pitch, 0, lane);
+    Tile::load(pc, ctx_w, nrows, a.pitch, 0, lane);
   }
   wave_lds_sync();
   for (uint32_t t = 0; t < nrounds; t++) {
@@ -331,8 +327,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
       Tile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
       if (h == 1 && t + 1 < nrounds) {  // registers are free again: fetch the next round behind 32 bins of work
-        Tile::load(pb, a.bins, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
-        Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+        Tile::load(pb, bins_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
+        Tile::load(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
       }
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
@@ -400,15 +396,17 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 // decode kernel
 // ------------------------------------------------------------------------------------------------
 struct DevMem {
-  const uint8_t *base;  // 4-byte aligned address at or below the stream's first byte
-  uint64_t avail;       // bytes from base to the end of the payload buffer
+  const uint8_t *payload;  // whole payload buffer (wave-uniform)
+  uint64_t total;          // its size in bytes (wave-uniform)
+  uint64_t abase;          // 4-byte aligned offset at or below the stream's first byte
   struct alignas(4) Q4 { uint32_t w[4]; };
   struct Pair { uint64_t lo, hi; };
   // the last few bytes of the whole payload buffer: never read past its end
-  static __device__ __forceinline__ Pair load16_tail(const uint8_t *base, uint64_t avail, uint32_t off) {
+  static __device__ __forceinline__ Pair load16_tail(const uint8_t *payload, uint64_t total, uint64_t at) {
     Pair r{0, 0};
+#pragma unroll 1
     for (uint32_t i = 0; i < 16; i++) {
-      const uint64_t b = (uint64_t)off + i < avail ? base[off + i] : 0;
+      const uint64_t b = at + i < total ? payload[at + i] : 0;
       if (i < 8) r.lo |= b << (8 * i);
       else r.hi |= b << (8 * (i - 8));
     }
@@ -418,12 +416,13 @@ struct DevMem {
 #ifdef ISSCABAC_ABL_HOT_PAYLOAD
     off &= 60u;  // timing only: every fetch hits the same hot line
 #endif
-    if ((uint64_t)off + 16 <= avail) {
-      const Q4 q = *reinterpret_cast<const Q4 *>(base + off);
+    const uint64_t at = abase + off;
+    if (at + 16 <= total) {
+      const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
       hi = (uint64_t)q.w[2] | ((uint64_t)q.w[3] << 32);
     } else {
-      const Pair r = load16_tail(base, avail, off);
+      const Pair r = load16_tail(payload, total, at);
       lo = r.lo;
       hi = r.hi;
     }
@@ -444,7 +443,7 @@ struct DecArgs {
 // experiment knobs (tools/ab_bench.py builds variants with -D...).  ISSCABAC_ABL_* builds are TIMING-ONLY: they drop
 // one piece of work to price it, their results are wrong.
 #ifndef ISSCABAC_DEC_OCC
-#define ISSCABAC_DEC_OCC 3  // waves per SIMD the decode kernel is register-limited to (3 vs 4 measured equal)
+#define ISSCABAC_DEC_OCC 4  // waves per SIMD the decode kernel is register-limited to (4 measured 6% faster than 3)
 #endif
 #ifndef ISSCABAC_DEC_ROLLED
 #define ISSCABAC_DEC_ROLLED 1  // 1: loop over the chunk's four words, 0: all 16 bins unrolled
@@ -453,7 +452,8 @@ struct DecArgs {
 template <int CM>
 __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
@@ -496,14 +496,18 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint64_t abase = start & ~3ull;
   const uint32_t skew = (uint32_t)(start - abase);
   WindowSrc<DevMem> src;
-  src.mem.base = a.payload + abase;
-  src.mem.avail = a.payload_bytes > abase ? a.payload_bytes - abase : 0;
+  src.mem.payload = a.payload;
+  src.mem.total = a.payload_bytes;
+  src.mem.abase = abase;
   src.len = skew + len;
   src.start(skew);
   src.boundary();
   DecCore d;
   dec_start(d, src);
 
+  const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
+  const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
+  uint8_t *out_w = a.bins_out + s0 * a.pitch;
   // decoded bins are kept as BITS in LDS, 128 bins (16 bytes) per stream, and leave as full 128-byte row segments:
   // 32-byte segment stores were measured at 1.35 TB/s, 128-byte ones at 4 TB/s (tools/ubench/tile_bw.hip)
   // (two bits per bin as collect_bin() leaves them: bin j of a 16-bin chunk at bit 2j + 1 of the chunk's dword)
@@ -518,13 +522,13 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       v.y = collected_bytes(bits, 1);
       v.z = collected_bytes(bits, 2);
       v.w = collected_bytes(bits, 3);
-      const uint64_t s_row = s0 + row;
       const uint32_t boff = off + c * 16;
+      const uint32_t voff = row * a.pitch + boff;  // 32-bit: see Tile::load
 #ifndef ISSCABAC_ABL_NO_STORE
 #if defined(ISSCABAC_NT_STREAMS) || defined(ISSCABAC_NT_STORES)
-      if (s_row < a.S && boff < a.pitch) nt_store16(a.bins_out + s_row * a.pitch + boff, v);
+      if (row < nrows && boff < a.pitch) nt_store16(out_w + voff, v);
 #else
-      if (s_row < a.S && boff < a.pitch) *reinterpret_cast<uint4 *>(a.bins_out + s_row * a.pitch + boff) = v;
+      if (row < nrows && boff < a.pitch) *reinterpret_cast<uint4 *>(out_w + voff) = v;
 #endif
 #endif
     }
@@ -532,7 +536,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 
   const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
   uint4 pc[Tile::NLD];
-  if (nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, 0, lane);
+  if (nrounds) Tile::load(pc, ctx_w, nrows, a.pitch, 0, lane);
   wave_lds_sync();
   bool have_out = false;
   uint32_t out_off = 0;
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #ifndef ISSCABAC_ABL_NO_PAYLOAD
         if (live) src.boundary();
 #else
-        src.cnt = 8;
+        src.cend = src.bpos + 64u;
 #endif
         if (j == 0) {
           // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
@@ -559,17 +563,18 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             wave_lds_sync();  // the bit tile is rewritten from here on
             have_out = false;
           }
-          if (h == 1 && t + 1 < nrounds) Tile::load(pc, a.ctx, s0, a.S, a.pitch, (t + 1) * Tile::T, lane);
+          if (h == 1 && t + 1 < nrounds) Tile::load(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
         }
         if (live) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
           const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
           if (full) {
-            // every lane decodes 16 bins: convergent, tables through the crossbar.  A top-up leaves sh >= 16, a context
-            // bin takes at most 6 bits and needs sh >= 7, a bypass bin takes 1 and needs sh >= 8: two bins per top-up
-            // never run short, so there is no per-bin look-ahead test; the window is re-based every 8 bins, which
-            // covers the 4 x 2 bytes four top-ups can take.  `hi` (wave-uniform) picks the bypass-capable step.
+            // every lane decodes 16 bins: convergent, tables through the crossbar.  One bit-granular top-up per four
+            // bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs sh >= 7, a bypass bin takes 1 and
+            // needs sh >= 8, so three bins never run short and only the fourth is guarded (wave-uniform, practically
+            // never taken); the window is re-based at the chunk boundary and, wave-uniformly, whenever a lane has fewer
+            // than the 24 bits a top-up can take.  `hi` (wave-uniform) picks the bypass-capable step.
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #else
@@ -577,22 +582,23 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
             for (int g = 0; g < 4; g++) {  // rolled over the four words: keeps the live register set small
 #ifndef ISSCABAC_ABL_NO_PAYLOAD
-              if (g == 2) src.rebase();
+              if (g != 0) src.ensure(24);  // g == 0: boundary() has just re-based
 #else
-              src.cnt = 8;
+              src.cend = src.bpos + 64u;
 #endif
               const uint32_t cw = word_of(wc, g);
+              dec_topup_nocheck(d, src);
               if (!hi) {
                 const CtxQuad z = stx.prep4(cw);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                  if ((k & 1) == 0) dec_topup_nocheck(d, src);
+                  if (k == 3) dec_guard(d, src, 7);
                   ob = collect_bin(ob, dec_bin_at_b1(d, stx.addr_of(z, k), stx));
                 }
               } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                  if ((k & 1) == 0) dec_topup_nocheck(d, src);
+                  if (k == 3) dec_guard(d, src, 8);
                   ob = collect_bin(ob, dec_bin_any_b1(d, (cw >> (8 * k)) & 0xFFu, stx));
                 }
               }
@@ -628,8 +634,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   }
   if (have_out) store_out(out_off);
   if (valid && a.status) {
-    const uint8_t *p = a.payload + start;
-    a.status[s] = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+    const uint64_t first = a.offsets[s];  // re-read: keeping it live through the loop costs two registers
+    const uint32_t sk = (uint32_t)first & 3u;
+    const uint8_t *p = a.payload + first;
+    a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
 }
 

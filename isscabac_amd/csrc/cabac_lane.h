@@ -421,42 +421,44 @@ CABAC_HD void enc_finish16(EncCore &e, Sink &out) {
 // Decoder
 // ------------------------------------------------------------------------------------------------
 // v holds the code value with (sh) fraction bits below the 9-bit range: the reference's m_uiValue is
-// v >> (sh - 7) with its not-yet-read low bits zero.  Invariant between bins: 8 <= sh <= 23.
+// v >> (sh - 7) with its not-yet-read low bits zero.  A context bin needs sh >= 7 and takes at most 6 bits, a bypass
+// bin needs sh >= 8 and takes 1; sh <= 23 keeps v inside 32 bits.
 struct DecCore {
   uint32_t v;
   uint32_t range;
   int32_t sh;
-  uint32_t nread;  // bytes merged into v so far (the reference has read fewer or as many)
 };
 
-// Src policy: uint32_t next() -> next payload byte (0xFF past the end, like fstream::get at EOF)
+// Src policy: uint32_t next() -> next payload byte (0xFF past the end, like fstream::get at EOF);
+// for the top-ups additionally feed(v, g) / feed_nocheck(v, g) -> (v << g) | next g payload bits, g in 0..23
 template <class Src>
 CABAC_HD void dec_refill(DecCore &d, Src &src) {
   while (d.sh <= 15) {
     d.v = (d.v << 8) | src.next();
     d.sh += 8;
-    d.nread++;
   }
 }
 
-// branch-free top-up used at fixed points of the bin loop: brings sh to 16..23 taking at most two bytes
-// (Src::take(k), k in 0..2, returns the next k bytes as a big-endian integer)
+// bit-granular top-up used at fixed points of the bin loop: fills v up to sh = 23
 template <class Src>
 CABAC_HD void dec_topup(DecCore &d, Src &src) {
-  const uint32_t k = (uint32_t)(23 - d.sh) >> 3;
-  d.v = (d.v << (8u * k)) | src.take(k);
-  d.sh += (int32_t)(8u * k);
-  d.nread += k;
+  d.v = src.feed(d.v, (uint32_t)(23 - d.sh));
+  d.sh = 23;
 }
-
-// the same when the caller knows the window holds at least two bytes (the kernels' fast path re-bases the window
-// every 8 bins = 4 top-ups of <= 2 bytes): no availability test, no branch
+// the same when the caller knows the window holds the bits (the kernels re-base the window every 8 bins: two top-ups
+// of at most 24 bits each): no availability test, no branch
 template <class Src>
 CABAC_HD void dec_topup_nocheck(DecCore &d, Src &src) {
-  const uint32_t k = (uint32_t)(23 - d.sh) >> 3;
-  d.v = (d.v << (8u * k)) | src.take_nocheck(k);
-  d.sh += (int32_t)(8u * k);
-  d.nread += k;
+  d.v = src.feed_nocheck(d.v, (uint32_t)(23 - d.sh));
+  d.sh = 23;
+}
+// After a top-up three context bins can never run short (23 - 2 * 6 >= 7); before a fourth one the wave checks and,
+// practically never, tops up the lanes that need it.
+template <class Src>
+CABAC_HD void dec_guard(DecCore &d, Src &src, int32_t min_sh) {
+  if (CABAC_WAVE_ANY(d.sh < min_sh)) {
+    if (d.sh < min_sh) dec_topup(d, src);
+  }
 }
 
 template <class Src>
@@ -465,7 +467,6 @@ CABAC_HD void dec_start(DecCore &d, Src &src) {  // ref: CABAC_ArithmeticDecoder
   d.v = src.next() << 8;
   d.v |= src.next();
   d.sh = 7;
-  d.nread = 2;
   dec_refill(d, src);
 }
 
@@ -572,12 +573,13 @@ CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331
 
 // decodeBinTrm + the two asserts of finish() as flags; len = payload length of this stream.
 // last_byte_at(i) must return payload byte i (i < len).
+// nbits = payload bits merged into v so far (8 x the bytes taken from a byte source).
 template <class ByteAt>
-CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t len, ByteAt byte_at) {
+CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t nbits, uint32_t len, ByteAt byte_at) {
   uint32_t status = 0;
   d.range -= 2;
   // bits the reference has shifted in total; it has read 2 + floor(shifted / 8) bytes
-  uint32_t shifted = 8u * (d.nread - 2u) - (uint32_t)(d.sh - 7);
+  uint32_t shifted = nbits - 16u - (uint32_t)(d.sh - 7);
   if (!(d.v >= (d.range << d.sh))) {
     status |= 1u;                      // terminate bin != 1 ...
     if (d.range < 256u) shifted += 1;  // ... and the reference then renormalises by one bit (:452-463)
@@ -591,38 +593,36 @@ CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t len, ByteAt byte_at) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Byte source for the decoder: a 64-bit big-endian window `cur` over the stream's payload bytes that is
-// re-based at wave-uniform points (boundary()) from a 16-byte piece fetched one boundary earlier, so the
-// HBM/L2 latency of the fetch is never on the bin loop's critical path.
+// Bit source for the decoder: a 64-bit MSB-first window `cur` over the stream's payload that is re-based at
+// wave-uniform points (boundary() / ensure()) from a 16-byte piece fetched one boundary earlier, so the HBM/L2 latency
+// of the fetch is never on the bin loop's critical path.  Positions are in bits from the Mem policy's base.
 // Mem policy: void load16(uint32_t off, uint64_t &lo, uint64_t &hi) -> payload bytes [a, a+16) of this
 // stream, a = off rounded down to 4 (little-endian in lo, hi); returns nothing past the payload buffer.
 // ------------------------------------------------------------------------------------------------
 template <class Mem>
 struct WindowSrc {
   Mem mem;
-  uint32_t len;   // payload bytes of this stream; reads at or past len give 0xFF (fstream EOF)
-  uint32_t pos;   // offset of the next byte to hand out
-  uint64_t cur;   // next bytes, big endian (next byte in bits 63..56)
-  int32_t cnt;    // valid bytes in cur
-  // piece in use: bytes [ppos, ppos + 16), complete (no load pending on these registers)
-  uint64_t plo, phi;
-  uint32_t ppos;
-  // piece in flight: bytes [npos, npos + 16), written by the most recent prefetch()
+  uint32_t len;   // payload bytes of this stream; bytes at or past len read as 0xFF (fstream EOF)
+  uint32_t bpos;  // bit position of the next unread bit
+  uint64_t cur;   // the next bits, MSB first
+  uint32_t cend;  // bit position just past the last bit cur holds
+  // piece in use: payload bits [pbit, pbit + 128) as one big-endian number, EOF fill applied, complete (no load pending
+  // on these registers): ph = its upper 64 bits, pl1 = its lower 64 bits >> 1 (pre-shifted for the funnel in rebase())
+  uint64_t ph, pl1;
+  uint32_t pbit;
+  // piece in flight: bytes [npos, npos + 16) as loaded (little endian), written by the most recent prefetch()
   uint64_t nlo, nhi;
   uint32_t npos;
 
+  CABAC_HD uint32_t byte_pos() const { return bpos >> 3; }
+  CABAC_HD int32_t avail_bits() const { return (int32_t)(cend - bpos); }
   CABAC_HD void prefetch() {
-    npos = pos & ~3u;
+    npos = byte_pos() & ~3u;
     mem.load16(npos, nlo, nhi);
   }
-  CABAC_HD void eof_fill() {
-    if (pos + 8u > len) {
-      const uint32_t k = len > pos ? len - pos : 0u;  // real bytes in cur
-      cur |= k == 0 ? ~0ull : (~0ull >> (8u * k));
-    }
-  }
-  // rare paths are free functions taking and returning values, so that the window itself never has
-  // its address taken and stays in registers
+  // ~0 >> (8 * k) for k real bytes in front of the fill, k in 0..8
+  static CABAC_HD uint64_t ff_after(uint32_t k) { return k == 0 ? ~0ull : (k >= 8 ? 0ull : (~0ull >> (8u * k))); }
+  // slow path: cur = the payload from bpos on, fetched now (blocking)
   static CABAC_HD_RARE uint64_t fetch8(Mem m, uint32_t at) {
     uint64_t a, b;
     const uint32_t base = at & ~3u, d = at - base;
@@ -630,63 +630,70 @@ struct WindowSrc {
     return d == 0 ? a : (a >> (8u * d)) | (b << (64u - 8u * d));
   }
   CABAC_HD void reload_blocking() {
-    cur = __builtin_bswap64(fetch8(mem, pos));
-    cnt = 8;
-    eof_fill();
+    const uint32_t at = byte_pos();
+    cur = __builtin_bswap64(fetch8(mem, at));
+    if (at + 8u > len) cur |= ff_after(len > at ? len - at : 0u);
+    cur <<= bpos & 7u;
+    cend = (bpos & ~7u) + 64u;
   }
-  CABAC_HD void start(uint32_t first) {
-    pos = first;
-    cnt = 0;
+  // make the piece in flight the piece in use (waits for its load)
+  CABAC_HD void adopt() {
+    ph = __builtin_bswap64(nlo);
+    uint64_t pl = __builtin_bswap64(nhi);
+    if (CABAC_WAVE_ANY(npos + 16u > len)) {  // only near the stream's end
+      const uint32_t k = len > npos ? len - npos : 0u;  // real bytes in the piece
+      if (k < 16u) {
+        ph |= ff_after(k);
+        pl |= ff_after(k > 8u ? k - 8u : 0u);
+      }
+    }
+    pl1 = pl >> 1;
+    pbit = 8u * npos;
+  }
+  CABAC_HD void start(uint32_t first_byte) {
+    bpos = 8u * first_byte;
+    cend = bpos;
     cur = 0;
+    ph = pl1 = 0;
     prefetch();
-    plo = phi = 0;
-    ppos = npos;
+    pbit = 8u * npos;
   }
-  // re-base cur on the piece in use: cur = the 8 bytes at pos.  Touches no register with a load in flight.
+  // re-base cur on the piece in use: 64 bits from bpos on.  Touches no register with a load in flight.
   CABAC_HD void rebase() {
-    const uint32_t d = pos - ppos;
-    if (d <= 8u) {
-      const uint64_t x = d == 0 ? plo : (d == 8u ? phi : (plo >> (8u * d)) | (phi << (64u - 8u * d)));
-      cur = __builtin_bswap64(x);
-      cnt = 8;
-      eof_fill();
+    const uint32_t b = bpos - pbit;
+    if (b < 64u) {
+      cur = (ph << b) | (pl1 >> (63u - b));
+      cend = bpos + 64u;
     } else {
       reload_blocking();  // more than 8 bytes into the piece: rare
+    }
+  }
+  // wave-uniform: re-base when some lane's window holds fewer than n bits
+  CABAC_HD void ensure(int32_t n) {
+    if (CABAC_WAVE_ANY(avail_bits() < n)) {
+      if (avail_bits() < n) rebase();
     }
   }
   // every 16 bins: adopt the piece fetched one boundary ago (the only point that waits for a payload load), re-base,
   // and fetch a new piece once 4 bytes of the current one are used up -- on average every payload byte is requested
   // ~2x instead of ~10x (the re-reads were missing in L2)
   CABAC_HD void boundary() {
-    plo = nlo;
-    phi = nhi;
-    ppos = npos;
+    adopt();
     rebase();
-    if (pos - npos >= 4u) prefetch();
+    if (bpos - pbit >= 32u) prefetch();
   }
-  CABAC_HD uint32_t next() {
-    if (cnt == 0) reload_blocking();
-    const uint32_t b = (uint32_t)(cur >> 56);
-    cur <<= 8;
-    cnt--;
-    pos++;
-    return b;
+  // (v << g) | the next g bits, g in 0..23 (avail_bits() >= g is the caller's business): one 64-bit shift of {v, cur.hi}
+  CABAC_HD uint32_t feed_nocheck(uint32_t v, uint32_t g) {
+    const uint64_t pair = ((uint64_t)v << 32) | (cur >> 32);
+    cur <<= g;
+    bpos += g;
+    return (uint32_t)((pair << g) >> 32);
   }
-  CABAC_HD uint32_t take_nocheck(uint32_t k) {  // k in 0..2, cnt >= k guaranteed by the caller
-    const uint32_t x = (uint32_t)(cur >> 48) >> (16u - 8u * k);
-    cur <<= 8u * k;
-    cnt -= (int32_t)k;
-    pos += k;
-    return x;
+  CABAC_HD uint32_t feed(uint32_t v, uint32_t g) {
+    if ((int32_t)g > avail_bits()) rebase();
+    return feed_nocheck(v, g);
   }
-  CABAC_HD uint32_t take(uint32_t k) {  // k in 0..2
-    if ((int32_t)k > cnt) {
-      uint32_t x = 0;
-      for (uint32_t i = 0; i < k; i++) x = (x << 8) | next();
-      return x;
-    }
-    return take_nocheck(k);
-  }
+  CABAC_HD uint32_t next() { return feed(0u, 8u); }
 };
 
 }  // namespace isscabac

@@ -114,7 +114,7 @@ __global__ void k_stream_dec_bins(StreamDev *st, const uint8_t *payload, const u
 __global__ void k_stream_dec_finish(StreamDev *st, const uint8_t *payload, uint32_t *status) {
   if (threadIdx.x != 0) return;
   DecCore d = st->dec;
-  *status = dec_finish(d, st->dec_len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
+  *status = dec_finish(d, 8u * st->dec_pos, st->dec_len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
   st->dec = d;
 }
 

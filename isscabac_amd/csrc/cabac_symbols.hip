@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   for (uint32_t i = n_my; i < a.nsym; i++) row[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
-    a.status[s] = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+    a.status[s] = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
 }
 

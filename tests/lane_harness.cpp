@@ -141,7 +141,12 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   if (any) group = -group;
   const bool quads = group == 40;
   if (quads) group = 4;
-  const bool noguard = group == 2;  // kernel fast path: top-up every 2 context bins, no per-bin guard
+  // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
+  const bool noguard = group == 2;
+  if (noguard) group = 4;
+  bool has_bypass = any;  // the kernel guards with 8 instead of 7 when a chunk holds bypass bins
+  for (uint32_t i = 0; i < n; i++) has_bypass |= ctx[i] == kBypass;
+  const int32_t min_sh = has_bypass ? 8 : 7;
   HostStates st;
   st.init(ctx_init, nctx);
   uint32_t fast = 0, slow = 0, slow_refills = 0;
@@ -157,15 +162,16 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   dec_start(d, src);
   for (uint32_t i = 0; i < n; i++) {
     if (i % (uint32_t)chunk == 0) src.boundary();
-    else if (noguard && i % 8 == 0) src.rebase();
+    else if (noguard && i % 4 == 0) src.ensure(24);
     if (i % (uint32_t)group == 0) {
       if (noguard) {
-        if (src.cnt < 2) return 0xDEAD1000u | i;  // the no-check top-up would be wrong
+        if (src.avail_bits() < 23 - d.sh) return 0xDEAD1000u | i;  // the no-check top-up would be wrong
         dec_topup_nocheck(d, src);
       } else {
         dec_topup(d, src);
       }
     }
+    if (noguard && i % 4 == 3) dec_guard(d, src, min_sh);
     if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
         ctx[i + 3] != kBypass) {
       uint32_t cw;
@@ -185,7 +191,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
     else bins_out[i] = (uint8_t)(ctx[i] == kBypass ? dec_bin_ep(d) : dec_bin(d, ctx[i], st));
   }
   const uint8_t *p = buf + start;
-  uint32_t status = dec_finish(d, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+  uint32_t status = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   if (ctx_final) st.final_packed(ctx_final, nctx);
   if (counters) {
     counters[0] = fast;
@@ -265,7 +271,7 @@ uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, 
       w.n++;
     }
   }
-  return dec_finish(d, len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
+  return dec_finish(d, src.bpos, len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
 }
 
 }  // extern "C"

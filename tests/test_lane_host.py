@@ -103,7 +103,7 @@ def test_fuzz_vs_oracle(lane, oracle):
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
-                                         pad_back=int(rng.integers(0, 20)), group=40 if it % 2 else 4)
+                                         pad_back=int(rng.integers(0, 20)), group=(40, 4, 16, 2)[it % 4])
         assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes()
         slow += cnt[2]
     assert slow > 0  # the in-chunk refill path was exercised
@@ -121,6 +121,10 @@ def test_all_lps_worst_case_width(lane, oracle, golden):
     want = oracle.encode_stream(bins, ctx, init)
     got, _fin, mw = lane_encode(lane, bins, ctx, init, 16)
     assert got.tobytes() == want.tobytes() and 50 <= mw <= 62
+    # ... and the decoder's fast path at its worst: 6 bits per bin, the guard before every fourth bin fires
+    for group in (2, -2, 4):
+        dec, st, _, _ = lane_decode(lane, want, ctx, init, pad_front=3, pad_back=1, group=group)
+        assert st == 0 and (dec == bins).all()
 
 
 def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
