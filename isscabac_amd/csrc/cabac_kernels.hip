@@ -34,9 +34,13 @@ namespace isscabac {
 __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
 struct NextTab {
   uint32_t e[64];
-  constexpr NextTab() : e{} {
+  uint32_t e16[64];  // two 16-bit entries per dword: packed states 2i, 2i + 1
+  constexpr NextTab() : e{}, e16{} {
     constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
-    for (uint32_t s = 0; s < 64; s++) e[s] = next_state_entry(s, trans[s]);
+    for (uint32_t s = 0; s < 64; s++) {
+      e[s] = next_state_entry(s, trans[s]);
+      e16[s] = next_state_entry16(2 * s, trans[s]) | next_state_entry16(2 * s + 1, trans[s]) << 16;
+    }
   }
 };
 __device__ const NextTab c_next{};
@@ -52,7 +56,8 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
 }
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kTabBytes = 512;
+constexpr int kTabBytes = 768;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state entries
+constexpr int kTab16Off = 512;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -134,16 +139,31 @@ __device__ __forceinline__ uint32_t bin_at_bit1(const uint4 &v, int k) {
   return (k & 3) == 0 ? (w << 1) : (w >> (8 * (k & 3) - 1));
 }
 
+// Bin policy of the encode kernel (cabac_lane.h: enc_bin_at): the four bins of one input word, pre-shifted so that bin k
+// sits at bit 1 of byte k; xor with the state picks the byte in the same instruction (SDWA operand select)
+template <int K>
+struct BinOfWord {
+  uint32_t w2;  // input word << 1
+  __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
+    uint32_t r;
+    if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));
+    else if (K == 1) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(q), "v"(w2));
+    else if (K == 2) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(q), "v"(w2));
+    else asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w2));
+    return r;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // context-state policies (see cabac_lane.h: States)
 // ------------------------------------------------------------------------------------------------
 // One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
 // pick, lane l only ever touches bank l % 32.  TABLES: true = ds_bpermute from a VGPR that holds entry `lane`
 // (legal only while all 64 lanes are active), false = LDS copy of the tables (any exec mask).
-template <bool XBAR>
+template <bool XBAR, bool NEXT16 = false>
 struct LdsStates {
   uint8_t *base;        // wave's state region + lane * 4
-  const uint32_t *tab;  // LDS: [0..63] rangeTabLps rows, [64..127] next-state entries
+  const uint32_t *tab;  // LDS: [0..63] rangeTabLps rows, [64..127] next-state entries, then the 16-bit entries
   uint32_t row_tab, next_tab;
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
@@ -166,10 +186,18 @@ struct LdsStates {
   __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
   }
+  // NEXT16 (encode kernel): the 16-bit table entry of packed state q >> 1 lives at byte q of its table -- an LDS read
+  // with no address arithmetic, conflict-free (the 256-byte table covers each bank once), and one VALU less per bin
   __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
+    // (LDS address as an integer: the kernels' dynamic LDS starts at 0 -- they have no static __shared__, which the
+    // engine checks at start-up -- so the table offset folds into the instruction and q itself is the address)
+    if (NEXT16) return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(kTab16Off + q));
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
   }
 #endif
+  __device__ __forceinline__ uint32_t next_q(uint32_t q, uint32_t lps_mask, uint32_t entry) const {
+    return NEXT16 ? next_state_q16(lps_mask, entry) : next_state_q(q, lps_mask, entry);
+  }
 };
 // <= 4 contexts: the four state bytes live in one VGPR
 template <bool XBAR>
@@ -259,6 +287,8 @@ struct WaveLds {
 // ------------------------------------------------------------------------------------------------
 template <int CM, bool XBAR>
 using StatesFor = typename std::conditional<CM == 0, RegStates<XBAR>, LdsStates<XBAR>>::type;
+template <int CM>
+using EncStatesFor = typename std::conditional<CM == 0, RegStates<true>, LdsStates<true, true>>::type;
 
 template <int CM>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
@@ -269,6 +299,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
     tab[64 + tid] = c_next.e[tid];
+    tab[128 + tid] = c_next.e16[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -292,7 +323,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     const uint32_t ngrp = (a.nctx + 3) / 4;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  StatesFor<CM, true> stx;
+  EncStatesFor<CM> stx;
   StatesFor<CM, false> stm;
   if constexpr (CM == 0) {
     stx = {&packed, tab, c_lps_rows[lane], c_next.e[lane]};
@@ -342,7 +373,11 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
-            enc_bin_at(e, bin_at_bit1(wb, k), stx.addr_of(z, k & 3), stx);
+            const uint32_t w2 = word_of(wb, k >> 2) << 1;
+            if ((k & 3) == 0) enc_bin_at(e, BinOfWord<0>{w2}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_at(e, BinOfWord<1>{w2}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_at(e, BinOfWord<2>{w2}, stx.addr_of(z, 2), stx);
+            else enc_bin_at(e, BinOfWord<3>{w2}, stx.addr_of(z, 3), stx);
 #ifndef ISSCABAC_ABL_NO_FLUSH
 #ifdef ISSCABAC_FLUSH4
             if ((k & 3) == 3 && wave_any(e.W >= 29)) enc_flush16(e, sink);
@@ -458,6 +493,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
     tab[64 + tid] = c_next.e[tid];
+    tab[128 + tid] = c_next.e16[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -809,6 +845,15 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
+  // LdsStates<.., NEXT16> addresses its table by absolute LDS address: the dynamic LDS must start at 0
+  static int static_lds = -1;
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode<CM>));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
   hipLaunchKernelGGL((k_encode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
   return hipGetLastError();

@@ -99,6 +99,24 @@ constexpr uint32_t next_state_entry(uint32_t s, uint32_t trans) {
 CABAC_HD uint32_t next_state_q(uint32_t q, uint32_t lps_mask, uint32_t entry) {
   return (entry >> (lps_mask & kLpsShift)) ^ (q & 2u);
 }
+// The same transitions as a table of 128 16-bit entries indexed by the packed state p = q >> 1 = (state << 1) | mps,
+// each holding the complete successors (mps included): bits 0..7 after an MPS, bits 8..15 after an LPS.  Entry p sits
+// at byte address q, so an LDS lookup needs no address arithmetic, and the update is (entry >> (lps_mask & 8)).
+constexpr uint32_t next_state_entry16(uint32_t p, uint32_t trans) {
+  return (((p >> 1) < 62 ? (p >> 1) + 1 : (p >> 1)) << 2 | (p & 1u) << 1) |
+         ((trans << 2 | ((p & 1u) ^ ((p >> 1) == 0 ? 1u : 0u)) << 1) << 8);
+}
+CABAC_HD uint32_t next_state_q16(uint32_t lps_mask, uint32_t entry16) { return entry16 >> (lps_mask & 8u); }
+// States policies may provide next_q(q, lps_mask, entry) for their own entry format; the default is next_state_q
+template <class States>
+CABAC_HD auto next_q_of(const States &st, uint32_t q, uint32_t m, uint32_t nx, int) -> decltype(st.next_q(q, m, nx)) {
+  return st.next_q(q, m, nx);
+}
+template <class States>
+CABAC_HD uint32_t next_q_of(const States &, uint32_t q, uint32_t m, uint32_t nx, long) {
+  return next_state_q(q, m, nx);
+}
+
 // a word whose bit 1 is the value of the bin just coded with state q (bit 0 is 0, the rest is garbage)
 CABAC_HD uint32_t bin_word_b1(uint32_t q, uint32_t lps_mask) { return q ^ (lps_mask & kLpsShift); }
 
@@ -171,14 +189,19 @@ CABAC_HD void enc_start(EncCore &e) {  // ref: CABAC_ArithmeticEncoder.cpp:54-68
 
 // States policy: load(ctx) -> doubled state q, store(ctx, q) (stores the low byte), lps_row(q), next_entry(q)
 // (plus addr / load_at / store_at for the quad variants).  b1: any word whose bit 1 is the bin.
-template <class States, class Addr>
-CABAC_HD void enc_bin_at(EncCore &e, uint32_t b1, Addr at, States &st) {
+// Bin policy: xor_q(q) -> a word whose bit 1 is bin ^ mps (mps = bit 1 of q).  BinB1 wraps a word whose bit 1 is the bin.
+struct BinB1 {
+  uint32_t b1;
+  CABAC_HD uint32_t xor_q(uint32_t q) const { return b1 ^ q; }
+};
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_at(EncCore &e, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
   const uint32_t row = st.lps_row(q);
   const uint32_t nx = st.next_entry(q);  // unconditional: the lookup may be a cross-lane op
   const uint32_t lps = lps_of(row, e.range);  // column (range >> 6) & 3
   const uint32_t rmps = e.range - lps;
-  const uint32_t m = mask_from_bit1(b1 ^ q);  // ~0: bin != mps
+  const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
   // new range before renormalisation; its leading zeros give the shift for both paths:
   // LPS: clz32(lps) - 23 == sm_aucRenormTable[lps >> 3] (lps in 6..240); MPS: rmps in 128..510 -> 1 or 0
   const uint32_t r = rmps ^ ((rmps ^ lps) & m);
@@ -186,11 +209,11 @@ CABAC_HD void enc_bin_at(EncCore &e, uint32_t b1, Addr at, States &st) {
   e.low = (e.low + (rmps & m)) << n;
   e.range = r << n;
   e.W += (int32_t)n;
-  st.store_at(at, next_state_q(q, m, nx));
+  st.store_at(at, next_q_of(st, q, m, nx, 0));
 }
 template <class States>
 CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
-  enc_bin_at(e, b1, st.addr(ctx), st);
+  enc_bin_at(e, BinB1{b1}, st.addr(ctx), st);
 }
 
 // Four context bins of one stream at once, state bytes read up front and forwarded in registers where
@@ -254,7 +277,7 @@ CABAC_HD void enc_bin_any(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   e.low = ((e.low + (rmps & m)) << n) + ((ep && (b1 & 2u)) ? e.range : 0u);
   e.range = ep ? e.range : (r << n);
   e.W += (int32_t)n;
-  const uint32_t qn = next_state_q(q, m, nx);
+  const uint32_t qn = next_q_of(st, q, m, nx, 0);
   st.store(c, ep ? q : qn);
 }
 
@@ -485,7 +508,7 @@ CABAC_HD uint32_t dec_bin_at_b1(DecCore &d, Addr at, States &st) {
   d.v -= scaled & m;
   d.range = r << n;
   d.sh -= (int32_t)n;
-  st.store_at(at, next_state_q(q, m, nx));
+  st.store_at(at, next_q_of(st, q, m, nx, 0));
   return bin_word_b1(q, m);
 }
 template <class States>
@@ -554,7 +577,7 @@ CABAC_HD uint32_t dec_bin_any_b1(DecCore &d, uint32_t ctx, States &st) {  // bin
   d.v -= scaled & m;
   d.range = ep ? d.range : (r << n);
   d.sh = sh - (int32_t)n;
-  const uint32_t qn = next_state_q(q, m, nx);
+  const uint32_t qn = next_q_of(st, q, m, nx, 0);
   st.store(c, ep ? q : qn);
   return ep ? (m & 2u) : bin_word_b1(q, m);
 }

@@ -202,6 +202,21 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
 }
 
 
+// the 16-bit next-state table of the encode kernel against the one-entry-per-state table: mismatches over all
+// (state 0..62, mps, mps/lps) combinations
+int lane_next16_mismatches() {
+  int bad = 0;
+  for (uint32_t s = 0; s < 63; s++)
+    for (uint32_t mps = 0; mps < 2; mps++)
+      for (uint32_t lps = 0; lps < 2; lps++) {
+        const uint32_t q = (s << 2) | (mps << 1), m = lps ? ~0u : 0u;
+        const uint32_t want = next_state_q(q, m, kNext.e[s]) & 0xFFu;
+        const uint32_t got = next_state_q16(m, next_state_entry16(q >> 1, kTransLps[s])) & 0xFFu;
+        bad += want != got;
+      }
+  return bad;
+}
+
 // the kernels' packed helpers: state-byte offsets of four contexts, and 16 decoded bins collected two bits apiece
 void lane_ctx_quad(uint32_t cw, uint32_t *out4) {
   const CtxQuad z = lds_ctx_quad(cw);

@@ -220,7 +220,9 @@ def test_whole_matrix_single_stream_mode(lane, oracle):
 
 
 def test_packed_helpers_ctx_quad_and_bin_collection(lane):
-    """lds_ctx_quad: four state-byte offsets per ctx word; collect_bin/collected_bytes: 16 bins, two bits apiece."""
+    """lds_ctx_quad: four state-byte offsets per ctx word; collect_bin/collected_bytes: 16 bins, two bits apiece;
+    the encode kernel's 16-bit next-state table."""
+    assert lane.lane_next16_mismatches() == 0
     rng = np.random.default_rng(5)
     out4 = (C.c_uint32 * 4)()
     for cw in [0, 0x7F7F7F7F, 0x03020100, 0x3F3E3D3C] + [int(x) & 0x7F7F7F7F for x in rng.integers(0, 2**32, 200)]:
