@@ -380,14 +380,39 @@ CABAC_HD void enc_lead16(EncCore &e, uint32_t lead, Sink &out) {
   }
 }
 
-// keeps 13 <= W' after every digit (W' >= 9 is what bounds the carry to one bit); W must stay below 63
+// keeps 13 <= W' after every digit like the reference's byte-wise writeOut (W' >= 9 is what bounds a later carry to one
+// bit; 25 measured no faster than 29); W must stay below 63
+#ifndef ISSCABAC_EMIT_THR
+#define ISSCABAC_EMIT_THR 29
+#endif
 template <class Sink>
 CABAC_HD void enc_flush16(EncCore &e, Sink &out) {
-  while (e.W >= 29) {
+  while (e.W >= ISSCABAC_EMIT_THR) {
     e.W -= 16;
     const uint32_t lead = (uint32_t)(e.low >> e.W) & 0x1FFFFu;
     e.low &= (1ull << e.W) - 1ull;
     enc_lead16(e, lead, out);
+  }
+}
+
+// The same for a whole wave at a point where some lane has to move output: the ordinary case -- a lane has at most one
+// digit ready, it is not 0xFFFF, and exactly one digit is pending behind it -- runs as one straight, predicated piece of
+// code; anything else (a 0xFFFF digit has probability 2^-16) takes the general loop above.
+template <class Sink>
+CABAC_HD void enc_flush16_wave(EncCore &e, Sink &out) {
+  const bool go = e.W >= ISSCABAC_EMIT_THR;
+  const int32_t wn = e.W - 16;
+  const uint32_t lead = (uint32_t)(e.low >> (wn & 63)) & 0x1FFFFu;  // meaningless unless go
+  const bool plain = (lead & 0xFFFFu) != 0xFFFFu && e.nbuf == 1u && wn < ISSCABAC_EMIT_THR;
+  if (CABAC_WAVE_ANY(go && !plain)) {
+    enc_flush16(e, out);
+    return;
+  }
+  if (go) {
+    out.put16((e.buffered + (lead >> 16)) & 0xFFFFu);
+    e.buffered = lead & 0xFFFFu;
+    e.W = wn;
+    e.low &= (1ull << wn) - 1ull;
   }
 }
 
@@ -398,7 +423,7 @@ CABAC_HD void enc_finish16(EncCore &e, Sink &out) {
   e.low = (e.low + e.range) << 7;
   e.range = 256;
   e.W += 7;
-  enc_flush16(e, out);  // 13 <= W <= 28
+  enc_flush16(e, out);  // W < ISSCABAC_EMIT_THR
   // pending digits [buffered][0xFFFF x (nbuf-1)] -> pending bytes [b][0xFF x (n-1)] of the byte-granular machine
   if (e.nbuf == 0) {
     e.buffered = 0xFFu;
@@ -413,7 +438,7 @@ CABAC_HD void enc_finish16(EncCore &e, Sink &out) {
       e.nbuf = 2 * e.nbuf - 1;
     }
   }
-  enc_flush(e, out);  // at most one more byte: 13 <= W <= 20, as in the reference after its testAndWriteOut
+  enc_flush(e, out);  // at most one more byte: W <= 20, as in the reference after its testAndWriteOut
   // finish(), ref: :76-104
   if ((e.low >> e.W) & 1ull) {
     out.put((e.buffered + 1u) & 0xFFu);
@@ -502,10 +527,13 @@ CABAC_HD uint32_t dec_bin_at_b1(DecCore &d, Addr at, States &st) {
   const uint32_t lps = lps_of(row, d.range);
   const uint32_t rmps = d.range - lps;
   const uint32_t scaled = rmps << d.sh;
-  const uint32_t m = d.v >= scaled ? ~0u : 0u;  // ~0: LPS
-  const uint32_t r = rmps ^ ((rmps ^ lps) & m);
+  // one subtract decides and updates: its borrow (v < scaled) is the MPS case
+  uint32_t diff;
+  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
+  const uint32_t m = mps_path ? 0u : ~0u;  // ~0: LPS
+  const uint32_t r = mps_path ? rmps : lps;
   const uint32_t n = clz32(r) - 23u;
-  d.v -= scaled & m;
+  d.v = mps_path ? d.v : diff;
   d.range = r << n;
   d.sh -= (int32_t)n;
   st.store_at(at, next_q_of(st, q, m, nx, 0));

@@ -112,8 +112,8 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
     if (e.W > mw) mw = e.W;
     if ((i + 1) % (uint32_t)flush_every == 0) {
-      if (digits16) {  // the batch kernel's cadence: every 8 bins, half way only when W >= 39
-        if ((i + 1) % 8 == 0 || e.W >= 39) enc_flush16(e, sink);
+      if (digits16) {  // the batch kernel's cadence: every 4 bins, only when `low` could overflow within 4 more
+        if (e.W >= 39) enc_flush16_wave(e, sink);
         if (e.W > 62) return -2;
       } else {
         enc_flush(e, sink);
