@@ -35,11 +35,14 @@ __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
 struct NextTab {
   uint32_t e[64];
   uint32_t e16[64];  // two 16-bit entries per dword: packed states 2i, 2i + 1
-  constexpr NextTab() : e{}, e16{} {
+  uint32_t eb[64];   // four bytes per dword: (packed state, bin) = (2i, 0), (2i, 1), (2i + 1, 0), (2i + 1, 1)
+  constexpr NextTab() : e{}, e16{}, eb{} {
     constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
     for (uint32_t s = 0; s < 64; s++) {
       e[s] = next_state_entry(s, trans[s]);
       e16[s] = next_state_entry16(2 * s, trans[s]) | next_state_entry16(2 * s + 1, trans[s]) << 16;
+      eb[s] = next_state_by_bin(2 * s, 0, trans[s]) | next_state_by_bin(2 * s, 1, trans[s]) << 8 |
+              next_state_by_bin(2 * s + 1, 0, trans[s]) << 16 | next_state_by_bin(2 * s + 1, 1, trans[s]) << 24;
     }
   }
 };
@@ -56,8 +59,9 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
 }
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kTabBytes = 768;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state entries
-constexpr int kTab16Off = 512;
+constexpr int kTabBytes = 1024;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
+                                 // entries, [768,1024) successor bytes by (packed state, bin)
+constexpr int kTab16Off = 512, kTabBinOff = 768;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -144,6 +148,15 @@ __device__ __forceinline__ uint32_t bin_at_bit1(const uint4 &v, int k) {
 template <int K>
 struct BinOfWord {
   uint32_t w2;  // input word << 1
+  uint32_t w;   // input word
+  __device__ __forceinline__ uint32_t or_q(uint32_t q) const {
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w));
+    else if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(q), "v"(w));
+    else if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(q), "v"(w));
+    else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w));
+    return r;
+  }
   __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
     uint32_t r;
     if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));
@@ -195,6 +208,14 @@ struct LdsStates {
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
   }
 #endif
+  // byte-table lookups by absolute LDS address (see next_entry): the rangeTabLps rows at LDS 0 are a [state][column]
+  // byte table, and the 16-bit next-state table is a [packed state][lps] byte table
+  __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
+  }
+  __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
+  }
   __device__ __forceinline__ uint32_t next_q(uint32_t q, uint32_t lps_mask, uint32_t entry) const {
     return NEXT16 ? next_state_q16(lps_mask, entry) : next_state_q(q, lps_mask, entry);
   }
@@ -304,6 +325,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[tid] = c_lps_rows[tid];
     tab[64 + tid] = c_next.e[tid];
     tab[128 + tid] = c_next.e16[tid];
+    tab[192 + tid] = c_next.eb[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -377,11 +399,19 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
-            const uint32_t w2 = word_of(wb, k >> 2) << 1;
-            if ((k & 3) == 0) enc_bin_at(e, BinOfWord<0>{w2}, stx.addr_of(z, 0), stx);
-            else if ((k & 3) == 1) enc_bin_at(e, BinOfWord<1>{w2}, stx.addr_of(z, 1), stx);
-            else if ((k & 3) == 2) enc_bin_at(e, BinOfWord<2>{w2}, stx.addr_of(z, 2), stx);
-            else enc_bin_at(e, BinOfWord<3>{w2}, stx.addr_of(z, 3), stx);
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+#ifndef ISSCABAC_ENC_XBAR  // (tables through ds_bpermute instead: 2 more VALU per bin, measured 1.8% slower)
+            if constexpr (CM != 0) {
+              if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+              else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+              else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+              else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+            } else
+#endif
+            if ((k & 3) == 0) enc_bin_at(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_at(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_at(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+            else enc_bin_at(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
 #ifndef ISSCABAC_ABL_NO_FLUSH
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a

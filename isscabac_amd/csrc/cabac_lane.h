@@ -107,6 +107,10 @@ constexpr uint32_t next_state_entry16(uint32_t p, uint32_t trans) {
          ((trans << 2 | ((p & 1u) ^ ((p >> 1) == 0 ? 1u : 0u)) << 1) << 8);
 }
 CABAC_HD uint32_t next_state_q16(uint32_t lps_mask, uint32_t entry16) { return entry16 >> (lps_mask & 8u); }
+// ... and as 256 bytes indexed by (p << 1) | bin = q | bin: the successor of packed state p after coding `bin`
+constexpr uint32_t next_state_by_bin(uint32_t p, uint32_t bin, uint32_t trans) {
+  return (next_state_entry16(p, trans) >> (bin == (p & 1u) ? 0 : 8)) & 0xFFu;
+}
 // States policies may provide next_q(q, lps_mask, entry) for their own entry format; the default is next_state_q
 template <class States>
 CABAC_HD auto next_q_of(const States &st, uint32_t q, uint32_t m, uint32_t nx, int) -> decltype(st.next_q(q, m, nx)) {
@@ -165,6 +169,16 @@ CABAC_HD CtxQuad lds_ctx_quad(uint32_t cw) {
 CABAC_HD uint32_t quad_field(const CtxQuad &z, int k) {
   return k == 0 ? (z.z01 & 0xFFFFu) : k == 1 ? (z.z01 >> 16) : k == 2 ? (z.z23 & 0xFFFFu) : (z.z23 >> 16);
 }
+// (m & a) | (~m & b) in one instruction (v_bfi_b32); written out for the host build
+CABAC_HD uint32_t select_mask(uint32_t m, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+#else
+  return (m & a) | (~m & b);
+#endif
+}
 // ~0 if bit 1 of x is set, else 0
 CABAC_HD uint32_t mask_from_bit1(uint32_t x) { return (uint32_t)((int32_t)(x << 30) >> 31); }
 
@@ -211,6 +225,23 @@ CABAC_HD void enc_bin_at(EncCore &e, Bin bin, Addr at, States &st) {
   e.W += (int32_t)n;
   st.store_at(at, next_q_of(st, q, m, nx, 0));
 }
+// The same step for a States policy whose tables are byte tables in memory: lps_mem(q, range) -> rangeTabLps entry,
+// next_mem(q | bin) -> successor state (Bin::or_q(q) = q | bin, the bin at bit 0).  Both lookups need one address
+// instruction and no extraction, and the state update waits neither for the decision nor for the range arithmetic.
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_at_mem(EncCore &e, Bin bin, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  st.store_at(at, st.next_mem(bin.or_q(q)));  // table indexed by (state, mps, bin): no decision needed first
+  const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
+  const uint32_t lps = st.lps_mem(q, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t n = clz32(r) - 23u;
+  e.low = (e.low + (rmps & m)) << n;
+  e.range = r << n;
+  e.W += (int32_t)n;
+}
+
 template <class States>
 CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   enc_bin_at(e, BinB1{b1}, st.addr(ctx), st);

@@ -213,6 +213,7 @@ int lane_next16_mismatches() {
         const uint32_t want = next_state_q(q, m, kNext.e[s]) & 0xFFu;
         const uint32_t got = next_state_q16(m, next_state_entry16(q >> 1, kTransLps[s])) & 0xFFu;
         bad += want != got;
+        bad += want != next_state_by_bin(q >> 1, lps ? 1u - mps : mps, kTransLps[s]);
       }
   return bad;
 }
