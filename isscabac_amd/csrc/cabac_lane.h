@@ -570,6 +570,29 @@ CABAC_HD uint32_t dec_bin_at_b1(DecCore &d, Addr at, States &st) {
   st.store_at(at, next_q_of(st, q, m, nx, 0));
   return bin_word_b1(q, m);
 }
+// The same step for a States policy with byte tables in memory (see enc_bin_at_mem): lps_mem(q, range) and
+// next_lps_mem(q | lps) -> successor state.  Returns q | lps: bit 1 = mps, bit 0 = "was an LPS"; sixteen of these
+// collected with collect_bin() turn into bin words with pairs_to_bins().
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  const uint32_t lps = st.lps_mem(q, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  uint32_t diff;
+  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
+  const uint32_t idx = q | (mps_path ? 0u : 1u);
+  st.store_at(at, st.next_lps_mem(idx));
+  const uint32_t r = mps_path ? rmps : lps;
+  const uint32_t n = clz32(r) - 23u;
+  d.v = mps_path ? d.v : diff;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return idx;
+}
+// collected (mps, lps) pairs -> the collect_bin() format: bin = mps ^ lps at the odd bits
+CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return acc ^ (acc << 1); }
+
 template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
   return (dec_bin_at_b1(d, st.addr(ctx), st) >> 1) & 1u;
