@@ -704,6 +704,9 @@ CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t nbits, uint32_t len, ByteAt by
 // Mem policy: void load16(uint32_t off, uint64_t &lo, uint64_t &hi) -> payload bytes [a, a+16) of this
 // stream, a = off rounded down to 4 (little-endian in lo, hi); returns nothing past the payload buffer.
 // ------------------------------------------------------------------------------------------------
+#ifndef ISSCABAC_PREFETCH_BITS
+#define ISSCABAC_PREFETCH_BITS 32u  // bits into the piece in use at which the next one is requested
+#endif
 template <class Mem>
 struct WindowSrc {
   Mem mem;
@@ -785,7 +788,7 @@ struct WindowSrc {
   CABAC_HD void boundary() {
     adopt();
     rebase();
-    if (bpos - pbit >= 32u) prefetch();
+    if (bpos - pbit >= ISSCABAC_PREFETCH_BITS) prefetch();
   }
   // (v << g) | the next g bits, g in 0..23 (avail_bits() >= g is the caller's business): one 64-bit shift of {v, cur.hi}
   CABAC_HD uint32_t feed_nocheck(uint32_t v, uint32_t g) {
