@@ -807,18 +807,35 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t s
   const uint32_t len = lens[s];
   const uint64_t off = offsets[s];
   if (off + len > cap) return;
-  const uint8_t *src = slots + s * slot_stride;
+  const uint8_t *src = slots + s * slot_stride;  // 16-byte aligned
   uint8_t *dst = payload + off;
-  // head bytes up to the first 4-byte aligned destination address, then aligned dwords, then the tail
+  // head bytes up to the first 4-byte aligned destination address, then 16 bytes per lane and step (destination dword
+  // aligned, source shifted by `head` bytes: five source dwords funnel into four), then single dwords, then the tail
   const uint32_t head = min(len, (uint32_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
   if (li < head) dst[li] = src[li];
-  const uint32_t nd = (len - head) >> 2;
+  const uint32_t nd = (len - head) >> 2;  // whole destination dwords
+  const uint32_t nq = nd >> 2;            // ... in groups of four
   const uint32_t *src32 = reinterpret_cast<const uint32_t *>(src);
   uint32_t *dst32 = reinterpret_cast<uint32_t *>(dst + head);
-  for (uint32_t j = li; j < nd; j += 16) {
-    // source bytes [head + 4j, head + 4j + 4): head < 4, so they straddle source dwords j and j+1
+  const uint32_t sh = 8 * head;
+  struct alignas(4) Q4 { uint32_t w[4]; };
+  for (uint32_t q = li; q < nq; q += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(src32 + 4 * q);  // the slot is 16-byte aligned and padded to 16
+    const uint32_t x = src32[4 * q + 4];
+    Q4 o;
+    if (head == 0) {
+      o.w[0] = v.x; o.w[1] = v.y; o.w[2] = v.z; o.w[3] = v.w;
+    } else {
+      o.w[0] = (v.x >> sh) | (v.y << (32 - sh));
+      o.w[1] = (v.y >> sh) | (v.z << (32 - sh));
+      o.w[2] = (v.z >> sh) | (v.w << (32 - sh));
+      o.w[3] = (v.w >> sh) | (x << (32 - sh));
+    }
+    *reinterpret_cast<Q4 *>(dst32 + 4 * q) = o;
+  }
+  for (uint32_t j = 4 * nq + li; j < nd; j += 16) {
     const uint32_t lo = src32[j], hi = src32[j + 1];
-    dst32[j] = head == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * head));
+    dst32[j] = head == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
   }
   const uint32_t done = head + nd * 4;
   if (done + li < len) dst[done + li] = src[done + li];
