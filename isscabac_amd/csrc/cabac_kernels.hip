@@ -271,7 +271,7 @@ struct SlotSink {
   }
   // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
   __device__ __forceinline__ void put16(uint32_t x) {
-    *reinterpret_cast<uint16_t *>(stage + (pos & 15u)) = (uint16_t)((x >> 8) | (x << 8));
+    *reinterpret_cast<uint16_t *>(stage + (pos & 15u)) = (uint16_t)__builtin_amdgcn_perm(x, x, 0x0C0C0001u);  // low 16 bits, byte-swapped
     pos += 2;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);

@@ -431,20 +431,18 @@ CABAC_HD void enc_flush16(EncCore &e, Sink &out) {
 // code; anything else (a 0xFFFF digit has probability 2^-16) takes the general loop above.
 template <class Sink>
 CABAC_HD void enc_flush16_wave(EncCore &e, Sink &out) {
-  const bool go = e.W >= ISSCABAC_EMIT_THR;
   const int32_t wn = e.W - 16;
-  const uint32_t lead = (uint32_t)(e.low >> (wn & 63)) & 0x1FFFFu;  // meaningless unless go
-  const bool plain = (lead & 0xFFFFu) != 0xFFFFu && e.nbuf == 1u && wn < ISSCABAC_EMIT_THR;
-  if (CABAC_WAVE_ANY(go && !plain)) {
-    enc_flush16(e, out);
-    return;
-  }
-  if (go) {
-    out.put16((e.buffered + (lead >> 16)) & 0xFFFFu);
-    e.buffered = lead & 0xFFFFu;
+  // digit, with the carry at bit 16 and nothing above it (low < 2^(W+1)); meaningless unless W >= 16
+  const uint32_t top = (uint32_t)(e.low >> (wn & 63));
+  // plain: exactly one digit ready (29 <= W < 45, so what stays behind fits 32 bits), not 0xFFFF, one digit pending
+  const bool plain = (uint32_t)(wn - (ISSCABAC_EMIT_THR - 16)) < 16u && (top & 0xFFFFu) != 0xFFFFu && e.nbuf == 1u;
+  if (plain) {
+    out.put16(e.buffered + (top >> 16));  // put16 keeps the low 16 bits
+    e.buffered = top & 0xFFFFu;
     e.W = wn;
-    e.low &= (1ull << wn) - 1ull;
+    e.low = (uint32_t)e.low & ((1u << wn) - 1u);
   }
+  if (CABAC_WAVE_ANY(e.W >= ISSCABAC_EMIT_THR)) enc_flush16(e, out);  // whatever was not plain
 }
 
 template <class Sink>
