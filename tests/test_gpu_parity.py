@@ -407,6 +407,7 @@ def test_c_abi_argument_errors_do_not_crash(engine):
 
     assert enc() > 0
     for bad in (dict(pitch=40), dict(nbins=B + 16), dict(S=0), dict(d_bins=bins.data_ptr() + 4), dict(d_bins=0),
+                dict(pitch=(1 << 25) + 16),  # ISSCABAC_MAX_PITCH: the kernels use 32-bit row offsets inside a wave
                 dict(ctx_init=np.zeros(0, np.uint8)), dict(ctx_init=np.full(3, 127, np.uint8))):
         with pytest.raises(isscabac_amd.EngineError) as ei:
             enc(**bad)
