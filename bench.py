@@ -139,7 +139,10 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ISSCABAC_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, reduction, gather) with one rank --
+    # the only way to exercise it on a 1-GPU box
+    multi = world > 1 or bool(os.environ.get("ISSCABAC_FORCE_DIST"))
+    if multi:
         dist.init_process_group("nccl", device_id=dev)
 
     from isscabac_amd import Engine, stream_bound
@@ -180,7 +183,7 @@ def main():
         return total
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +196,7 @@ def main():
         total = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -207,7 +210,7 @@ def main():
 
     # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
     gather_ms = None
-    if world > 1:
+    if multi:
         try:
             from isscabac_amd import sharding
             fence()
@@ -280,7 +283,7 @@ def main():
         elif args.cpu_seconds > 0:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
