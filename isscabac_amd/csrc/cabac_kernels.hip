@@ -10,14 +10,18 @@
 //     are issued while the current one is coded, so HBM latency hides behind >= 32 bins of arithmetic.
 //   * per-stream context states: one byte per (stream, ctx) in LDS at  (ctx/4)*256 + lane*4 + ctx%4 ,
 //     so every lane always hits its own bank; with <= 4 contexts they live in one VGPR instead.
-//   * rangeTabLps row and transIdxLps are 64-entry tables: lane i keeps entry i in a VGPR and a lookup
-//     is one ds_bpermute_b32 (LDS crossbar, no bank conflicts); divergent (ragged) sections use an LDS
-//     copy instead because bpermute cannot read inactive lanes.
+//   * rangeTabLps and the successor states are 256-byte LDS tables read by absolute LDS address
+//     ([state][column]; [packed state][bin] for the encoder, [packed state][lps] for the decoder): one
+//     address instruction per lookup, no extraction.  Chunks with bypass bins use 64-entry dword tables
+//     instead: lane i keeps entry i in a VGPR and a lookup is one ds_bpermute_b32; divergent (ragged)
+//     sections use an LDS copy of those because bpermute cannot read inactive lanes.
 //   * emitted bytes are staged 16 per lane in LDS and go to a per-stream HBM slot of provable worst-case
 //     size with 16-byte stores; a scan over the lengths and
 //     a gather kernel then produce the tight payload + offsets (the reference's one-file-per-stream
 //     content, concatenated).
-//   * the decoder fetches its payload bytes 16 at a time, one chunk ahead of use (WindowSrc).
+//   * the decoder fetches its payload bytes 16 at a time, one chunk ahead of use (WindowSrc), and tops
+//     its value register up bit-granularly once per four bins.
+//   * per-lane global addresses are a wave-uniform base (SGPRs) plus a 32-bit lane offset.
 //
 // No MFMA anywhere: this is integer / table work bounded by VALU issue and LDS, then HBM.
 #include <hip/hip_runtime.h>

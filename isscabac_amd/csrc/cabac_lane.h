@@ -3,7 +3,7 @@
 // One wavefront lane owns one bitstream, so everything in here is lane-private sequential integer
 // work: no cross-lane traffic, no MFMA.  The functions are written against two small policies so
 // that the very same code is compiled into the HIP kernels (cabac_kernels.hip: context states in LDS
-// or a VGPR, tables through ds_bpermute, bytes to an HBM slot) and into a host harness used by the
+// or a VGPR, tables in LDS or through ds_bpermute, bytes to an HBM slot) and into a host harness used by the
 // CPU test-suite (tests/lane_harness.cpp: plain arrays) -- the harness is a test build of THIS code,
 // not a fallback.
 //
@@ -19,9 +19,9 @@
 //   * encoder `low` is 64 bit wide and bytes are moved out every few bins instead of after every bin
 //     (the byte sequence is the same big number either way); renorm count = clz32(lps)-23 instead of
 //     sm_aucRenormTable (equal for every reachable LPS value, states 0..62);
-//   * decoder keeps up to 16 look-ahead bits in `v` and moves the comparison point (`sh`) instead of
-//     shifting the value and pulling one byte at a time; the MPS/LPS decision only depends on bits the
-//     reference has also read, so every decoded bin is identical.
+//   * decoder keeps look-ahead bits in `v` (topped up bit-granularly to sh = 23) and moves the comparison
+//     point (`sh`) instead of shifting the value and pulling one byte at a time; the MPS/LPS decision only
+//     depends on bits the reference has also read, so every decoded bin is identical.
 #ifndef ISSCABAC_LANE_H
 #define ISSCABAC_LANE_H
 
