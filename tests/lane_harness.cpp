@@ -41,6 +41,17 @@ struct HostStates {
   void store_at(uint32_t a, uint32_t q) { cm[a] = (uint8_t)q; }
   uint32_t lps_row(uint32_t q) const { return kLpsRow[q >> 2]; }
   uint32_t next_entry(uint32_t q) const { return kNext.e[q >> 2]; }
+  // the byte tables of the kernels' fast paths (cabac_kernels.hip: LdsStates::lps_mem / next_mem / next_lps_mem)
+  uint32_t lps_mem(uint32_t q, uint32_t range) const { return (kLpsRow[q >> 2] >> (8 * ((range >> 6) & 3u))) & 0xFFu; }
+  uint32_t next_mem(uint32_t q_or_bin) const { return next_state_by_bin(q_or_bin >> 1, q_or_bin & 1u, kTransLps[q_or_bin >> 2]); }
+  uint32_t next_lps_mem(uint32_t q_or_lps) const {
+    return (next_state_entry16(q_or_lps >> 1, kTransLps[q_or_lps >> 2]) >> (8 * (q_or_lps & 1u))) & 0xFFu;
+  }
+};
+struct HostBin {  // Bin policy of enc_bin_at_mem
+  uint32_t bin;
+  uint32_t xor_q(uint32_t q) const { return (bin << 1) ^ q; }
+  uint32_t or_q(uint32_t q) const { return q | bin; }
 };
 
 struct HostSink {
@@ -87,6 +98,8 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   if (any) flush_every = -flush_every;
   const bool quads = flush_every == 40;
   if (quads) flush_every = 4;
+  const bool memtab = flush_every == 17;  // ... with the kernel's byte-table bin step (enc_bin_at_mem)
+  if (memtab) flush_every = 16;
   const bool digits16 = flush_every == 16;  // the batch kernel's output path: 16-bit digits, checked every 4 bins
   if (digits16) flush_every = 4;
   HostStates st;
@@ -109,6 +122,7 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     }
     if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);
     else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
+    else if (memtab) enc_bin_at_mem(e, HostBin{bins[i]}, st.addr(ctx[i]), st);
     else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
     if (e.W > mw) mw = e.W;
     if ((i + 1) % (uint32_t)flush_every == 0) {
@@ -142,8 +156,12 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   const bool quads = group == 40;
   if (quads) group = 4;
   // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
+  bool memtab = group == 3;  // ... with the byte-table bin step and (mps, lps) pair collection of the kernel
+  if (memtab) group = 2;
+  for (uint32_t i = 0; i < n; i++) memtab = memtab && ctx[i] != kBypass;  // like the kernel: chunks without bypass bins
   const bool noguard = group == 2;
   if (noguard) group = 4;
+  uint32_t pairs = 0;
   bool has_bypass = any;  // the kernel guards with 8 instead of 7 when a chunk holds bypass bins
   for (uint32_t i = 0; i < n; i++) has_bypass |= ctx[i] == kBypass;
   const int32_t min_sh = has_bypass ? 8 : 7;
@@ -186,6 +204,20 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
     } else if (d.sh < 8) {
       dec_refill(d, src);
       slow_refills++;
+    }
+    if (memtab && ctx[i] != kBypass) {
+      pairs = collect_bin(pairs, dec_bin_at_mem(d, st.addr(ctx[i]), st));
+      if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
+        const uint32_t done = i % 16 + 1;
+        const uint32_t bw = pairs_to_bins(pairs) >> (2 * (16 - done));  // a short last chunk sits at the top
+        for (uint32_t w = 0; w < 4; w++) {
+          const uint32_t b4 = collected_bytes(bw, (int)w);
+          for (uint32_t k = 0; k < 4; k++)
+            if (4 * w + k < done) bins_out[i + 1 - done + 4 * w + k] = (uint8_t)(b4 >> (8 * k));
+        }
+        pairs = 0;
+      }
+      continue;
     }
     if (any) bins_out[i] = (uint8_t)dec_bin_any(d, ctx[i], st);
     else bins_out[i] = (uint8_t)(ctx[i] == kBypass ? dec_bin_ep(d) : dec_bin(d, ctx[i], st));

@@ -67,16 +67,16 @@ def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
-@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40, 16])
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40, 16, 17])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
         out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
         assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
-        assert mw <= (62 if flush_every == 16 else 20 + 6 * min(abs(flush_every), 4) + 1)
+        assert mw <= (62 if flush_every in (16, 17) else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
-@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2), (1, 7, -2)])
+@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2), (1, 7, -2), (2, 6, 3)])
 def test_decode_golden(lane, golden, pads):
     for s in golden["streams"]:
         bins, st, fin, _ = lane_decode(lane, s["payload_a"], s["ctx_a"], s["ctx_init_a"], pad_front=pads[0],
@@ -99,11 +99,11 @@ def test_fuzz_vs_oracle(lane, oracle):
         skew = rng.random(Cn + 1) ** (1 + it % 4)
         bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        got, fin, _ = lane_encode(lane, bins, ctx, init, (40, 4, 16)[it % 3])
+        got, fin, _ = lane_encode(lane, bins, ctx, init, (40, 4, 16, 17)[it % 4])
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
-                                         pad_back=int(rng.integers(0, 20)), group=(40, 4, 16, 2)[it % 4])
+                                         pad_back=int(rng.integers(0, 20)), group=(40, 4, 16, 2, 3)[it % 5])
         assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes()
         slow += cnt[2]
     assert slow > 0  # the in-chunk refill path was exercised
@@ -122,7 +122,7 @@ def test_all_lps_worst_case_width(lane, oracle, golden):
     got, _fin, mw = lane_encode(lane, bins, ctx, init, 16)
     assert got.tobytes() == want.tobytes() and 50 <= mw <= 62
     # ... and the decoder's fast path at its worst: 6 bits per bin, the guard before every fourth bin fires
-    for group in (2, -2, 4):
+    for group in (2, 3, -2, 4):
         dec, st, _, _ = lane_decode(lane, want, ctx, init, pad_front=3, pad_back=1, group=group)
         assert st == 0 and (dec == bins).all()
 
@@ -149,7 +149,7 @@ def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
             bad = np.concatenate([bad, rng.integers(0, 256, 3).astype(np.uint8)])
         want, st_want = oracle.decode_stream(bad, ctx, init)
         got, st, _, _ = lane_decode(lane, bad, ctx, init, pad_front=2, pad_back=int(rng.integers(0, 30)),
-                                    group=int(rng.choice([2, 4, -2])))
+                                    group=int(rng.choice([2, 3, 4, -2])))
         assert (got == want).all()
         assert st == st_want
         flagged += st != 0
