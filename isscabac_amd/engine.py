@@ -65,6 +65,10 @@ def _load():
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -m isscabac_amd.build` (needs hipcc); there is no CPU "
                            "fallback for the coding path" % path)
+    try:  # when PyTorch-ROCm is around, load its bundled HIP runtime first: two copies of libamdhip64 in one process
+        import torch  # noqa: F401   (ours via the rpath, torch's later) leave the later one without a device
+    except Exception:
+        pass
     L = C.CDLL(path)
     L.isscabac_abi_version.restype = C.c_int
     L.isscabac_create.argtypes = [C.c_int, C.POINTER(_vp)]

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def lib():
+    import torch  # noqa: F401  (torch's bundled HIP runtime first: a later GPU test in the same process must share it)
     from isscabac_amd import build
     return ctypes.CDLL(build.build_lib())
 
