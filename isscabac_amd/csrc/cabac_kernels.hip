@@ -430,10 +430,26 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #endif
           }
         } else if (full) {
-          // bypass bins (or contexts >= 128) somewhere in the wave: combined step, still convergent
+          // bypass bins (or contexts >= 128) somewhere in the wave.  The byte-table bin step works under any exec mask,
+          // so context-coded and bypass lanes simply take their own branch (both sides run when a wave mixes them:
+          // ~29 VALU per bin against ~37 for one combined, select-based step).  <= 4 contexts (states in a VGPR,
+          // tables through ds_bpermute, which needs all lanes): combined step.
 #pragma unroll
           for (int k = 0; k < 16; k++) {
-            enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+            if constexpr (CM != 0) {
+              const CtxQuad z = stx.prep4(word_of(wc, k >> 2));
+              const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+              if (byte_of(wc, k) != kBypass) {
+                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+              } else {
+                enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
+              }
+            } else {
+              enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+            }
             if ((k & 3) == 3 && wave_any(e.W >= 39)) ISSCABAC_FLUSH_FN(e, sink);
           }
         } else {
@@ -676,6 +692,19 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   ob = collect_bin(ob, dec_bin_at_b1(d, stx.addr_of(z, k), stx));
                 }
               } else {
+#ifndef ISSCABAC_DEC_XBAR
+                if constexpr (CM != 0) {  // context-coded and bypass lanes take their own branch (see k_encode)
+                  const CtxQuad z = stx.prep4(cw);
+#pragma unroll
+                  for (int k = 0; k < 4; k++) {
+                    if (k == 3) dec_guard(d, src, 8);
+                    uint32_t w;
+                    if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
+                    else w = dec_bin_ep(d) << 1;  // as a (mps, lps) pair: (bin, 0)
+                    ob = collect_bin(ob, w);
+                  }
+                } else
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 8);
@@ -684,7 +713,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               }
             }
 #ifndef ISSCABAC_DEC_XBAR
-            if (CM != 0 && !hi) ob = pairs_to_bins(ob);
+            if (CM != 0) ob = pairs_to_bins(ob);
 #endif
           } else {
             // ragged end: lanes drop out one by one, per-bin guard, tables from LDS memory (bpermute cannot read

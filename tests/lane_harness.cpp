@@ -158,7 +158,6 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
   bool memtab = group == 3;  // ... with the byte-table bin step and (mps, lps) pair collection of the kernel
   if (memtab) group = 2;
-  for (uint32_t i = 0; i < n; i++) memtab = memtab && ctx[i] != kBypass;  // like the kernel: chunks without bypass bins
   const bool noguard = group == 2;
   if (noguard) group = 4;
   uint32_t pairs = 0;
@@ -205,8 +204,8 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       dec_refill(d, src);
       slow_refills++;
     }
-    if (memtab && ctx[i] != kBypass) {
-      pairs = collect_bin(pairs, dec_bin_at_mem(d, st.addr(ctx[i]), st));
+    if (memtab) {  // bypass bins join the pair format as (bin, 0), like the kernel's mixed chunks
+      pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : dec_bin_ep(d) << 1);
       if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
         const uint32_t done = i % 16 + 1;
         const uint32_t bw = pairs_to_bins(pairs) >> (2 * (16 - done));  // a short last chunk sits at the top
