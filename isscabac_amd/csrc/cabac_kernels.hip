@@ -219,6 +219,9 @@ struct LdsStates {
   }
   // the 16-bit next-state table read as bytes: [packed state][lps]
   __device__ __forceinline__ uint32_t next_lps_mem(uint32_t q_or_lps) const {
+#ifdef ISSCABAC_ABL_NO_NEXTMEM
+    return q_or_lps & 0xFEu;  // timing only: no successor lookup, the state never moves
+#endif
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTab16Off + q_or_lps));
   }
   __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
@@ -481,6 +484,7 @@ struct DevMem {
   const uint8_t *payload;  // whole payload buffer (wave-uniform)
   uint64_t total;          // its size in bytes (wave-uniform)
   uint64_t abase;          // 4-byte aligned offset at or below the stream's first byte
+  int32_t lim;             // largest off for which [abase + off, +16) lies inside the buffer (-1: none), capped at 2^31-1
   struct alignas(4) Q4 { uint32_t w[4]; };
   struct Pair { uint64_t lo, hi; };
   // the last few bytes of the whole payload buffer: never read past its end
@@ -499,7 +503,7 @@ struct DevMem {
     off &= 60u;  // timing only: every fetch hits the same hot line
 #endif
     const uint64_t at = abase + off;
-    if (at + 16 <= total) {
+    if ((int32_t)off <= lim) {  // off is far below 2^31 (a stream's payload is bounded by 6/8 of its <= 2^25 bins)
       const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
       hi = (uint64_t)q.w[2] | ((uint64_t)q.w[3] << 32);
@@ -587,6 +591,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   src.mem.payload = a.payload;
   src.mem.total = a.payload_bytes;
   src.mem.abase = abase;
+  src.mem.lim = a.payload_bytes >= abase + 16 ? (int32_t)min(a.payload_bytes - 16 - abase, (uint64_t)0x7FFFFFFF) : -1;
   src.len = skew + len;
   src.start(skew);
   src.boundary();
@@ -669,7 +674,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
             for (int g = 0; g < 4; g++) {  // rolled over the four words: keeps the live register set small
 #ifndef ISSCABAC_ABL_NO_PAYLOAD
-              if (g != 0) src.ensure(24);  // g == 0: boundary() has just re-based
+              if (g >= 2) src.ensure(24);  // boundary() has just re-based: 64 bits cover the top-ups of g = 0 and 1
 #else
               src.cend = src.bpos + 64u;
 #endif

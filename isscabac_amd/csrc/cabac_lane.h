@@ -147,9 +147,10 @@ CABAC_HD uint32_t alignbit_b32(uint32_t hi, uint32_t lo, uint32_t s) {
 // accumulator and everything older two places down.  After 16 bins, bin j of the 16 sits at bit 2j + 1.
 CABAC_HD uint32_t collect_bin(uint32_t acc, uint32_t bin_word) { return alignbit_b32(bin_word, acc, 2); }
 // bins 4w .. 4w+3 of a collected 16-bin word as four bytes of 0/1 (bin 4w in byte 0): the bins sit at bits 1,3,5,7 of
-// byte w; (1 + 2^6 + 2^12 + 2^18) moves bit 2i to bit 8i and no carry of the product reaches those positions
+// byte w and the even bits are 0 (bit 0 of every collected word is 0); (1 + 2^6 + 2^12 + 2^18) moves bit 2i to bit 8i
+// and no carry of the product reaches those positions
 CABAC_HD uint32_t collected_bytes(uint32_t acc, int w) {
-  return (((acc >> (8 * w + 1)) & 0x55u) * 0x00041041u) & 0x01010101u;
+  return (((acc >> (8 * w + 1)) & 0x7Fu) * 0x00041041u) & 0x01010101u;  // shift + mask = one v_bfe_u32
 }
 
 // Offsets of four contexts' state bytes in the kernels' LDS state image, from the four ctx bytes of one input word:
@@ -589,7 +590,7 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   return idx;
 }
 // collected (mps, lps) pairs -> the collect_bin() format: bin = mps ^ lps at the odd bits
-CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return acc ^ (acc << 1); }
+CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return (acc ^ (acc << 1)) & 0xAAAAAAAAu; }
 
 template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
