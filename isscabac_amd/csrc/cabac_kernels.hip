@@ -40,11 +40,13 @@ struct NextTab {
   uint32_t e[64];
   uint32_t e16[64];  // two 16-bit entries per dword: packed states 2i, 2i + 1
   uint32_t eb[64];   // four bytes per dword: (packed state, bin) = (2i, 0), (2i, 1), (2i + 1, 0), (2i + 1, 1)
-  constexpr NextTab() : e{}, e16{}, eb{} {
+  uint32_t ep[64];   // four bytes per dword: (packed state, path) with path 0 = LPS, 1 = MPS: e16 with its bytes swapped
+  constexpr NextTab() : e{}, e16{}, eb{}, ep{} {
     constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
     for (uint32_t s = 0; s < 64; s++) {
       e[s] = next_state_entry(s, trans[s]);
       e16[s] = next_state_entry16(2 * s, trans[s]) | next_state_entry16(2 * s + 1, trans[s]) << 16;
+      ep[s] = ((e16[s] & 0x00FF00FFu) << 8) | ((e16[s] >> 8) & 0x00FF00FFu);
       eb[s] = next_state_by_bin(2 * s, 0, trans[s]) | next_state_by_bin(2 * s, 1, trans[s]) << 8 |
               next_state_by_bin(2 * s + 1, 0, trans[s]) << 16 | next_state_by_bin(2 * s + 1, 1, trans[s]) << 24;
     }
@@ -63,9 +65,9 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
 }
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kTabBytes = 1024;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
-                                 // entries, [768,1024) successor bytes by (packed state, bin)
-constexpr int kTab16Off = 512, kTabBinOff = 768;
+constexpr int kTabBytes = 1280;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
+                                 // entries, [768,1024) successor bytes by (packed state, bin), [1024,1280) by (.., path)
+constexpr int kTab16Off = 512, kTabBinOff = 768, kTabPathOff = 1024;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -217,12 +219,13 @@ struct LdsStates {
   __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
   }
-  // the 16-bit next-state table read as bytes: [packed state][lps]
-  __device__ __forceinline__ uint32_t next_lps_mem(uint32_t q_or_lps) const {
+  // successor bytes by [packed state][path], path 0 = LPS, 1 = MPS
+  __device__ __forceinline__ uint32_t path_index(uint32_t q) const { return kTabPathOff + q; }  // = the LDS address
+  __device__ __forceinline__ uint32_t next_path_mem(uint32_t addr) const {
 #ifdef ISSCABAC_ABL_NO_NEXTMEM
-    return q_or_lps & 0xFEu;  // timing only: no successor lookup, the state never moves
+    return addr & 0xFEu;  // timing only: no successor lookup, the state never moves
 #endif
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTab16Off + q_or_lps));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)addr);
   }
   __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
@@ -550,6 +553,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     tab[tid] = c_lps_rows[tid];
     tab[64 + tid] = c_next.e[tid];
     tab[128 + tid] = c_next.e16[tid];
+    tab[256 + tid] = c_next.ep[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
@@ -705,7 +709,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                     if (k == 3) dec_guard(d, src, 8);
                     uint32_t w;
                     if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                    else w = dec_bin_ep(d) << 1;  // as a (mps, lps) pair: (bin, 0)
+                    else w = pair_of_bin(dec_bin_ep(d));
                     ob = collect_bin(ob, w);
                   }
                 } else

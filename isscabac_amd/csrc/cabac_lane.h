@@ -570,8 +570,9 @@ CABAC_HD uint32_t dec_bin_at_b1(DecCore &d, Addr at, States &st) {
   return bin_word_b1(q, m);
 }
 // The same step for a States policy with byte tables in memory (see enc_bin_at_mem): lps_mem(q, range) and
-// next_lps_mem(q | lps) -> successor state.  Returns q | lps: bit 1 = mps, bit 0 = "was an LPS"; sixteen of these
-// collected with collect_bin() turn into bin words with pairs_to_bins().
+// next_path_mem(path_index(q) + path) -> successor state, path = 1 for the MPS path (the borrow of the deciding subtraction, added
+// in with one add-with-carry).  Returns q + path: bit 1 = mps, bit 0 = "was an MPS"; sixteen of these collected with
+// collect_bin() turn into bin words with pairs_to_bins().
 template <class States, class Addr>
 CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
@@ -580,8 +581,9 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   const uint32_t scaled = rmps << d.sh;
   uint32_t diff;
   const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
-  const uint32_t idx = q | (mps_path ? 0u : 1u);
-  st.store_at(at, st.next_lps_mem(idx));
+  // the policy may bias the index by a multiple of 4 (a table address): its low two bits stay (mps, path)
+  const uint32_t idx = st.path_index(q) + (uint32_t)mps_path;
+  st.store_at(at, st.next_path_mem(idx));
   const uint32_t r = mps_path ? rmps : lps;
   const uint32_t n = clz32(r) - 23u;
   d.v = mps_path ? d.v : diff;
@@ -589,8 +591,10 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   d.sh -= (int32_t)n;
   return idx;
 }
-// collected (mps, lps) pairs -> the collect_bin() format: bin = mps ^ lps at the odd bits
-CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return (acc ^ (acc << 1)) & 0xAAAAAAAAu; }
+// collected (mps, path) pairs -> the collect_bin() format: bin = mps ^ !path at the odd bits, even bits 0
+CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return ~(acc ^ (acc << 1)) & 0xAAAAAAAAu; }
+// a bypass bin in pair form
+CABAC_HD uint32_t pair_of_bin(uint32_t bin) { return (bin << 1) | 1u; }
 
 template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {

@@ -44,8 +44,9 @@ struct HostStates {
   // the byte tables of the kernels' fast paths (cabac_kernels.hip: LdsStates::lps_mem / next_mem / next_lps_mem)
   uint32_t lps_mem(uint32_t q, uint32_t range) const { return (kLpsRow[q >> 2] >> (8 * ((range >> 6) & 3u))) & 0xFFu; }
   uint32_t next_mem(uint32_t q_or_bin) const { return next_state_by_bin(q_or_bin >> 1, q_or_bin & 1u, kTransLps[q_or_bin >> 2]); }
-  uint32_t next_lps_mem(uint32_t q_or_lps) const {
-    return (next_state_entry16(q_or_lps >> 1, kTransLps[q_or_lps >> 2]) >> (8 * (q_or_lps & 1u))) & 0xFFu;
+  uint32_t path_index(uint32_t q) const { return q; }
+  uint32_t next_path_mem(uint32_t q_plus_path) const {  // path 1 = MPS
+    return (next_state_entry16(q_plus_path >> 1, kTransLps[q_plus_path >> 2]) >> (8 * (1u - (q_plus_path & 1u)))) & 0xFFu;
   }
 };
 struct HostBin {  // Bin policy of enc_bin_at_mem
@@ -205,7 +206,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       slow_refills++;
     }
     if (memtab) {  // bypass bins join the pair format as (bin, 0), like the kernel's mixed chunks
-      pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : dec_bin_ep(d) << 1);
+      pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
       if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
         const uint32_t done = i % 16 + 1;
         const uint32_t bw = pairs_to_bins(pairs) >> (2 * (16 - done));  // a short last chunk sits at the top
