@@ -74,6 +74,7 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->slots) (void)hipFree(e->slots);
   if (e->lens) (void)hipFree(e->lens);
   if (e->scan_tmp) (void)hipFree(e->scan_tmp);
+  if (e->flag) (void)hipFree(e->flag);
   for (void *p : e->stage)
     if (p) (void)hipFree(p);
   if (e->ev_ready)
@@ -215,12 +216,22 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
   if (misaligned(d_ctx) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
   HIP_TRY(e, hipSetDevice(e->device));
+  if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
   if ((rc = prof_begin(e))) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
   PROF_MARK(e, 0);
-  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->stream));
+  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag, e->stream));
   PROF_MARK(e, 1);
+  uint32_t need_exact = 0;
+  HIP_TRY(e, hipMemcpyAsync(&need_exact, e->flag, sizeof need_exact, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   if (e->profiling) HIP_TRY(e, hipEventElapsedTime(&e->last_ms[3], e->ev[0], e->ev[1]));
+  if (need_exact) {
+    // some stream starts with 0xFF (corrupt input): the reference's value register overflows on those, and only its own
+    // formulation reproduces what it then decodes (cabac_lane.h: RefDec).  One thread per such stream, rare and slow.
+    HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  }
   return ISSCABAC_OK;
 }
 

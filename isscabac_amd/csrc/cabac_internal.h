@@ -23,6 +23,7 @@ struct isscabac_engine {
   uint64_t lens_bytes = 0;
   void *scan_tmp = nullptr;
   uint64_t scan_tmp_bytes = 0;
+  uint32_t *flag = nullptr;  // one word: "some stream needs the reference-formulation decoder" (see launch_decode_exact)
   // staging for the host-buffer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -69,9 +70,15 @@ hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, 
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,
                          uint64_t S, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 // decode: payload/offsets/ctx -> bins (+status)
+// *d_flag (zeroed by the caller) is set when a stream starts with 0xFF: such streams (corrupt input only) must be
+// decoded again with launch_decode_exact to reproduce the reference's 32-bit register wrap-around
 hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
                          const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out, uint32_t *d_status,
-                         hipStream_t stream);
+                         uint32_t *d_flag, hipStream_t stream);
+// one thread per stream, reference formulation (cabac_lane.h: RefDec); touches only streams that start with 0xFF
+hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
+                               const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
+                               uint32_t *d_status, hipStream_t stream);
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);

@@ -524,6 +524,7 @@ struct DecArgs {
   const uint32_t *nbins_per_stream;
   uint8_t *bins_out;
   uint32_t *status;
+  uint32_t *exact_flag;  // set when a stream of this launch needs k_decode_exact
   uint64_t S, payload_bytes;
   uint32_t nbins, pitch, nctx;
   uint32_t ctx_init[64];
@@ -601,6 +602,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   src.boundary();
   DecCore d;
   dec_start(d, src);
+  // v now holds the stream's first four bytes.  A first byte of 0xFF (corrupt input only) makes the reference's value
+  // register overflow: those streams are decoded again, in the reference's formulation, by k_decode_exact
+  if (valid && needs_ref_decoder(d.v >> 24) && a.exact_flag) *a.exact_flag = 1u;
 
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
@@ -760,6 +764,42 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     const uint8_t *p = a.payload + first;
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streams that start with 0xFF (see cabac_lane.h: RefDec): one thread per stream, the reference's own formulation,
+// context states in a private array, tables from memory.  Slow, and only ever runs on corrupt input.
+// ------------------------------------------------------------------------------------------------
+struct PrivateStates {
+  uint8_t *cm;
+  __device__ uint32_t load(uint32_t c) const { return cm[c]; }
+  __device__ void store(uint32_t c, uint32_t q) const { cm[c] = (uint8_t)q; }
+  __device__ uint32_t lps_row(uint32_t q) const { return c_lps_rows[q >> 2]; }
+  __device__ uint32_t next_entry(uint32_t q) const { return c_next.e[q >> 2]; }
+};
+
+__global__ void __launch_bounds__(64) k_decode_exact(DecArgs a) {
+  const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.S) return;
+  const uint64_t start = a.offsets[s];
+  const uint32_t len = (uint32_t)(a.offsets[s + 1] - start);
+  if (len != 0 && !needs_ref_decoder(a.payload[start])) return;  // (an empty stream reads 0xFF at EOF)
+  uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
+  n = min(n, a.nbins);
+  uint8_t cm[256];
+  for (uint32_t c = 0; c < 256; c++) cm[c] = (uint8_t)(((a.ctx_init[(c >> 2) & 63] >> (8 * (c & 3))) & 0x7Fu) << 1);
+  PrivateStates st{cm};
+  RefReader rd{a.payload + start, len, 0, 0};
+  RefDec r;
+  ref_dec_start(r, rd);
+  const uint8_t *ctx = a.ctx + s * a.pitch;
+  uint8_t *out = a.bins_out + s * a.pitch;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = ctx[i];
+    out[i] = (uint8_t)(c == kBypass ? ref_dec_bin_ep(r, rd) : ref_dec_bin(r, c, st, rd));
+  }
+  const uint32_t status = ref_dec_finish(r, rd, len);
+  if (a.status) a.status[s] = status;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,22 +1037,38 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
   ISSCABAC_DISPATCH(run_encode, a);
 }
 
-hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
-                         const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out, uint32_t *d_status,
-                         hipStream_t stream) {
-  DecArgs a;
+static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
+                          const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
+                          uint32_t *d_status, uint32_t *d_flag) {
   a.payload = d_payload;
   a.ctx = d_ctx;
   a.offsets = d_offsets;
   a.nbins_per_stream = d_nbins;
   a.bins_out = d_bins_out;
   a.status = d_status;
+  a.exact_flag = d_flag;
   a.S = sh.S;
   a.payload_bytes = payload_bytes;
   a.nbins = sh.nbins;
   a.pitch = sh.pitch;
   a.nctx = sh.nctx;
   std::memcpy(a.ctx_init, sh.ctx_init, 256);
+}
+
+hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
+                               const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
+                               uint32_t *d_status, hipStream_t stream) {
+  DecArgs a;
+  fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, nullptr);
+  hipLaunchKernelGGL(k_decode_exact, dim3((unsigned)((sh.S + 63) / 64)), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                         const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out, uint32_t *d_status,
+                         uint32_t *d_flag, hipStream_t stream) {
+  DecArgs a;
+  fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, d_flag);
   ISSCABAC_DISPATCH(run_decode, a);
 }
 

@@ -701,6 +701,106 @@ CABAC_HD uint32_t dec_finish(DecCore &d, uint32_t nbits, uint32_t len, ByteAt by
 }
 
 // ------------------------------------------------------------------------------------------------
+// The decoder in the reference's own formulation (32-bit m_uiValue, m_bitsNeeded, one byte at a time).
+// DecCore above is bit-identical to it as long as value < range << 7, which the arithmetic itself maintains from
+// start() on -- unless the stream's first byte is 0xFF (no encoder emits that): then value >= range << 7 from the
+// first bin, every bin decodes as an LPS, the excess doubles with every renormalisation shift and the reference's
+// 32-bit register wraps; DecCore, which keeps up to 16 look-ahead bits in the same 32 bits, would wrap earlier.  Streams
+// that start with 0xFF (only corrupt input) are therefore decoded with this restatement, so that even their garbage and
+// their status flags are the reference's.   ref: CABAC/CABAC_ArithmeticDecoder.cpp:54-71, 87-190, 288-331, 423-472, 73-85
+// Rd policy: uint32_t operator()() -> next payload byte, 0xFF past the end.
+// ------------------------------------------------------------------------------------------------
+struct RefDec {
+  uint32_t value, range;
+  int32_t need;  // m_bitsNeeded
+};
+CABAC_HD bool needs_ref_decoder(uint32_t first_byte) { return first_byte == 0xFFu; }
+
+template <class Rd>
+CABAC_HD void ref_dec_start(RefDec &r, Rd &rd) {  // ref: :54-71
+  r.range = 510;
+  r.need = -8;
+  r.value = rd() << 8;
+  r.value |= rd();
+}
+template <class States, class Rd>
+CABAC_HD uint32_t ref_dec_bin(RefDec &r, uint32_t ctx, States &st, Rd &rd) {  // ref: :87-190
+  const uint32_t q = st.load(ctx);
+  const uint32_t lps = (st.lps_row(q) >> (8u * ((r.range >> 6) & 3u))) & 0xFFu;
+  const uint32_t nx = st.next_entry(q);
+  r.range -= lps;
+  const uint32_t scaled = r.range << 7;
+  if (r.value < scaled) {  // MPS path
+    st.store(ctx, next_q_of(st, q, 0u, nx, 0));
+    if (scaled < (256u << 7)) {
+      r.range = scaled >> 6;
+      r.value += r.value;
+      if (++r.need == 0) {
+        r.need = -8;
+        r.value += rd();
+      }
+    }
+    return (q >> 1) & 1u;
+  }
+  const uint32_t n = clz32(lps) - 23u;  // == sm_aucRenormTable[lps >> 3]
+  r.value = (r.value - scaled) << n;
+  r.range = lps << n;
+  st.store(ctx, next_q_of(st, q, ~0u, nx, 0));
+  r.need += (int32_t)n;
+  if (r.need >= 0) {
+    r.value += rd() << r.need;
+    r.need -= 8;
+  }
+  return ((q >> 1) & 1u) ^ 1u;
+}
+template <class Rd>
+CABAC_HD uint32_t ref_dec_bin_ep(RefDec &r, Rd &rd) {  // ref: :288-331
+  r.value += r.value;
+  if (++r.need >= 0) {
+    r.need = -8;
+    r.value += rd();
+  }
+  const uint32_t scaled = r.range << 7;
+  if (r.value >= scaled) {
+    r.value -= scaled;
+    return 1u;
+  }
+  return 0u;
+}
+// decodeBinTrm + the two asserts of finish() as flags.  nread = payload bytes handed out by rd so far (it keeps counting
+// past the end), last = the byte the most recent rd() returned, len = payload length of the stream
+template <class Rd>
+CABAC_HD uint32_t ref_dec_finish(RefDec &r, Rd &rd, uint32_t len) {  // ref: :423-472, :73-85
+  uint32_t status = 0;
+  r.range -= 2;
+  const uint32_t scaled = r.range << 7;
+  if (!(r.value >= scaled)) {
+    status |= 1u;
+    if (scaled < (256u << 7)) {
+      r.range = scaled >> 6;
+      r.value += r.value;
+      if (++r.need == 0) {
+        r.need = -8;
+        r.value += rd();
+      }
+    }
+  }
+  if (((rd.last << (8 + r.need)) & 0xFFu) != 0x80u) status |= 2u;
+  if (rd.nread - 1u >= len || len < 2u) status |= 4u;
+  return status;
+}
+// byte reader over a stream's payload for the functions above
+struct RefReader {
+  const uint8_t *p;
+  uint32_t len, nread, last;
+  CABAC_HD uint32_t operator()() {
+    last = nread < len ? p[nread] : 0xFFu;
+    nread++;
+    return last;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Bit source for the decoder: a 64-bit MSB-first window `cur` over the stream's payload that is re-based at
 // wave-uniform points (boundary() / ensure()) from a 16-byte piece fetched one boundary earlier, so the HBM/L2 latency
 // of the fetch is never on the bin loop's critical path.  Positions are in bits from the Mem policy's base.

@@ -28,8 +28,9 @@ __device__ const StreamNextTab s_next{};
 struct StreamDev {
   EncCore enc;
   uint32_t enc_bytes;  // bytes written to the sink so far
-  DecCore dec;
-  uint32_t dec_pos, dec_len;
+  RefDec dec;  // the per-bin handle decodes in the reference's own formulation (cabac_lane.h: RefDec): one bin per call,
+               // nothing to gain from look-ahead, and exact even on streams no encoder produces
+  uint32_t dec_pos, dec_len, dec_last;  // bytes handed out so far, payload length, the last byte handed out
   uint8_t q_enc[256], q_dec[256];  // doubled context states, encoder and decoder sets (ref: :175-176)
 };
 
@@ -48,12 +49,6 @@ struct GlobalSink {
   uint32_t pos;
   __device__ void put(uint32_t b) { buf[pos++] = (uint8_t)b; }
 };
-struct GlobalSrc {
-  const uint8_t *buf;
-  uint32_t pos, len;
-  __device__ uint32_t next() { return pos < len ? buf[pos++] : (pos++, 0xFFu); }
-};
-
 __global__ void k_stream_reset(StreamDev *st, const uint8_t *init /* 256 packed states */) {
   const int t = threadIdx.x;
   st->q_enc[t] = (uint8_t)q_from_packed(init[t]);
@@ -90,31 +85,32 @@ __global__ void k_stream_enc_finish(StreamDev *st, uint8_t *out) {
 
 __global__ void k_stream_dec_start(StreamDev *st, const uint8_t *payload, uint32_t len) {
   if (threadIdx.x != 0) return;
-  GlobalSrc src{payload, 0, len};
-  DecCore d;
-  dec_start(d, src);
+  RefReader rd{payload, len, 0, 0};
+  RefDec d;
+  ref_dec_start(d, rd);
   st->dec = d;
-  st->dec_pos = src.pos;
+  st->dec_pos = rd.nread;
+  st->dec_last = rd.last;
   st->dec_len = len;
 }
 
 __global__ void k_stream_dec_bins(StreamDev *st, const uint8_t *payload, const uint8_t *ctx, uint32_t n, uint8_t *bins_out) {
   if (threadIdx.x != 0) return;
-  DecCore d = st->dec;
+  RefDec d = st->dec;
   GlobalStates cs{st->q_dec};
-  GlobalSrc src{payload, st->dec_pos, st->dec_len};
-  for (uint32_t i = 0; i < n; i++) {
-    if (d.sh < 8) dec_refill(d, src);
-    bins_out[i] = (uint8_t)(ctx[i] == kBypass ? dec_bin_ep(d) : dec_bin(d, ctx[i], cs));
-  }
+  RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
+  for (uint32_t i = 0; i < n; i++)
+    bins_out[i] = (uint8_t)(ctx[i] == kBypass ? ref_dec_bin_ep(d, rd) : ref_dec_bin(d, ctx[i], cs, rd));
   st->dec = d;
-  st->dec_pos = src.pos;
+  st->dec_pos = rd.nread;
+  st->dec_last = rd.last;
 }
 
 __global__ void k_stream_dec_finish(StreamDev *st, const uint8_t *payload, uint32_t *status) {
   if (threadIdx.x != 0) return;
-  DecCore d = st->dec;
-  *status = dec_finish(d, 8u * st->dec_pos, st->dec_len, [payload](uint32_t i) { return (uint32_t)payload[i]; });
+  RefDec d = st->dec;
+  RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
+  *status = ref_dec_finish(d, rd, st->dec_len);
   st->dec = d;
 }
 

@@ -172,15 +172,25 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   src.boundary();
   DecCore d;
   dec_start(d, src);
+  // a stream that starts with 0xFF (corrupt input only) is decoded in the reference's own formulation, see RefDec
+  const bool exact = needs_ref_decoder(d.v >> 24);
+  RefReader rd{a.payload + start, len, 0, 0};
+  RefDec r;
+  if (exact) ref_dec_start(r, rd);
   uint8_t *row = a.sym_out + s * a.pitch;
   SymWalk w;
   w.start();
   uint32_t it = 0;
   while (w.idx < n_my) {
-    if ((it++ & 15u) == 0) src.boundary();
-    if (d.sh < 8) dec_refill(d, src);
     const uint32_t c = w.ctx(a.P);
-    const uint32_t bin = dec_bin(d, c, st);
+    uint32_t bin;
+    if (!exact) {
+      if ((it++ & 15u) == 0) src.boundary();
+      if (d.sh < 8) dec_refill(d, src);
+      bin = dec_bin(d, c, st);
+    } else {
+      bin = ref_dec_bin(r, c, st, rd);
+    }
     w.cur.bits |= bin << (w.n - 1);
     w.cur.len = w.n;
     if (symbol_finished(w.cur, a.P) || w.n == 32) {
@@ -193,7 +203,8 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   for (uint32_t i = n_my; i < a.nsym; i++) row[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
-    a.status[s] = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+    a.status[s] = exact ? ref_dec_finish(r, rd, len)
+                        : dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
 }
 

@@ -234,6 +234,18 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
 }
 
 
+// one stream through the reference-formulation decoder (RefDec): what the engine uses for streams starting with 0xFF
+uint32_t lane_decode_stream_ref(const uint8_t *payload, uint32_t len, const uint8_t *ctx, uint32_t n, const uint8_t *ctx_init,
+                                int nctx, uint8_t *bins_out) {
+  HostStates st;
+  st.init(ctx_init, nctx);
+  RefReader rd{payload, len, 0, 0};
+  RefDec r;
+  ref_dec_start(r, rd);
+  for (uint32_t i = 0; i < n; i++) bins_out[i] = (uint8_t)(ctx[i] == kBypass ? ref_dec_bin_ep(r, rd) : ref_dec_bin(r, ctx[i], st, rd));
+  return ref_dec_finish(r, rd, len);
+}
+
 // the 16-bit next-state table of the encode kernel against the one-entry-per-state table: mismatches over all
 // (state 0..62, mps, mps/lps) combinations
 int lane_next16_mismatches() {

@@ -441,3 +441,50 @@ def test_device_side_per_stream_lengths_and_null_status(engine, oracle):
     got = out.cpu().numpy()
     for s in range(S):
         assert (got[s, :nb[s]] == hb[s, :nb[s]]).all() and (got[s, nb[s]:] == 0).all()
+
+
+def test_streams_starting_with_ff_decode_like_the_reference(engine, oracle):
+    """A first byte of 0xFF (no encoder emits it) puts the reference's value register above range << 7 for good: every
+    bin decodes as an LPS and the 32-bit register eventually wraps.  The engine decodes such streams in the reference's
+    own formulation (RefDec) so that bins and status flags stay equal -- batch kernel, symbol kernel and per-bin handle."""
+    from isscabac_amd import Stream, SymbolParams, init_by_prob
+    rng = np.random.default_rng(21)
+    S, B, C = 300, 500, 64
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    ctx = rng.integers(0, C, (S, B)).astype(np.uint8)
+    ctx[S // 2:][rng.random((S - S // 2, B)) < 0.3] = 0xFF  # some chunks with bypass bins
+    bins = rng.integers(0, 2, (S, B)).astype(np.uint8)
+    nb = rng.integers(0, B + 1, S).astype(np.uint32)
+    payload, offsets = oracle.encode_batch(bins, ctx, init, nb)
+    bad = payload.copy()
+    for s in range(0, S, 3):
+        a = int(offsets[s])
+        bad[a] = 0xFF
+        if s % 2:
+            bad[a + 1] = int(rng.integers(0, 256))
+    want_bins, want_status = oracle.decode_batch(bad, offsets, ctx, init, nb)
+    dec, status = engine.decode(bad, offsets, ctx, init, nb)
+    assert (status == want_status).all() and (status[::3] != 0).all()
+    for s in range(S):
+        assert (dec[s, :nb[s]] == want_bins[s, :nb[s]]).all(), s
+    # symbol kernel (cabacDemo selector, TU)
+    nq, N = 4, 400
+    sinit = init_by_prob([0.5, 0.5, 0.5])
+    params = SymbolParams.demo(nq)
+    syms = rng.integers(0, nq, (40, N)).astype(np.uint8)
+    p2, o2, _ = engine.encode_symbols(syms, params, sinit)
+    p2 = p2.copy()
+    for s in range(0, 40, 2):
+        p2[int(o2[s])] = 0xFF
+    got, st2 = engine.decode_symbols(p2, o2, N, params, sinit)
+    for s in range(40):
+        want, wst = oracle.demo_decode(p2[int(o2[s]):int(o2[s + 1])], N, nq, sinit)
+        assert st2[s] == wst and (got[s, :N] == want).all(), s
+    # per-bin handle
+    for s in (0, 3, 6):
+        n = int(nb[s])
+        h = Stream(engine, init)
+        h.decode_start(bad[int(offsets[s]):int(offsets[s + 1])])
+        d = h.decode_bins(ctx[s, :n]) if n else np.zeros(0, np.uint8)
+        assert (d == want_bins[s, :n]).all() and h.decode_finish() == want_status[s]
+        h.close()

@@ -239,3 +239,38 @@ def test_packed_helpers_ctx_quad_and_bin_collection(lane):
         got = np.zeros(16, np.uint8)
         lane.lane_collect16(words, _p(got))
         assert got.tolist() == bins.tolist()
+
+
+def test_reference_formulation_decoder_matches_oracle_even_on_streams_starting_with_ff(lane, oracle):
+    """RefDec (used for streams whose first byte is 0xFF) against the oracle on valid, corrupted and 0xFF-led streams;
+    and the look-ahead decoder differs from the oracle only on the 0xFF-led ones"""
+    lane.lane_decode_stream_ref.restype = C.c_uint32
+    lane.lane_decode_stream_ref.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, u8p]
+    rng = np.random.default_rng(11)
+    led, differ = 0, 0
+    for it in range(400):
+        n = int(rng.integers(1, 600))
+        Cn = int(rng.choice([1, 3, 64]))
+        init = rng.integers(0, 126, Cn).astype(np.uint8)
+        ctx = rng.integers(0, Cn, n).astype(np.uint8)
+        if it % 3 == 0:
+            ctx[rng.random(n) < 0.3] = 0xFF
+        bins = rng.integers(0, 2, n).astype(np.uint8)
+        payload = oracle.encode_stream(bins, ctx, init).copy()
+        if it % 2:
+            payload[0] = 0xFF  # no encoder emits this
+            if it % 4 == 1 and payload.size > 1:
+                payload[1] = int(rng.integers(0, 256))
+        elif it % 5 == 0:
+            payload[rng.integers(0, payload.size)] ^= 1 << int(rng.integers(0, 8))
+        want, st_want = oracle.decode_stream(payload, ctx, init)
+        got = np.zeros(n, np.uint8)
+        st = lane.lane_decode_stream_ref(_p(payload), payload.size, _p(ctx), n, _p(init), init.size, _p(got))
+        assert (got == want).all() and st == st_want, it
+        got2, st2, _, _ = lane_decode(lane, payload, ctx, init, group=3)
+        if payload[0] == 0xFF:
+            led += 1
+            differ += int(not (got2 == want).all() or st2 != st_want)
+        else:
+            assert (got2 == want).all() and st2 == st_want, it
+    assert led > 100 and differ > 0  # the case RefDec exists for is real
