@@ -193,8 +193,9 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     }
     w.cur.bits |= bin << (w.n - 1);
     w.cur.len = w.n;
-    if (symbol_finished(w.cur, a.P) || w.n == 32) {
-      row[w.idx] = (uint8_t)debinarize(w.cur, a.P);
+    const bool finished = symbol_finished(w.cur, a.P);
+    if (finished || w.n == 32) {  // 32 bins without an end: corrupt stream; the symbol is cut there and reads as 0
+      row[w.idx] = finished ? (uint8_t)debinarize(w.cur, a.P) : (uint8_t)0;
       w.next_symbol(a.P);
     } else {
       w.n++;

@@ -569,6 +569,10 @@ int orc_iss_ctx(int n, const uint8_t *g_prev, const uint8_t *g_up1, int len_up1,
 }
 
 #define ORC_MAX_SYM_BINS 96
+/* decoding: the reference has no limit on a symbol's bin string (MATLAB keeps appending), but a string longer than 32
+ * bins cannot come from a uint8 symbol (EG2 of 255 has 17 bins); on corrupt streams the engine cuts a symbol at 32 bins
+ * (its bin string is one 32-bit word) and the restatement does the same so that both stay in step afterwards */
+#define ORC_DEC_SYM_CAP 32
 
 static int binarize(uint32_t v, uint32_t nq, int method, uint32_t k, uint8_t *g) {
   return method == 0 ? orc_binarize_tu(v, nq - 1, g) : orc_binarize_egk(v, k, g);
@@ -615,14 +619,15 @@ uint32_t orc_iss_decode_column(const uint8_t *payload, size_t len, int rows, uin
   for (int d = 0; d < rows; d++) {
     sym_state st = {0, -1};
     int n = 1, done = 0;
-    while (!done && n <= ORC_MAX_SYM_BINS) {
+    while (!done && n <= ORC_DEC_SYM_CAP) {
       int id = orc_iss_ctx(n, g, up, len_up, types, nlbp);
       g[n - 1] = (uint8_t)orc_dec_bin(&dec, &cm[id - 1]);
       done = symbol_finished(g, n, nq, method, k, &st);
       n++;
     }
     int glen = n - 1;
-    sym_out[d] = method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
+    sym_out[d] = !done ? 0 /* cut at the cap: see ORC_DEC_SYM_CAP */
+                       : method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
     memcpy(up, g, (size_t)glen);
     len_up = glen;
   }
@@ -672,14 +677,14 @@ uint32_t orc_iss_decode_matrix(const uint8_t *payload, size_t len, int rows, int
     for (int d = 0; d < rows; d++) {
       sym_state st = {0, -1};
       int n = 1, done = 0;
-      while (!done && n <= ORC_MAX_SYM_BINS) {
+      while (!done && n <= ORC_DEC_SYM_CAP) {
         int id = orc_iss_ctx(n, g, up, len_up, types, nlbp);
         g[n - 1] = (uint8_t)orc_dec_bin(&dec, &cm[id - 1]);
         done = symbol_finished(g, n, nq, method, k, &st);
         n++;
       }
       int glen = n - 1;
-      sym_out[(size_t)c * rows + d] = method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
+      sym_out[(size_t)c * rows + d] = !done ? 0 : method == 0 ? orc_debinarize_tu(g, glen, nq - 1) : orc_debinarize_egk(g, glen, k);
       memcpy(up, g, (size_t)glen);
       len_up = glen;
     }

@@ -324,8 +324,9 @@ uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, 
     const uint32_t bin = dec_bin(d, c, st);
     w.cur.bits |= bin << (w.n - 1);
     w.cur.len = w.n;
-    if (symbol_finished(w.cur, P) || w.n == 32) {
-      sym_out[w.idx] = (uint8_t)debinarize(w.cur, P);
+    const bool finished = symbol_finished(w.cur, P);
+    if (finished || w.n == 32) {
+      sym_out[w.idx] = finished ? (uint8_t)debinarize(w.cur, P) : (uint8_t)0;
       w.next_symbol(P);
     } else {
       w.n++;
