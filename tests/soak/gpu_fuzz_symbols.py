@@ -64,5 +64,50 @@ while time.time() - t0 < budget:
             assert st[s] == wst, ("corrupt status", S, R, demo, s, st[s], wst)
             assert (dec[s, :n] == (want & 0xFF)).all(), ("corrupt symbols", S, R, demo, s)  # engine symbols are uint8
         flagged += int((st != 0).sum())
+    # --- whole matrix as ONE stream (col_rows), empirical context init, per-bin handle: a smaller case each round
+    if not demo and rounds % 4 == 0:
+        rows, cols = int(rng.choice([1, 5, 20, 109])), int(rng.choice([1, 3, 20]))
+        G = np.minimum(rng.exponential(skew, (rows, cols)).astype(np.int64), nq - 1).astype(np.uint8)
+        mp = SymbolParams.iss(nq, method, k, types, nlbp, col_rows=rows)
+        pm, om, nbm = eng.encode_symbols(G.T.reshape(1, -1).copy(), mp, init)
+        want, wnb = orc.iss_encode_matrix(G, nq, method, k, types, nlbp, init)
+        assert pm.tobytes() == want.tobytes() and nbm[0] == wnb, ("matrix payload", rows, cols)
+        dm, sm = eng.decode_symbols(pm, om, rows * cols, mp, init)
+        assert sm[0] == 0 and (dm[0, :rows * cols].reshape(cols, rows).T == G).all()
+        bm = pm.copy()
+        bm[int(rng.integers(0, bm.size))] ^= 1 << int(rng.integers(0, 8))
+        if rounds % 8 == 0:
+            bm[0] = 0xFF
+        dm, sm = eng.decode_symbols(bm, om, rows * cols, mp, init)
+        wantm, wsm = orc.iss_decode_matrix(bm, rows, cols, nq, method, k, types, nlbp, init)
+        assert sm[0] == wsm and (dm[0, :rows * cols].reshape(cols, rows).T == (wantm & 0xFF)).all(), ("matrix corrupt", rows, cols)
+        p0, b0 = eng.iss_init_context_model(G.T.copy(), SymbolParams.iss(nq, method, k, types, nlbp))
+        wp0, wb0 = orc.iss_init_context_model(G, nq, method, k, types, nlbp)
+        assert np.allclose(p0, wp0, rtol=0, atol=1e-15, equal_nan=True) and (b0 == wb0).all(), ("init model", rows, cols)
+    if rounds % 16 == 0 and payload.size:
+        from isscabac_amd import Stream
+        n = int(rng.integers(1, 200))
+        cx = rng.integers(0, nctx, n).astype(np.uint8)
+        cx[rng.random(n) < 0.2] = 0xFF
+        bn = rng.integers(0, 2, n).astype(np.uint8)
+        h = Stream(eng, init)
+        h.encode_start()
+        i = 0
+        while i < n:
+            j = min(n, i + int(rng.integers(1, 9)))
+            h.encode_bins(bn[i:j], cx[i:j])
+            i = j
+        ph = h.encode_finish()
+        assert ph.tobytes() == orc.encode_stream(bn, cx, init).tobytes()
+        bh = ph.copy()
+        if rounds % 32 == 0:
+            bh[0] = 0xFF
+        else:
+            bh[int(rng.integers(0, bh.size))] ^= 1 << int(rng.integers(0, 8))
+        h.decode_start(bh)
+        got = np.concatenate([h.decode_bins(cx[i:i + 7]) for i in range(0, n, 7)])
+        wantb, wsth = orc.decode_stream(bh, cx, init)
+        assert (got == wantb).all() and h.decode_finish() == wsth, "per-bin handle"
+        h.close()
     rounds += 1
 print("symbol soak ok: %d rounds, %d corrupted streams flagged, %.0f s" % (rounds, flagged, time.time() - t0))
