@@ -17,6 +17,8 @@
  *     (a MATLAB B x S uint8 matrix, column-major, is exactly this with pitch = B).
  *     pitch must be a multiple of 16, at most ISSCABAC_MAX_PITCH, and the base pointers 16-byte aligned
  *     (the kernels address a wave's 64 rows with 32-bit offsets; one longer stream goes through a stream handle).
+ *   - bins[i] is 0 or 1 (the reference's MEX refuses anything else, ref: CABAC/SimpleCABACMex.cpp:221-228); other
+ *     values are not checked in the batch calls and give an unspecified (but memory-safe) result for that stream.
  *   - ctx[i] = context index 0..nctx-1, or ISSCABAC_BYPASS (0xFF) for an equiprobable bin
  *     (ref: encodeBinEP, CABAC/CABAC_ArithmeticEncoder.cpp:250-270 -- not reachable through the
  *     reference MEX; additive).
