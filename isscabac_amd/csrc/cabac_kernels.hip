@@ -187,7 +187,17 @@ struct LdsStates {
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
   __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
-  __device__ __forceinline__ uint8_t *addr_of(const CtxQuad &z, int k) const { return base + quad_field(z, k); }
+  // address = lane base + 16-bit field of the quad, in ONE instruction (SDWA word select) and as a 32-bit LDS address
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  __device__ __forceinline__ lds_u8 *addr_of(const CtxQuad &z, int k) const {
+    const uint32_t b32 = (uint32_t)(uintptr_t)(lds_u8 *)base, zz = k < 2 ? z.z01 : z.z23;
+    uint32_t a;
+    if ((k & 1) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"(b32), "v"(zz));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a) : "v"(b32), "v"(zz));
+    return (lds_u8 *)(uintptr_t)a;
+  }
+  __device__ __forceinline__ uint32_t load_at(const lds_u8 *a) const { return *a; }
+  __device__ __forceinline__ void store_at(lds_u8 *a, uint32_t p) const { *a = (uint8_t)p; }
   __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
 #ifdef ISSCABAC_ABL_NO_STATE_LDS
@@ -1007,6 +1017,14 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
+  static int static_lds = -1;  // absolute LDS addresses, as in run_encode
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode<CM>));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
   hipLaunchKernelGGL((k_decode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
   return hipGetLastError();
