@@ -64,7 +64,9 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
   __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
 }
 
-constexpr int kWavesPerBlock = 4;
+// waves per workgroup: 4, except with more than 64 contexts (16 KiB of states per wave): single-wave workgroups then let
+// 7 waves share a CU's LDS instead of 4
+constexpr int waves_per_block(int cm) { return cm == 2 ? 1 : 4; }
 constexpr int kTabBytes = 1280;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
                                  // entries, [768,1024) successor bytes by (packed state, bin), [1024,1280) by (.., path)
 constexpr int kTab16Off = 512, kTabBinOff = 768, kTabPathOff = 1024;
@@ -352,7 +354,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[192 + tid] = c_next.eb[tid];
   }
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
+  const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
   using WL = WaveLds<CM>;
@@ -567,7 +569,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     tab[256 + tid] = c_next.ep[tid];
   }
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * kWavesPerBlock + wib) * 64;
+  const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
   using WL = WaveLds<CM>;
@@ -988,7 +990,7 @@ uint64_t slot_stride_for(uint32_t nbins) {
 
 template <int CM>
 static size_t coder_lds_bytes() {
-  return kTabBytes + kWavesPerBlock * WaveLds<CM>::BYTES;
+  return kTabBytes + waves_per_block(CM) * WaveLds<CM>::BYTES;
 }
 
 template <int CM>
@@ -1006,8 +1008,8 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-  hipLaunchKernelGGL((k_encode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
+  hipLaunchKernelGGL((k_encode<CM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1025,8 +1027,8 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-  hipLaunchKernelGGL((k_decode<CM>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
+  hipLaunchKernelGGL((k_decode<CM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
