@@ -9,7 +9,7 @@
 //     stream's bytes back 16 at a time with conflict-free ds_read_b128.  The next round's global loads
 //     are issued while the current one is coded, so HBM latency hides behind >= 32 bins of arithmetic.
 //   * per-stream context states: one byte per (stream, ctx) in LDS at  (ctx/4)*256 + lane*4 + ctx%4 ,
-//     so every lane always hits its own bank; with <= 4 contexts they live in one VGPR instead.
+//     so every lane always hits its own bank.
 //   * rangeTabLps and the successor states are 256-byte LDS tables read by absolute LDS address
 //     ([state][column]; [packed state][bin] for the encoder, [packed state][lps] for the decoder): one
 //     address instruction per lookup, no extraction.  Chunks with bypass bins use 64-entry dword tables
@@ -246,29 +246,6 @@ struct LdsStates {
     return NEXT16 ? next_state_q16(lps_mask, entry) : next_state_q(q, lps_mask, entry);
   }
 };
-// <= 4 contexts: the four state bytes live in one VGPR
-template <bool XBAR>
-struct RegStates {
-  uint32_t *packed;
-  const uint32_t *tab;
-  uint32_t row_tab, next_tab;
-  __device__ __forceinline__ uint32_t addr(uint32_t c) const { return 8u * (c & 3u); }
-  __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return CtxQuad{(cw & 0x03030303u) << 3, 0u}; }
-  __device__ __forceinline__ uint32_t addr_of(const CtxQuad &z, int k) const { return (z.z01 >> (8 * k)) & 0xFFu; }
-  __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return (*packed >> a) & 0xFFu; }
-  // only the low byte of q is meaningful (next_state_q leaves garbage above it)
-  __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *packed = (*packed & ~(0xFFu << a)) | ((q & 0xFFu) << a); }
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return load_at(addr(c)); }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { store_at(addr(c), p); }
-  // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
-  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
-    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
-  }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
-    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
 // (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
@@ -323,7 +300,7 @@ struct EncArgs {
 // LDS bytes of one wave: context states, two half tiles, (encoder) the output staging
 template <int CM>
 struct WaveLds {
-  static constexpr uint32_t SB = CM == 0 ? 0u : (CM == 1 ? 4096u : 16384u);
+  static constexpr uint32_t SB = CM == 1 ? 4096u : 16384u;  // CM 1: <= 64 contexts, CM 2: <= 255
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE;
@@ -336,10 +313,9 @@ struct WaveLds {
 #define ISSCABAC_FLUSH_FN enc_flush16_wave  // or enc_flush16: the general loop only
 #endif
 
-template <int CM, bool XBAR>
-using StatesFor = typename std::conditional<CM == 0, RegStates<XBAR>, LdsStates<XBAR>>::type;
-template <int CM>
-using EncStatesFor = typename std::conditional<CM == 0, RegStates<true>, LdsStates<true, true>>::type;
+template <bool XBAR>
+using StatesFor = LdsStates<XBAR>;
+using EncStatesFor = LdsStates<true, true>;
 
 template <int CM>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
@@ -369,21 +345,13 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 
   // context states
   // doubled states q = m_ucState << 1, four per dword
-  uint32_t packed = (a.ctx_init[0] & 0x7F7F7F7Fu) << 1;
-  if (CM != 0) {
+  {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
     const uint32_t ngrp = (a.nctx + 3) / 4;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  EncStatesFor<CM> stx;
-  StatesFor<CM, false> stm;
-  if constexpr (CM == 0) {
-    stx = {&packed, tab, c_lps_rows[lane], c_next.e[lane]};
-    stm = {&packed, tab, 0, 0};
-  } else {
-    stx = {wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
-    stm = {wbase + lane * 4, tab, 0, 0};
-  }
+  EncStatesFor stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
+  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};
 
   EncCore e;
   enc_start(e);
@@ -426,18 +394,17 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-#ifndef ISSCABAC_ENC_XBAR  // (tables through ds_bpermute instead: 2 more VALU per bin, measured 1.8% slower)
-            if constexpr (CM != 0) {
-              if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-              else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-              else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-              else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-            } else
-#endif
+#ifndef ISSCABAC_ENC_XBAR
+            if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+            else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+#else  // tables through ds_bpermute instead: 2 more VALU per bin, measured 1.8% slower
             if ((k & 3) == 0) enc_bin_at(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
             else if ((k & 3) == 1) enc_bin_at(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
             else if ((k & 3) == 2) enc_bin_at(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
             else enc_bin_at(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+#endif
 #ifndef ISSCABAC_ABL_NO_FLUSH
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a
@@ -450,23 +417,18 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         } else if (full) {
           // bypass bins (or contexts >= 128) somewhere in the wave.  The byte-table bin step works under any exec mask,
           // so context-coded and bypass lanes simply take their own branch (both sides run when a wave mixes them:
-          // ~29 VALU per bin against ~37 for one combined, select-based step).  <= 4 contexts (states in a VGPR,
-          // tables through ds_bpermute, which needs all lanes): combined step.
+          // ~29 VALU per bin against ~37 for one combined, select-based step).
 #pragma unroll
           for (int k = 0; k < 16; k++) {
-            if constexpr (CM != 0) {
-              const CtxQuad z = stx.prep4(word_of(wc, k >> 2));
-              const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-              if (byte_of(wc, k) != kBypass) {
-                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-              } else {
-                enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
-              }
+            const CtxQuad z = stx.prep4(word_of(wc, k >> 2));
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+            if (byte_of(wc, k) != kBypass) {
+              if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+              else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+              else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+              else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
             } else {
-              enc_bin_any(e, bin_at_bit1(wb, k), byte_of(wc, k), stx);
+              enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
             }
             if ((k & 3) == 3 && wave_any(e.W >= 39)) ISSCABAC_FLUSH_FN(e, sink);
           }
@@ -583,21 +545,13 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t nmin = wave_min_u32(n);
 
   // doubled states q = m_ucState << 1, four per dword
-  uint32_t packed = (a.ctx_init[0] & 0x7F7F7F7Fu) << 1;
-  if (CM != 0) {
+  {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
     const uint32_t ngrp = (a.nctx + 3) / 4;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  StatesFor<CM, true> stx;
-  StatesFor<CM, false> stm;
-  if constexpr (CM == 0) {
-    stx = {&packed, tab, c_lps_rows[lane], c_next.e[lane]};
-    stm = {&packed, tab, 0, 0};
-  } else {
-    stx = {wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
-    stm = {wbase + lane * 4, tab, 0, 0};
-  }
+  StatesFor<true> stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
+  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};
 
   // payload window
   const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
@@ -700,45 +654,44 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
               const uint32_t cw = word_of(wc, g);
               dec_topup_nocheck(d, src);
+              const CtxQuad z = stx.prep4(cw);
+#ifndef ISSCABAC_DEC_XBAR
+              // ob collects (mps, path) pairs here, turned into bins after the chunk.  With bypass bins in the chunk,
+              // context-coded and bypass lanes take their own branch (see k_encode).
               if (!hi) {
-                const CtxQuad z = stx.prep4(cw);
-#ifndef ISSCABAC_DEC_XBAR  // (tables through ds_bpermute instead: 3 more VALU per bin, measured 1.8% slower)
-                if constexpr (CM != 0) {  // ob collects (mps, lps) pairs here; turned into bins after the chunk
 #pragma unroll
-                  for (int k = 0; k < 4; k++) {
-                    if (k == 3) dec_guard(d, src, 7);
-                    ob = collect_bin(ob, dec_bin_at_mem(d, stx.addr_of(z, k), stx));
-                  }
-                } else
-#endif
+                for (int k = 0; k < 4; k++) {
+                  if (k == 3) dec_guard(d, src, 7);
+                  ob = collect_bin(ob, dec_bin_at_mem(d, stx.addr_of(z, k), stx));
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  if (k == 3) dec_guard(d, src, 8);
+                  uint32_t w;
+                  if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
+                  else w = pair_of_bin(dec_bin_ep(d));
+                  ob = collect_bin(ob, w);
+                }
+              }
+#else  // tables through ds_bpermute and one combined step for chunks with bypass bins: 3 more VALU per bin
+              if (!hi) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 7);
                   ob = collect_bin(ob, dec_bin_at_b1(d, stx.addr_of(z, k), stx));
                 }
               } else {
-#ifndef ISSCABAC_DEC_XBAR
-                if constexpr (CM != 0) {  // context-coded and bypass lanes take their own branch (see k_encode)
-                  const CtxQuad z = stx.prep4(cw);
-#pragma unroll
-                  for (int k = 0; k < 4; k++) {
-                    if (k == 3) dec_guard(d, src, 8);
-                    uint32_t w;
-                    if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                    else w = pair_of_bin(dec_bin_ep(d));
-                    ob = collect_bin(ob, w);
-                  }
-                } else
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 8);
                   ob = collect_bin(ob, dec_bin_any_b1(d, (cw >> (8 * k)) & 0xFFu, stx));
                 }
               }
+#endif
             }
 #ifndef ISSCABAC_DEC_XBAR
-            if (CM != 0) ob = pairs_to_bins(ob);
+            ob = pairs_to_bins(ob);
 #endif
           } else {
             // ragged end: lanes drop out one by one, per-bin guard, tables from LDS memory (bpermute cannot read
@@ -1032,12 +985,10 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-#define ISSCABAC_DISPATCH(FN, ARGS)                            \
-  do {                                                         \
-    const int cm = sh.nctx <= 4 ? 0 : (sh.nctx <= 64 ? 1 : 2); \
-    if (cm == 0) return FN<0>(ARGS, stream);                   \
-    if (cm == 1) return FN<1>(ARGS, stream);                   \
-    return FN<2>(ARGS, stream);                                \
+#define ISSCABAC_DISPATCH(FN, ARGS)             \
+  do {                                          \
+    if (sh.nctx <= 64) return FN<1>(ARGS, stream); \
+    return FN<2>(ARGS, stream);                 \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
