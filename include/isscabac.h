@@ -162,11 +162,36 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
                                 const uint64_t *d_offsets, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
                                 uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
                                 int nctx, uint8_t *d_sym_out, uint32_t *d_status);
+/* The encoder-side debugging statistics of +coder/cabacEncode.m (ref: ISS/+coder/cabacEncode.m:39-42,60-67), per
+ * stream, all optional (NULL = not wanted):
+ *   ctx_hist[s * ISSCABAC_STAT_CTX + c]  bins coded with context c                              (ctxHist)
+ *   ctx_cost[s * ISSCABAC_STAT_CTX + c]  growth of getNumBits() while coding them               (ctxCost)
+ *   sym_bits[s * pitch + i]              growth of getNumBits() over symbol i, the heat map     (H)
+ * getNumBits() counts bits already written to the file (whole bytes, ref: CABAC/CABAC_BitstreamFile.h:70), so the
+ * kernel emits bytes at the reference's own cadence (one write-out test per bin), as this symbol path always does. */
+#define ISSCABAC_STAT_CTX 64
+typedef struct isscabac_symbol_stats {
+  uint32_t *ctx_hist;
+  uint32_t *ctx_cost;
+  uint16_t *sym_bits;
+} isscabac_symbol_stats;
+/* as isscabac_encode_symbols_dev, d_stats->* are device pointers */
+int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
+                                      uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                      const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
+                                      uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out,
+                                      const isscabac_symbol_stats *d_stats);
 /* host-buffer forms (H2D, kernels, D2H inside) */
 int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
                             uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
                             const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
                             uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out);
+/* stats->* are host arrays ([S * ISSCABAC_STAT_CTX] x 2 and [S * pitch]) */
+int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                                  uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                  const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                                  uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out,
+                                  const isscabac_symbol_stats *stats);
 int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets,
                             const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym, uint32_t pitch,
                             const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,

@@ -58,6 +58,8 @@ struct SymEncArgs {
   const uint32_t *nsym_per_stream;
   uint8_t *slots;
   uint32_t *lens, *nbins_out;
+  uint32_t *ctx_hist, *ctx_cost;  // optional statistics (include/isscabac.h: isscabac_symbol_stats)
+  uint16_t *sym_bits;
   uint64_t S, slot_stride;
   uint32_t nsym, pitch, nctx;
   SymParams P;
@@ -95,20 +97,39 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   w.start();
   uint32_t nbins = 0;
   uint4 buf = make_uint4(0, 0, 0, 0);
+  // statistics of cabacEncode.m:39-42,60-67 (debugging aid there, optional here): this lane's rows in global memory
+  uint32_t *hist = a.ctx_hist ? a.ctx_hist + s * ISSCABAC_STAT_CTX : nullptr;
+  uint32_t *cost = a.ctx_cost ? a.ctx_cost + s * ISSCABAC_STAT_CTX : nullptr;
+  uint16_t *hbits = a.sym_bits ? a.sym_bits + s * a.pitch : nullptr;
+  for (uint32_t c = 0; c < ISSCABAC_STAT_CTX; c++) {
+    if (hist) hist[c] = 0;
+    if (cost) cost[c] = 0;
+  }
+  uint32_t sym_start = 0;
   while (w.idx < n_my) {
     if (w.n == 1) {
       if ((w.idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row + w.idx);
       const uint32_t wi = (w.idx >> 2) & 3u;
       const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
       w.cur = binarize((word >> (8 * (w.idx & 3u))) & 0xFFu, a.P);
+      sym_start = sink.pos;
     }
     const uint32_t c = w.ctx(a.P);
+    const uint32_t before = sink.pos;  // 8 * pos = the reference's getNumBits()
     enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
     enc_flush(e, sink);
     nbins++;
-    if (w.n == w.cur.len) w.next_symbol(a.P);
-    else w.n++;
+    if (hist) hist[c]++;
+    if (cost) cost[c] += 8u * (sink.pos - before);
+    if (w.n == w.cur.len) {
+      if (hbits) hbits[w.idx] = (uint16_t)(8u * (sink.pos - sym_start));
+      w.next_symbol(a.P);
+    } else {
+      w.n++;
+    }
   }
+  if (hbits)
+    for (uint32_t i = n_my; i < a.nsym; i++) hbits[i] = 0;
   enc_finish(e, sink);
   sink.close();
   a.lens[s] = sink.pos;
@@ -432,7 +453,19 @@ int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const 
                                 uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
                                 uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes,
                                 uint32_t *d_nbins_out) {
+  return isscabac_encode_symbols_stats_dev(e, d_sym, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_payload, payload_cap,
+                                           d_offsets, total_bytes, d_nbins_out, nullptr);
+}
+
+int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
+                                      uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                      const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
+                                      uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out,
+                                      const isscabac_symbol_stats *d_stats) {
   SymEncArgs a;
+  a.ctx_hist = d_stats ? d_stats->ctx_hist : nullptr;
+  a.ctx_cost = d_stats ? d_stats->ctx_cost : nullptr;
+  a.sym_bits = d_stats ? d_stats->sym_bits : nullptr;
   uint32_t maxbins = 0;
   int rc = sym_check(e, "isscabac_encode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins);
   if (rc) return rc;
@@ -501,6 +534,14 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
 int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym,
                             uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
                             uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out) {
+  return isscabac_encode_symbols_stats(e, sym, nsym_per_stream, S, nsym, pitch, params, ctx_init, nctx, payload, payload_cap,
+                                       offsets, total_bytes, nbins_out, nullptr);
+}
+
+int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                                  uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
+                                  int nctx, uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes,
+                                  uint32_t *nbins_out, const isscabac_symbol_stats *stats) {
   if (!e) return ISSCABAC_ERR_ARG;
   if (!sym || !payload || !offsets || !params) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols: null buffer");
   const uint32_t maxbins = isscabac_symbol_max_bins(params);
@@ -515,11 +556,25 @@ int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32
   if ((rc = sym_grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
   HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, in_bytes, hipMemcpyHostToDevice, e->stream));
   if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  // statistics: one device block behind the staged symbols' own buffer [hist | cost | sym_bits]
+  isscabac_symbol_stats dst = {nullptr, nullptr, nullptr};
+  const uint64_t hbytes = S * ISSCABAC_STAT_CTX * sizeof(uint32_t), sbytes = S * pitch * sizeof(uint16_t);
+  if (stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits)) {
+    if ((rc = sym_grow(e, &e->stage[1], &e->stage_bytes[1], 2 * hbytes + sbytes))) return rc;
+    uint8_t *b = static_cast<uint8_t *>(e->stage[1]);
+    if (stats->ctx_hist) dst.ctx_hist = reinterpret_cast<uint32_t *>(b);
+    if (stats->ctx_cost) dst.ctx_cost = reinterpret_cast<uint32_t *>(b + hbytes);
+    if (stats->sym_bits) dst.sym_bits = reinterpret_cast<uint16_t *>(b + 2 * hbytes);
+  }
   uint64_t total = 0;
-  rc = isscabac_encode_symbols_dev(e, static_cast<uint8_t *>(e->stage[0]), nsym_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr,
-                                   S, nsym, pitch, params, ctx_init, nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap,
-                                   static_cast<uint64_t *>(e->stage[4]), &total, static_cast<uint32_t *>(e->stage[5]));
+  rc = isscabac_encode_symbols_stats_dev(e, static_cast<uint8_t *>(e->stage[0]),
+                                         nsym_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nsym, pitch, params,
+                                         ctx_init, nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap,
+                                         static_cast<uint64_t *>(e->stage[4]), &total, static_cast<uint32_t *>(e->stage[5]), &dst);
   if (rc) return rc;
+  if (dst.ctx_hist) HIP_TRY(e, hipMemcpyAsync(stats->ctx_hist, dst.ctx_hist, hbytes, hipMemcpyDeviceToHost, e->stream));
+  if (dst.ctx_cost) HIP_TRY(e, hipMemcpyAsync(stats->ctx_cost, dst.ctx_cost, hbytes, hipMemcpyDeviceToHost, e->stream));
+  if (dst.sym_bits) HIP_TRY(e, hipMemcpyAsync(stats->sym_bits, dst.sym_bits, sbytes, hipMemcpyDeviceToHost, e->stream));
   if (total_bytes) *total_bytes = total;
   if (total > payload_cap)
     return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols: payload needs %llu bytes, capacity is %llu",

@@ -41,6 +41,14 @@ class SymbolParams(C.Structure):
         return cls(0 if method == "TU" else 1, k, nq, 1, types, nlbp, col_rows)
 
 
+class SymbolStats(C.Structure):
+    """isscabac_symbol_stats: the encoder-side statistics of +coder/cabacEncode.m (ctxHist, ctxCost, H)."""
+    _fields_ = [("ctx_hist", C.POINTER(C.c_uint32)), ("ctx_cost", C.POINTER(C.c_uint32)), ("sym_bits", C.POINTER(C.c_uint16))]
+
+
+STAT_CTX = 64
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("isscabac error %d: %s" % (code, msg))
@@ -97,6 +105,9 @@ def _load():
                                               C.POINTER(SymbolParams), _u8p, C.c_int, _vp, _vp]
     L.isscabac_encode_symbols.argtypes = [_vp, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
                                           _u8p, C.c_int, _u8p, C.c_uint64, _u64p, _u64p, _u32p]
+    L.isscabac_encode_symbols_stats.argtypes = [_vp, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                C.POINTER(SymbolParams), _u8p, C.c_int, _u8p, C.c_uint64, _u64p, _u64p,
+                                                _u32p, C.POINTER(SymbolStats)]
     L.isscabac_decode_symbols.argtypes = [_vp, _u8p, _u64p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32,
                                           C.POINTER(SymbolParams), _u8p, C.c_int, _u8p, _u32p]
     L.isscabac_iss_init_context_model.argtypes = [_vp, _u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
@@ -285,6 +296,34 @@ class Engine:
                                                     C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
                                                     _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p)))
         return payload[:int(total.value)].copy(), offsets, nbins
+
+    def encode_symbols_stats(self, sym, params, ctx_init, nsym=None):
+        """encode_symbols plus cabacEncode.m's statistics: returns (payload, offsets, bins_per_stream,
+        ctx_hist uint32[S, 64], ctx_cost uint32[S, 64], sym_bits uint16[S, R])."""
+        sym = _np(sym, np.uint8)
+        S, R = sym.shape
+        pitch = max(16, (R + 15) // 16 * 16)
+        symp = self._pad_rows(sym, pitch)
+        ci = _np(ctx_init, np.uint8)
+        ns = None if nsym is None else _np(nsym, np.uint32)
+        mb = int(self._L.isscabac_symbol_max_bins(C.byref(params)))
+        if mb == 0:
+            raise EngineError(1, "unsupported symbol parameters")
+        cap = S * stream_bound(R * mb)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        nbins = np.zeros(S, np.uint32)
+        hist = np.zeros((S, STAT_CTX), np.uint32)
+        cost = np.zeros((S, STAT_CTX), np.uint32)
+        hb = np.zeros((S, pitch), np.uint16)
+        st = SymbolStats(hist.ctypes.data_as(C.POINTER(C.c_uint32)), cost.ctypes.data_as(C.POINTER(C.c_uint32)),
+                         hb.ctypes.data_as(C.POINTER(C.c_uint16)))
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_symbols_stats(self._h, _ptr(symp, _u8p), _ptr(ns, _u32p), S, R, pitch,
+                                                          C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p),
+                                                          cap, _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p),
+                                                          C.byref(st)))
+        return payload[:int(total.value)].copy(), offsets, nbins, hist, cost, hb[:, :R].copy()
 
     def decode_symbols(self, payload, offsets, R, params, ctx_init, nsym=None):
         """Returns (sym uint8[S, R], status uint32[S])."""

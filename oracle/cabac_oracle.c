@@ -663,6 +663,39 @@ size_t orc_iss_encode_matrix(const uint32_t *sym, int rows, int cols, uint32_t n
   return e.sink.overflow ? 0 : e.sink.len;
 }
 
+/* the same walk with the debugging statistics of cabacEncode.m:39-42,60-67: ctx_hist[id-1] = bins coded with context
+ * id, ctx_cost[id-1] = getNumBits() growth while coding them, sym_bits[c*rows+d] = H(d,k) = getNumBits() growth over the
+ * symbol (getNumBits counts the bits already written to the file, CABAC_BitstreamFile.h:70: whole bytes) */
+size_t orc_iss_encode_matrix_stats(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                                   unsigned types, int nlbp, const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
+                                   uint32_t *ctx_hist, uint32_t *ctx_cost, uint32_t *sym_bits) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  memcpy(cm, ctx_init, (size_t)nctx);
+  uint8_t g[ORC_MAX_SYM_BINS], up[ORC_MAX_SYM_BINS];
+  orc_encoder e;
+  orc_enc_start(&e, out, cap);
+  for (int c = 0; c < cols; c++) {
+    int len_up = 0;
+    for (int d = 0; d < rows; d++) {
+      const uint64_t sym_start = orc_enc_bits(&e);
+      int len = binarize(sym[(size_t)c * rows + d], nq, method, k, g);
+      for (int cnt = 1; cnt <= len; cnt++) {
+        int id = orc_iss_ctx(cnt, g, up, len_up, types, nlbp);
+        const uint64_t before = orc_enc_bits(&e);
+        orc_enc_bin(&e, g[cnt - 1], &cm[id - 1]);
+        ctx_hist[id - 1]++;
+        ctx_cost[id - 1] += (uint32_t)(orc_enc_bits(&e) - before);
+      }
+      sym_bits[(size_t)c * rows + d] = (uint32_t)(orc_enc_bits(&e) - sym_start);
+      memcpy(up, g, (size_t)len);
+      len_up = len;
+    }
+  }
+  orc_enc_finish(&e);
+  return e.sink.overflow ? 0 : e.sink.len;
+}
+
 uint32_t orc_iss_decode_matrix(const uint8_t *payload, size_t len, int rows, int cols, uint32_t nq, int method,
                                uint32_t k, unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
                                uint32_t *sym_out) {

@@ -152,6 +152,9 @@ uint32_t orc_iss_decode_column(const uint8_t *payload, size_t len, int rows, uin
 size_t orc_iss_encode_matrix(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
                              unsigned types, int nlbp, const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
                              uint32_t *nbins_out);
+size_t orc_iss_encode_matrix_stats(const uint32_t *sym, int rows, int cols, uint32_t nq, int method, uint32_t k,
+                                   unsigned types, int nlbp, const uint8_t *ctx_init, int nctx, uint8_t *out, size_t cap,
+                                   uint32_t *ctx_hist, uint32_t *ctx_cost, uint32_t *sym_bits);
 uint32_t orc_iss_decode_matrix(const uint8_t *payload, size_t len, int rows, int cols, uint32_t nq, int method,
                                uint32_t k, unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
                                uint32_t *sym_out);

@@ -293,6 +293,24 @@ class Oracle:
                                            _p(ctx_init, u8p), ctx_init.size, _p(out, u8p), cap, C.byref(nb))
         return out[:n].copy(), int(nb.value)
 
+    def iss_encode_matrix_stats(self, G, nq, method, k, types, nlbp, ctx_init):
+        """-> (payload, ctxHist[7*nlbp+2], ctxCost[...], H[rows, cols]) of cabacEncode.m:39-42,60-67"""
+        G = np.asarray(G)
+        rows, cols = G.shape
+        sym = np.ascontiguousarray(G.T, np.uint32).ravel()
+        ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
+        cap = self.stream_cap(sym.size * 96)
+        out = np.zeros(cap, np.uint8)
+        n = 7 * nlbp + 2
+        hist, cost, H = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(rows * cols, np.uint32)
+        f = self.lib.orc_iss_encode_matrix_stats
+        f.restype = C.c_size_t
+        f.argtypes = [u32p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint, C.c_int, u8p, C.c_int, u8p,
+                      C.c_size_t, u32p, u32p, u32p]
+        m = f(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp, _p(ctx_init, u8p), ctx_init.size,
+              _p(out, u8p), cap, _p(hist, u32p), _p(cost, u32p), _p(H, u32p))
+        return out[:m].copy(), hist, cost, H.reshape(cols, rows).T.copy()
+
     def iss_decode_matrix(self, payload, rows, cols, nq, method, k, types, nlbp, ctx_init):
         payload = np.ascontiguousarray(payload, np.uint8)
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)

@@ -81,6 +81,10 @@ while time.time() - t0 < budget:
         dm, sm = eng.decode_symbols(bm, om, rows * cols, mp, init)
         wantm, wsm = orc.iss_decode_matrix(bm, rows, cols, nq, method, k, types, nlbp, init)
         assert sm[0] == wsm and (dm[0, :rows * cols].reshape(cols, rows).T == (wantm & 0xFF)).all(), ("matrix corrupt", rows, cols)
+        _, _, _, hist, cost, hb = eng.encode_symbols_stats(G.T.reshape(1, -1).copy(), mp, init)
+        _, wh, wc, wH = orc.iss_encode_matrix_stats(G, nq, method, k, types, nlbp, init)
+        assert (hist[0, :nctx] == wh).all() and (cost[0, :nctx] == wc).all(), ("stats", rows, cols)
+        assert (hb[0, :rows * cols].reshape(cols, rows).T == wH).all(), ("heat map", rows, cols)
         p0, b0 = eng.iss_init_context_model(G.T.copy(), SymbolParams.iss(nq, method, k, types, nlbp))
         wp0, wb0 = orc.iss_init_context_model(G, nq, method, k, types, nlbp)
         assert np.allclose(p0, wp0, rtol=0, atol=1e-15, equal_nan=True) and (b0 == wb0).all(), ("init model", rows, cols)

@@ -488,3 +488,31 @@ def test_streams_starting_with_ff_decode_like_the_reference(engine, oracle):
         d = h.decode_bins(ctx[s, :n]) if n else np.zeros(0, np.uint8)
         assert (d == want_bins[s, :n]).all() and h.decode_finish() == want_status[s]
         h.close()
+
+
+def test_encoder_statistics_ctxhist_ctxcost_heatmap(engine, oracle):
+    """+coder/cabacEncode.m:39-42,60-67: ctxHist, ctxCost and the heat map H, per column and for a whole matrix coded
+    as one stream, against the oracle's walk (getNumBits() growth per bin / per symbol)."""
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(4)
+    for nq, method, k, types, nlbp, rows, cols in [(8, "EG", 0, 15, 3, 109, 20), (8, "TU", 0, 31, 2, 50, 7),
+                                                   (16, "EG", 1, 5, 1, 33, 3)]:
+        n = 7 * nlbp + 2
+        init = init_by_prob(rng.random(n))
+        G = np.minimum(rng.exponential(1.4, (rows, cols)).astype(np.int64), nq - 1).astype(np.uint8)
+        # columns as independent streams
+        params = SymbolParams.iss(nq, method, k, types, nlbp)
+        payload, offsets, nbins, hist, cost, hb = engine.encode_symbols_stats(G.T.copy(), params, init)
+        for c in range(cols):
+            wp, wh, wc, wH = oracle.iss_encode_matrix_stats(G[:, c:c + 1], nq, method, k, types, nlbp, init)
+            assert payload[int(offsets[c]):int(offsets[c + 1])].tobytes() == wp.tobytes()
+            assert (hist[c, :n] == wh).all() and (cost[c, :n] == wc).all() and (hist[c, n:] == 0).all()
+            assert (hb[c, :rows] == wH[:, 0]).all() and nbins[c] == wh.sum()
+        # the whole matrix as one stream (what ISS.m writes)
+        mparams = SymbolParams.iss(nq, method, k, types, nlbp, col_rows=rows)
+        payload, offsets, nbins, hist, cost, hb = engine.encode_symbols_stats(G.T.reshape(1, -1).copy(), mparams, init)
+        wp, wh, wc, wH = oracle.iss_encode_matrix_stats(G, nq, method, k, types, nlbp, init)
+        assert payload.tobytes() == wp.tobytes()
+        assert (hist[0, :n] == wh).all() and (cost[0, :n] == wc).all()
+        assert (hb[0, :rows * cols].reshape(cols, rows).T == wH).all()
+        assert cost[0].sum() + 8 * 0 <= 8 * payload.size  # what finish() writes is nobody's cost
