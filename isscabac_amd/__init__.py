@@ -4,4 +4,5 @@ include/isscabac.h; this package is the thin host-side binding."""
 from .engine import (BYPASS, Engine, EngineError, Stream, SymbolParams, init_by_prob, init_by_state, lib_path,  # noqa: F401
                      stream_bound)
 from .wrapper import cabacWrapper  # noqa: F401
+from . import coder  # noqa: F401
 

@@ -516,3 +516,33 @@ def test_encoder_statistics_ctxhist_ctxcost_heatmap(engine, oracle):
         assert (hist[0, :n] == wh).all() and (cost[0, :n] == wc).all()
         assert (hb[0, :rows * cols].reshape(cols, rows).T == wH).all()
         assert cost[0].sum() + 8 * 0 <= 8 * payload.size  # what finish() writes is nobody's cost
+
+
+def test_coder_front_end_mirrors_cabacEncode_cabacDecode(engine, oracle, tmp_path):
+    """isscabac_amd.coder.cabacEncode / cabacDecode (ISS/+coder) against the oracle's restatement of the same walk:
+    side-info bytes, file bytes, bit count, statistics, round trip; ISS.m's parameter-matrix shapes (config 4)."""
+    from isscabac_amd import coder, init_by_prob
+    rng = np.random.default_rng(12)
+    for (rows, cols), Nq, method, equal in [((400, 20), 8, "DEC2EG0", False), ((109, 20), 8, "DEC2EG0", True),
+                                            ((60, 7), 4, "DEC2TU", False), ((33, 5), 2, "DEC2EG0", False),
+                                            ((50, 3), 16, "DEC2EG1", False)]:
+        G = np.minimum(rng.exponential(1.3, (rows, cols)).astype(np.int64), Nq - 1).astype(np.uint8)
+        param = dict(binMethod=method, cmTypes=["cond0", "cond1", "conds0", "conds1"], Nlbp=3, equalProb=equal,
+                     fn=str(tmp_path / "g.bin"))
+        nbits, ctx0, hist, cost, H = coder.cabacEncode(G, Nq, param, engine=engine, stats=True)
+        kind, k, nq = ("TU", 0, 2) if Nq <= 2 else (("TU", 0, Nq) if method == "DEC2TU" else ("EG", int(method[-1]), Nq))
+        if equal:
+            want0 = np.full(23, 128, np.uint8)
+        else:
+            _, want0 = oracle.iss_init_context_model(G, nq, kind, k, 15, 3)
+        assert (ctx0 == want0).all()
+        states = oracle.init_by_prob(want0 / 255.0)
+        wp, wh, wc, wH = oracle.iss_encode_matrix_stats(G, nq, kind, k, 15, 3, states)
+        assert open(param["fn"], "rb").read() == wp.tobytes() and nbits == 8 * wp.size
+        assert (hist == wh).all() and (cost == wc).all() and (H == wH).all()
+        back = coder.cabacDecode(Nq, param, ctx0, G.shape, engine=engine)
+        assert (back == G).all()
+    bad = bytearray(open(param["fn"], "rb").read())
+    bad[-1] ^= 0x80
+    with pytest.raises(ValueError):
+        coder.cabacDecode(Nq, param, ctx0, G.shape, engine=engine, payload=np.frombuffer(bytes(bad), np.uint8))
