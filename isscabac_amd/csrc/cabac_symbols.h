@@ -31,6 +31,7 @@ struct SymParams {
 
 struct BinString {
   uint32_t bits, len;
+  uint32_t np;  // 1-based position of the first 0 bin (the end of a TU string / of an EG prefix), 0 = none so far
 };
 
 CABAC_HD uint32_t low_mask(uint32_t n) { return n >= 32 ? ~0u : ((1u << n) - 1u); }
@@ -38,10 +39,14 @@ CABAC_HD uint32_t first_zero_1based(uint32_t bits, uint32_t len) {  // 0 = none
   const uint32_t z = ~bits & low_mask(len);
   return z ? (uint32_t)__builtin_ctz(z) + 1u : 0u;
 }
-CABAC_HD uint32_t bitrev(uint32_t v, uint32_t n) {  // reverse the low n bits (n <= 32)
+CABAC_HD uint32_t bitrev(uint32_t v, uint32_t n) {  // reverse the low n bits (1 <= n <= 32)
+#if defined(__clang__)
+  return __builtin_bitreverse32(v) >> (32u - n);
+#else
   uint32_t r = 0;
   for (uint32_t i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1 - i);
   return r;
+#endif
 }
 
 CABAC_HD BinString binarize(uint32_t v, const SymParams &P) {
@@ -50,6 +55,7 @@ CABAC_HD BinString binarize(uint32_t v, const SymParams &P) {
     const uint32_t mx = P.nq - 1;
     g.bits = low_mask(v);
     g.len = v == mx ? mx : v + 1;
+    g.np = v == mx ? 0u : v + 1;
   } else {  // EGCode
     const uint32_t t = (v >> P.k) + 1;
     const uint32_t n_p = 32u - clz32(t);  // floor(log2(t)) + 1
@@ -57,14 +63,22 @@ CABAC_HD BinString binarize(uint32_t v, const SymParams &P) {
     const uint32_t v_s = v - (low_mask(n_p - 1) << P.k);
     g.bits = low_mask(n_p - 1) | (n_s ? bitrev(v_s, n_s) << n_p : 0u);  // suffix MSB first
     g.len = n_p + n_s;
+    g.np = n_p;
   }
   return g;
 }
 
+// bin n (1-based) of a symbol being decoded
+CABAC_HD BinString append_bin(BinString g, uint32_t n, uint32_t bin) {
+  g.bits |= bin << (n - 1);
+  g.len = n;
+  g.np = (g.np == 0 && bin == 0) ? n : g.np;
+  return g;
+}
+
 CABAC_HD uint32_t debinarize(BinString g, const SymParams &P) {
-  const uint32_t fz = first_zero_1based(g.bits, g.len);
-  if (P.method == 0) return fz ? fz - 1 : P.nq - 1;
-  const uint32_t n_p = fz;  // an EG string always has its prefix zero
+  if (P.method == 0) return g.np ? g.np - 1 : P.nq - 1;
+  const uint32_t n_p = g.np;  // an EG string always has its prefix zero
   const uint32_t n_s = g.len - n_p;
   const uint32_t suffix = n_s ? bitrev(g.bits >> n_p, n_s) : 0u;
   return (low_mask(n_p - 1) << P.k) + suffix;
@@ -73,46 +87,31 @@ CABAC_HD uint32_t debinarize(BinString g, const SymParams &P) {
 // has the symbol ended with bin n (1-based) = the bin just decoded?  g holds bins 1..n.
 CABAC_HD bool symbol_finished(BinString g, const SymParams &P) {
   const uint32_t n = g.len;
-  if (P.method == 0) return ((g.bits >> (n - 1)) & 1u) == 0 || n == P.nq - 1;
-  const uint32_t n_p = first_zero_1based(g.bits, n);
-  if (n_p == 0) return false;            // still in the prefix
-  return n == n_p + (P.k + n_p - 1);     // prefix + suffix complete (n_s == 0: done at the zero)
+  if (P.method == 0) return g.np == n || n == P.nq - 1;
+  return g.np != 0 && n == g.np + (P.k + g.np - 1);  // prefix + suffix complete (n_s == 0: done at the zero)
 }
 
-// 0-based context index for bin n (1-based) of the current symbol; cur holds at least bins 1..n-1, up is the bin
-// string of the symbol one row up (len 0 = none)
+// 0-based context index for bin n (1-based) of the current symbol; cur holds at least bins 1..n-1 (cur.np may describe
+// the whole symbol: only a zero before bin n counts), up is the bin string of the symbol one row up (len 0 = none)
 CABAC_HD uint32_t iss_ctx(uint32_t n, BinString cur, BinString up, const SymParams &P) {
   const uint32_t N = P.nlbp;
-  const uint32_t np_prev = first_zero_1based(cur.bits, n - 1);
-  const uint32_t np_up = first_zero_1based(up.bits, up.len);
-  const bool prefix_up = !(np_up && n > np_up);
+  const bool in_prefix = cur.np == 0 || cur.np >= n;           // no zero among bins 1..n-1
+  const bool prefix_up = up.np == 0 || n <= up.np;              // the upper symbol is still in its prefix at n
   const bool has_up = up.len >= n;
   const uint32_t upbit = (up.bits >> (n - 1)) & 1u;
-  uint32_t id;
-  if (np_prev == 0) {  // prefix
-    if (n <= N) {
-      id = n;
-      if (has_up && prefix_up) {
-        if (upbit == 0 && (P.types & 1u)) id = N + n;
-        else if (upbit == 1 && (P.types & 2u)) id = 2 * N + n;
-      } else if (n > 1 && ((cur.bits >> (n - 2)) & 1u) && (P.types & 16u)) {
-        id = 3 * N + n - 1;
-      }
-    } else {
-      id = 7 * N + 1;
-    }
-  } else {  // suffix
-    const uint32_t j = n - np_prev;
-    if (j <= N) {
-      id = 4 * N + j;
-      if (has_up && !prefix_up) {
-        if (upbit == 0 && (P.types & 4u)) id = 5 * N + j;
-        else if (upbit == 1 && (P.types & 8u)) id = 6 * N + j;
-      }
-    } else {
-      id = 7 * N + 2;
-    }
-  }
+  const uint32_t j = in_prefix ? n : n - cur.np;                // position inside the prefix / the suffix
+  const bool cond = has_up && (prefix_up == in_prefix);         // the upper bin n belongs to the same part
+  // the conditioning types: prefix cond0 / cond1 = bits 0 / 1, suffix conds0 / conds1 = bits 2 / 3
+  const uint32_t tbit = (in_prefix ? 0u : 2u) + upbit;
+  const bool use_up = cond && ((P.types >> tbit) & 1u);
+  const uint32_t base = in_prefix ? 0u : 4u * N;
+  uint32_t id = base + j;
+  id = use_up ? base + (1u + upbit) * N + j : id;
+  // prefix only: condbinlft (bit 4) when the upper symbol does not condition: previous bin of this symbol is 1 (always
+  // true inside a prefix for n > 1), ref: cabacContextSelection.m:44-45
+  const bool lft = in_prefix && !(has_up && prefix_up) && n > 1 && ((cur.bits >> (n - 2)) & 1u) && (P.types & 16u);
+  id = lft ? 3u * N + n - 1u : id;
+  id = j <= N ? id : 7u * N + (in_prefix ? 1u : 2u);
   return id - 1;  // cabacEncode.m:64 passes id-1 to the engine
 }
 
@@ -129,8 +128,8 @@ struct SymWalk {
   CABAC_HD void start() {
     idx = 0;
     n = 1;
-    cur.bits = cur.len = 0;
-    up.bits = up.len = 0;
+    cur.bits = cur.len = cur.np = 0;
+    up.bits = up.len = up.np = 0;
     prev_first = 0;
   }
   CABAC_HD uint32_t ctx(const SymParams &P) const {
@@ -141,8 +140,8 @@ struct SymWalk {
     prev_first = cur.bits & 1u;
     idx++;
     n = 1;
-    cur.bits = cur.len = 0;
-    if (P.col_rows && idx % P.col_rows == 0) up.bits = up.len = 0;  // first row of the next column
+    cur.bits = cur.len = cur.np = 0;
+    if (P.col_rows && idx % P.col_rows == 0) up.bits = up.len = up.np = 0;  // first row of the next column
   }
 };
 

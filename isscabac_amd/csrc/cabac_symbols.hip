@@ -212,8 +212,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     } else {
       bin = ref_dec_bin(r, c, st, rd);
     }
-    w.cur.bits |= bin << (w.n - 1);
-    w.cur.len = w.n;
+    w.cur = append_bin(w.cur, w.n, bin);
     const bool finished = symbol_finished(w.cur, a.P);
     if (finished || w.n == 32) {  // 32 bins without an end: corrupt stream; the symbol is cut there and reads as 0
       row[w.idx] = finished ? (uint8_t)debinarize(w.cur, a.P) : (uint8_t)0;

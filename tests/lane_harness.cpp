@@ -322,8 +322,7 @@ uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, 
     if (d.sh < 8) dec_refill(d, src);
     const uint32_t c = w.ctx(P);
     const uint32_t bin = dec_bin(d, c, st);
-    w.cur.bits |= bin << (w.n - 1);
-    w.cur.len = w.n;
+    w.cur = append_bin(w.cur, w.n, bin);
     const bool finished = symbol_finished(w.cur, P);
     if (finished || w.n == 32) {
       sym_out[w.idx] = finished ? (uint8_t)debinarize(w.cur, P) : (uint8_t)0;
