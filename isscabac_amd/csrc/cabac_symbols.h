@@ -125,8 +125,10 @@ struct SymWalk {
   uint32_t n;          // 1-based position of the next bin inside the current symbol
   BinString cur, up;
   uint32_t prev_first;
+  uint32_t row;        // idx % col_rows, kept by counting
   CABAC_HD void start() {
     idx = 0;
+    row = 0;
     n = 1;
     cur.bits = cur.len = cur.np = 0;
     up.bits = up.len = up.np = 0;
@@ -141,7 +143,11 @@ struct SymWalk {
     idx++;
     n = 1;
     cur.bits = cur.len = cur.np = 0;
-    if (P.col_rows && idx % P.col_rows == 0) up.bits = up.len = up.np = 0;  // first row of the next column
+    row++;
+    if (row == P.col_rows) {  // first row of the next column (never true for col_rows == 0)
+      row = 0;
+      up.bits = up.len = up.np = 0;
+    }
   }
 };
 

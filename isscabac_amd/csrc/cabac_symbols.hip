@@ -16,15 +16,26 @@ namespace isscabac {
 __device__ const uint32_t y_lps_rows[64] = {ISSCABAC_LPS_ROWS};
 struct SymNextTab {
   uint32_t e[64];
-  constexpr SymNextTab() : e{} {
+  uint32_t eb[64];  // successor bytes by (packed state, bin): four per dword
+  uint32_t ep[64];  // successor bytes by (packed state, path), path 0 = LPS, 1 = MPS
+  constexpr SymNextTab() : e{}, eb{}, ep{} {
     constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
-    for (uint32_t s = 0; s < 64; s++) e[s] = next_state_entry(s, trans[s]);
+    for (uint32_t s = 0; s < 64; s++) {
+      e[s] = next_state_entry(s, trans[s]);
+      const uint32_t a = next_state_entry16(2 * s, trans[s]), b = next_state_entry16(2 * s + 1, trans[s]);
+      ep[s] = (a >> 8) | (a & 0xFFu) << 8 | (b >> 8) << 16 | (b & 0xFFu) << 24;
+      eb[s] = next_state_by_bin(2 * s, 0, trans[s]) | next_state_by_bin(2 * s, 1, trans[s]) << 8 |
+              next_state_by_bin(2 * s + 1, 0, trans[s]) << 16 | next_state_by_bin(2 * s + 1, 1, trans[s]) << 24;
+    }
   }
 };
 __device__ const SymNextTab y_next{};
 
 constexpr int kSymWaves = 4;
-constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024, kSymTab = 512;
+constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
+// LDS of a workgroup: [0,256) rangeTabLps rows = [state][column] bytes, [256,512) next-state entries, [512,768) successor
+// bytes by (packed state, bin), [768,1024) by (packed state, path), then {bits, len | np << 8} per symbol value
+constexpr uint32_t kSymByBin = 512, kSymByPath = 768, kSymBinTab = 1024, kSymTab = 1024 + 256 * 8;
 constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
 
 // states in LDS (same conflict-free layout as the bin kernels), tables in LDS memory (lanes finish at different times)
@@ -38,6 +49,22 @@ struct SymStates {
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t q) const { *a = (uint8_t)q; }
   __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return tab[q >> 2]; }
   __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return tab[64 + (q >> 2)]; }
+  // byte tables by absolute LDS address, as in the bin kernels (no static LDS in these kernels: checked at launch)
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
+    return *reinterpret_cast<const lds_u8 *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
+  }
+  __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
+    return *reinterpret_cast<const lds_u8 *>((uintptr_t)(kSymByBin + q_or_bin));
+  }
+  __device__ __forceinline__ uint32_t path_index(uint32_t q) const { return kSymByPath + q; }
+  __device__ __forceinline__ uint32_t next_path_mem(uint32_t addr) const { return *reinterpret_cast<const lds_u8 *>((uintptr_t)addr); }
+};
+// Bin policy of enc_bin_at_mem for one bin in a register
+struct SymBin {
+  uint32_t bin;
+  __device__ __forceinline__ uint32_t xor_q(uint32_t q) const { return (bin << 1) ^ q; }
+  __device__ __forceinline__ uint32_t or_q(uint32_t q) const { return q | bin; }
 };
 
 struct SymSink {
@@ -71,6 +98,8 @@ __device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, u
   if (tid < 64) {
     tab[tid] = y_lps_rows[tid];
     tab[64 + tid] = y_next.e[tid];
+    tab[128 + tid] = y_next.eb[tid];
+    tab[192 + tid] = y_next.ep[tid];
   }
   __syncthreads();
   wbase = smem + kSymTab + (tid >> 6) * kSymWaveBytes;
@@ -81,15 +110,22 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t *tab;
   uint8_t *wbase;
+  {  // every symbol value binarised once per workgroup: the per-symbol work in the loop is then one LDS read
+    uint2 *bt = reinterpret_cast<uint2 *>(smem + kSymBinTab);
+    const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);
+    bt[tid] = make_uint2(g.bits, g.len | (g.np << 8));
+  }
   sym_init_common(smem, tab, wbase, tid);
+  const uint2 *bintab = reinterpret_cast<const uint2 *>(smem + kSymBinTab);
   const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   SymStates st{wbase + lane * 4, tab};
-  if (!valid) return;  // no cross-lane operation below
+  if (!valid) return;  // the only cross-lane operation below is a ballot over the lanes still coding
   uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   const uint8_t *row = a.sym + s * a.pitch;
+  const bool want_stats = a.ctx_hist || a.ctx_cost || a.sym_bits;
   EncCore e;
   enc_start(e);
   SymSink sink{wbase + kSymStateBytes + lane * 16, a.slots + s * a.slot_stride, 0};
@@ -111,13 +147,20 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
       if ((w.idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row + w.idx);
       const uint32_t wi = (w.idx >> 2) & 3u;
       const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
-      w.cur = binarize((word >> (8 * (w.idx & 3u))) & 0xFFu, a.P);
+      const uint2 g = bintab[(word >> (8 * (w.idx & 3u))) & 0xFFu];  // (values >= nq cannot be coded: undefined)
+      w.cur.bits = g.x;
+      w.cur.len = g.y & 0xFFu;
+      w.cur.np = g.y >> 8;
       sym_start = sink.pos;
     }
     const uint32_t c = w.ctx(a.P);
     const uint32_t before = sink.pos;  // 8 * pos = the reference's getNumBits()
-    enc_bin(e, ((w.cur.bits >> (w.n - 1)) & 1u) << 1, c, st);
-    enc_flush(e, sink);
+    enc_bin_at_mem(e, SymBin{(w.cur.bits >> (w.n - 1)) & 1u}, st.addr(c), st);
+    // bytes leave at the reference's cadence (a write-out test per bin) when the statistics are wanted -- they are
+    // defined through getNumBits() -- and otherwise only when some lane still coding could overflow `low` with its next
+    // bins (W < 39 => W <= 62 after four more): the bytes are the same either way
+    if (want_stats) enc_flush(e, sink);
+    else if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);
     nbins++;
     if (hist) hist[c]++;
     if (cost) cost[c] += 8u * (sink.pos - before);
@@ -208,7 +251,8 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     if (!exact) {
       if ((it++ & 15u) == 0) src.boundary();
       if (d.sh < 8) dec_refill(d, src);
-      bin = dec_bin(d, c, st);
+      const uint32_t pair = dec_bin_at_mem(d, st.addr(c), st);  // bit 1 = mps, bit 0 = MPS path
+      bin = ((pair >> 1) ^ ~pair) & 1u;
     } else {
       bin = ref_dec_bin(r, c, st, rd);
     }
@@ -448,6 +492,14 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *p) {
   return m > 32 ? 0 : m;
 }
 
+// the symbol kernels read their tables by absolute LDS address: their dynamic LDS must start at 0
+static int sym_check_no_static_lds(isscabac_engine *e, const void *fn) {
+  hipFuncAttributes fa;
+  HIP_TRY(e, hipFuncGetAttributes(&fa, fn));
+  if (fa.sharedSizeBytes != 0) return engine_fail(e, ISSCABAC_ERR_HIP, "internal: symbol kernel has static LDS");
+  return ISSCABAC_OK;
+}
+
 int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
                                 uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
                                 uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes,
@@ -487,6 +539,7 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   a.nctx = (uint32_t)nctx;
   const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
   const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
+  if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
   hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
@@ -524,6 +577,7 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
   a.nctx = (uint32_t)nctx;
   const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
   const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
+  if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols)))) return rc;
   hipLaunchKernelGGL(k_decode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(e->stream));
