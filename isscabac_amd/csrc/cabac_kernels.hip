@@ -351,7 +351,6 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   EncStatesFor stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
-  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};
 
   EncCore e;
   enc_start(e);
@@ -414,34 +413,26 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             if ((k & 3) == 3) { e.W &= 15; }
 #endif
           }
-        } else if (full) {
-          // bypass bins (or contexts >= 128) somewhere in the wave.  The byte-table bin step works under any exec mask,
-          // so context-coded and bypass lanes simply take their own branch (both sides run when a wave mixes them:
-          // ~29 VALU per bin against ~37 for one combined, select-based step).
+        } else {
+          // bypass bins (or contexts >= 128) somewhere in the wave, or streams that end inside this chunk.  The byte-table
+          // bin step works under any exec mask, so every lane simply takes its own branch: context-coded bin, bypass bin,
+          // or nothing once its stream is over (all sides run when a wave mixes them: ~29 VALU per bin against ~37 for
+          // one combined, select-based step).
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-            if (byte_of(wc, k) != kBypass) {
-              if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-              else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-              else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-              else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-            } else {
-              enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
+            if (full || i0 + k < n) {
+              if (byte_of(wc, k) != kBypass) {
+                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+              } else {
+                enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
+              }
             }
             if ((k & 3) == 3 && wave_any(e.W >= 39)) ISSCABAC_FLUSH_FN(e, sink);
-          }
-        } else {
-          // ragged end: lanes drop out one by one, tables from LDS memory
-#pragma unroll 4
-          for (int k = 0; k < 16; k++) {
-            if (i0 + k < n) {
-              const uint32_t b1 = (word_of(wb, k >> 2) >> (8 * (k & 3))) << 1;
-              const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-              enc_bin_any(e, b1, cx, stm);
-            }
-            if ((k & 3) == 3) enc_flush16(e, sink);
           }
         }
       }
@@ -542,7 +533,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint64_t s = valid ? s0 + lane : a.S - 1;
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
-  const uint32_t nmin = wave_min_u32(n);
+  const uint32_t nmin = wave_min_u32(n), nmax = wave_max_u32(n);
 
   // doubled states q = m_ucState << 1, four per dword
   {
@@ -551,7 +542,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   StatesFor<true> stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
-  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};
+#ifdef ISSCABAC_DEC_XBAR
+  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};  // LDS copy of the dword tables for the ragged loop
+#endif
 
   // payload window
   const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
@@ -615,7 +608,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
         const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output tile
         uint32_t ob = 0;
-        const bool live = i0 < a.nbins;
+        const bool live = i0 < nmax;  // past the longest stream of the wave: zeros
 #ifndef ISSCABAC_ABL_NO_PAYLOAD
         if (live) src.boundary();
 #else
@@ -635,12 +628,16 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
           const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
-          if (full) {
-            // every lane decodes 16 bins: convergent, tables through the crossbar.  One bit-granular top-up per four
-            // bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs sh >= 7, a bypass bin takes 1 and
-            // needs sh >= 8, so three bins never run short and only the fourth is guarded (wave-uniform, practically
-            // never taken); the window is re-based at the chunk boundary and, wave-uniformly, whenever a lane has fewer
-            // than the 24 bits a top-up can take.  `hi` (wave-uniform) picks the bypass-capable step.
+#ifndef ISSCABAC_DEC_XBAR
+          {
+            // One bit-granular top-up per four bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs
+            // sh >= 7, a bypass bin takes 1 and needs sh >= 8, so three bins never run short and only the fourth is
+            // guarded (wave-uniform, practically never taken); the window is re-based at the chunk boundary and,
+            // wave-uniformly, whenever a lane has fewer than the 24 bits a top-up can take.  ob collects (mps, path)
+            // pairs, turned into bins after the chunk.  `plain` (wave-uniform): every lane decodes 16 context bins.
+            // Otherwise -- bypass bins in the chunk, or streams that end inside it -- every lane takes its own branch
+            // under the exec mask: context bin, bypass bin, or nothing (its output reads 0) once its stream is over.
+            const bool plain = full && !hi;
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #else
@@ -655,10 +652,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               const uint32_t cw = word_of(wc, g);
               dec_topup_nocheck(d, src);
               const CtxQuad z = stx.prep4(cw);
-#ifndef ISSCABAC_DEC_XBAR
-              // ob collects (mps, path) pairs here, turned into bins after the chunk.  With bypass bins in the chunk,
-              // context-coded and bypass lanes take their own branch (see k_encode).
-              if (!hi) {
+              if (plain) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 7);
@@ -668,13 +662,25 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 8);
-                  uint32_t w;
-                  if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                  else w = pair_of_bin(dec_bin_ep(d));
+                  uint32_t w = pair_of_bin(0u);
+                  if (full || i0 + 4 * g + k < n) {
+                    if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
+                    else w = pair_of_bin(dec_bin_ep(d));
+                  }
                   ob = collect_bin(ob, w);
                 }
               }
-#else  // tables through ds_bpermute and one combined step for chunks with bypass bins: 3 more VALU per bin
+            }
+            ob = pairs_to_bins(ob);
+          }
+#else  // tables through ds_bpermute (3 more VALU per bin), one combined step for chunks with bypass bins, and a per-bin
+       // guarded loop with LDS tables for ragged ends (bpermute cannot read inactive lanes)
+          if (full) {
+            for (int g = 0; g < 4; g++) {
+              if (g >= 2) src.ensure(24);
+              const uint32_t cw = word_of(wc, g);
+              dec_topup_nocheck(d, src);
+              const CtxQuad z = stx.prep4(cw);
               if (!hi) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -688,14 +694,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   ob = collect_bin(ob, dec_bin_any_b1(d, (cw >> (8 * k)) & 0xFFu, stx));
                 }
               }
-#endif
             }
-#ifndef ISSCABAC_DEC_XBAR
-            ob = pairs_to_bins(ob);
-#endif
           } else {
-            // ragged end: lanes drop out one by one, per-bin guard, tables from LDS memory (bpermute cannot read
-            // inactive lanes)
 #pragma unroll 1
             for (int k = 0; k < 16; k++) {
               uint32_t w = 0;
@@ -707,6 +707,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               ob = collect_bin(ob, w);
             }
           }
+#endif
         }
         obits[cidx * 64 + lane] = ob;
       }
