@@ -622,7 +622,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             wave_lds_sync();  // the bit tile is rewritten from here on
             have_out = false;
           }
-          if (h == 1 && t + 1 < nrounds) Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
+          if (h == 1 && t + 1 < nrounds && (t + 1) * Tile::T < nmax)  // nothing to decode past the wave's longest stream
+            Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
         }
         if (live) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
