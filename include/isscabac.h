@@ -19,7 +19,8 @@
  *     (the kernels address a wave's 64 rows with 32-bit offsets; one longer stream goes through a stream handle).
  *   - bins[i] is 0 or 1 (the reference's MEX refuses anything else, ref: CABAC/SimpleCABACMex.cpp:221-228); other
  *     values are not checked in the batch calls and give an unspecified (but memory-safe) result for that stream.
- *   - ctx[i] = context index 0..nctx-1, or ISSCABAC_BYPASS (0xFF) for an equiprobable bin
+ *   - ctx[i] = context index 0..nctx-1, or ISSCABAC_BYPASS (0xFF) for an equiprobable bin; any other value is
+ *     invalid: the result for that stream is unspecified, the other streams of the batch are not affected
  *     (ref: encodeBinEP, CABAC/CABAC_ArithmeticEncoder.cpp:250-270 -- not reachable through the
  *     reference MEX; additive).
  *   - ctx_init: nctx packed context states, byte = (state << 1) | mps, i.e. ContextModel::m_ucState

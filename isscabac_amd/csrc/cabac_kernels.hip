@@ -64,6 +64,15 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
   __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
 }
 
+// ctx bytes that the plain 16-bin path cannot take: bypass (0xFF), contexts >= 128 and, with the 4 KiB state image of
+// <= 64 contexts, anything >= 64 -- an out-of-range context index must not reach another stream's LDS.  Such chunks take
+// the general path, which looks at every byte and ignores an invalid one (that stream's result is unspecified, its
+// neighbours' are not affected).
+template <int CM>
+constexpr uint32_t not_plain_mask() { return CM == 1 ? 0xC0C0C0C0u : 0x80808080u; }
+template <int CM>
+__device__ __forceinline__ bool is_ctx_byte(uint32_t c) { return CM == 1 ? c < 64u : c != 0xFFu; }
+
 // waves per workgroup: 4, except with more than 64 contexts (16 KiB of states per wave): single-wave workgroups then let
 // 7 waves share a CU's LDS instead of 4
 constexpr int waves_per_block(int cm) { return cm == 2 ? 1 : 4; }
@@ -386,7 +395,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const uint4 wb = Tile::row_chunk(tile_b, lane, j);
         const uint4 wc = Tile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
-        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
+        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         if (full && !hi) {
           // every lane codes 16 context bins: convergent, tables through the crossbar
 #pragma unroll
@@ -423,12 +432,13 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
             if (full || i0 + k < n) {
-              if (byte_of(wc, k) != kBypass) {
+              const uint32_t cb = byte_of(wc, k);
+              if (is_ctx_byte<CM>(cb)) {
                 if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
                 else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
                 else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
                 else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-              } else {
+              } else if (cb == kBypass) {
                 enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
               }
             }
@@ -628,7 +638,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         if (live) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
-          const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & 0x80808080u) != 0);
+          const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
 #ifndef ISSCABAC_DEC_XBAR
           {
             // One bit-granular top-up per four bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs
@@ -665,8 +675,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   if (k == 3) dec_guard(d, src, 8);
                   uint32_t w = pair_of_bin(0u);
                   if (full || i0 + 4 * g + k < n) {
-                    if (((cw >> (8 * k)) & 0xFFu) != kBypass) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                    else w = pair_of_bin(dec_bin_ep(d));
+                    const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
+                    if (is_ctx_byte<CM>(cb)) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
+                    else if (cb == kBypass) w = pair_of_bin(dec_bin_ep(d));
                   }
                   ob = collect_bin(ob, w);
                 }

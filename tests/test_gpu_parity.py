@@ -546,3 +546,26 @@ def test_coder_front_end_mirrors_cabacEncode_cabacDecode(engine, oracle, tmp_pat
     bad[-1] ^= 0x80
     with pytest.raises(ValueError):
         coder.cabacDecode(Nq, param, ctx0, G.shape, engine=engine, payload=np.frombuffer(bytes(bad), np.uint8))
+
+
+def test_out_of_range_context_bytes_do_not_disturb_other_streams(engine, oracle):
+    """A ctx byte >= 64 in a batch declared with <= 64 contexts is invalid input; the stream that carries it gets an
+    unspecified result, every other stream of the batch must still be bit-exact."""
+    rng = np.random.default_rng(33)
+    S, B, C = 256, 700, 40
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    ctx = rng.integers(0, C, (S, B)).astype(np.uint8)
+    bins = rng.integers(0, 2, (S, B)).astype(np.uint8)
+    bad_rows = [5, 70, 131, 255]
+    dirty = ctx.copy()
+    for s in bad_rows:
+        dirty[s, rng.integers(0, B, 30)] = rng.integers(64, 255, 30)
+    want_p, want_o = oracle.encode_batch(bins, ctx, init)
+    got_p, got_o = engine.encode(bins, dirty, init)
+    for s in range(S):
+        if s not in bad_rows:
+            assert got_p[int(got_o[s]):int(got_o[s + 1])].tobytes() == want_p[int(want_o[s]):int(want_o[s + 1])].tobytes(), s
+    dec, status = engine.decode(want_p, want_o, dirty, init)
+    for s in range(S):
+        if s not in bad_rows:
+            assert status[s] == 0 and (dec[s] == bins[s]).all(), s
