@@ -557,8 +557,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
 
   // payload window
-  const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
-  const uint32_t len = (uint32_t)(end - start);
+  uint64_t start = a.offsets[s];
+  const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
   const uint64_t abase = start & ~3ull;
   const uint32_t skew = (uint32_t)(start - abase);
   WindowSrc<DevMem> src;
@@ -737,7 +737,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   }
   if (have_out) store_out(out_off);
   if (valid && a.status) {
-    const uint64_t first = a.offsets[s];  // re-read: keeping it live through the loop costs two registers
+    uint64_t first = a.offsets[s];  // re-read: keeping it live through the loop costs two registers
+    (void)clip_stream(first, first, a.payload_bytes);
     const uint32_t sk = (uint32_t)first & 3u;
     const uint8_t *p = a.payload + first;
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
@@ -759,8 +760,8 @@ struct PrivateStates {
 __global__ void __launch_bounds__(64) k_decode_exact(DecArgs a) {
   const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
-  const uint64_t start = a.offsets[s];
-  const uint32_t len = (uint32_t)(a.offsets[s + 1] - start);
+  uint64_t start = a.offsets[s];
+  const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
   if (len != 0 && !needs_ref_decoder(a.payload[start])) return;  // (an empty stream reads 0xFF at EOF)
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);

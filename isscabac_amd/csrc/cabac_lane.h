@@ -716,6 +716,15 @@ struct RefDec {
 };
 CABAC_HD bool needs_ref_decoder(uint32_t first_byte) { return first_byte == 0xFFu; }
 
+// a stream's payload [start, end) clipped to the payload buffer: offsets handed over in device memory are not validated
+// on the host, and no kernel may read outside the buffer whatever they say.  Returns the length, start is clipped too.
+CABAC_HD uint32_t clip_stream(uint64_t &start, uint64_t end, uint64_t payload_bytes) {
+  if (start > payload_bytes) start = payload_bytes;
+  if (end > payload_bytes) end = payload_bytes;
+  const uint64_t len = end > start ? end - start : 0;
+  return len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
+}
+
 template <class Rd>
 CABAC_HD void ref_dec_start(RefDec &r, Rd &rd) {  // ref: :54-71
   r.range = 510;

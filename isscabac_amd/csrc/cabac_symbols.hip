@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   SymStates st{wbase + lane * 4, tab};
   if (!valid) return;
   uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
-  const uint64_t start = a.offsets[s], end = a.offsets[s + 1];
-  const uint32_t len = (uint32_t)(end - start);
+  uint64_t start = a.offsets[s];
+  const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
   const uint64_t abase = start & ~3ull;
   const uint32_t skew = (uint32_t)(start - abase);
   WindowSrc<SymDevMem> src;

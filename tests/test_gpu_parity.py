@@ -569,3 +569,20 @@ def test_out_of_range_context_bytes_do_not_disturb_other_streams(engine, oracle)
     for s in range(S):
         if s not in bad_rows:
             assert status[s] == 0 and (dec[s] == bins[s]).all(), s
+
+
+def test_garbage_offsets_in_device_memory_are_clipped_not_followed(engine):
+    """the device-pointer decode call cannot validate offsets that live in device memory: whatever they say, the kernels
+    stay inside the payload buffer (streams clipped to it), flag the streams and return"""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S, B = 200, 256
+    ctx = torch.zeros((S, B), dtype=torch.uint8, device=dev)
+    payload = torch.randint(0, 256, (1000,), dtype=torch.uint8, device=dev)
+    offs = torch.randint(-(1 << 40), 1 << 40, (S + 1,), dtype=torch.int64, device=dev)
+    offs[::3] = torch.randint(0, 2000, (offs[::3].numel(),), dtype=torch.int64, device=dev)
+    out = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    status = torch.empty((S,), dtype=torch.int32, device=dev)
+    engine.decode_dev(payload.data_ptr(), payload.numel(), offs.data_ptr(), ctx.data_ptr(), S, B, B, np.zeros(1, np.uint8),
+                      out.data_ptr(), status.data_ptr())
+    assert int((status != 0).sum()) > S // 2 and int(out.max()) <= 1
