@@ -398,11 +398,21 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         if (full && !hi) {
           // every lane codes 16 context bins: convergent, tables through the crossbar
+          EncWordAcc acc;
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-#ifndef ISSCABAC_ENC_XBAR
+#if !defined(ISSCABAC_ENC_XBAR) && !defined(ISSCABAC_ENC_LOW_PER_BIN)
+            // `low` takes the word's four additions at once (EncWordAcc): one 64-bit shift + add per word, not per bin
+            if ((k & 3) == 0) enc_bin_at_mem_acc(e, acc, true, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_at_mem_acc(e, acc, false, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_at_mem_acc(e, acc, false, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+            else {
+              enc_bin_at_mem_acc(e, acc, false, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+              enc_word_close(e, acc);
+            }
+#elif !defined(ISSCABAC_ENC_XBAR)
             if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
             else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
             else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);

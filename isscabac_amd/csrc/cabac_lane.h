@@ -243,6 +243,36 @@ CABAC_HD void enc_bin_at_mem(EncCore &e, Bin bin, Addr at, States &st) {
   e.W += (int32_t)n;
 }
 
+// The additions four bins make to `low`, accumulated in 32 bits, so that the 64-bit `low` is shifted and added to once
+// per input word instead of once per bin (64-bit shifts and adds issue at half rate on CDNA4):
+//   ((((low + a0) << n0) + a1) << n1 ...) = (low << S) + T,   T = (((a0 << n0) + a1) << n1 ...),   S = n0 + n1 + n2 + n3.
+// a < 2^9, and a != 0 (LPS) implies n >= 1, so the non-zero terms of T sit at strictly decreasing shifts <= S and
+// T < 2^(S + 10).  S <= 22 for any four context bins: a 6-bit shift needs an LPS of 6 or 7 (states 61, 62 in columns 0, 1),
+// which leaves range = 384 or 448, columns 2 or 3, where every LPS is >= 8 -- so the worst run is 6,5,6,5 (exhaustive
+// search over range x state x path: tests/lane_harness.cpp: lane_max_shift_sum).  T is therefore exact in 32 bits.
+struct EncWordAcc {
+  uint32_t T, S;
+};
+// enc_bin_at_mem for one bin of an input word (first: the word's first bin): everything except `low` and W, which
+// enc_word_close updates
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_at_mem_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  st.store_at(at, st.next_mem(bin.or_q(q)));
+  const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
+  const uint32_t lps = st.lps_mem(q, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t n = clz32(r) - 23u;
+  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;  // v_add_lshl_u32
+  g.S = (first ? 0u : g.S) + n;
+  e.range = r << n;
+}
+CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
+  e.low = (e.low << g.S) + g.T;
+  e.W += (int32_t)g.S;
+}
+
 template <class States>
 CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   enc_bin_at(e, BinB1{b1}, st.addr(ctx), st);

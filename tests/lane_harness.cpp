@@ -89,7 +89,35 @@ struct HostMem {
 
 }  // namespace
 
+static uint32_t g_word_shift_max = 0;  // largest total shift of one input word seen by mode 18
+
 extern "C" {
+
+uint32_t lane_word_shift_max(void) { return g_word_shift_max; }
+
+// Largest total renormalisation shift of k consecutive context bins, over every start range, state (0..62) and path:
+// the bound behind EncWordAcc (k = 4 must give 22) and behind the 4-bin flush check of the batch encoder.
+uint32_t lane_max_shift_sum(int k) {
+  static uint32_t best[2][511];
+  for (uint32_t r = 256; r <= 510; r++) best[0][r] = 0;
+  int cur = 0;
+  for (int step = 0; step < k; step++, cur ^= 1) {
+    for (uint32_t r = 256; r <= 510; r++) {
+      uint32_t b = 0;
+      for (uint32_t state = 0; state <= 62; state++) {
+        const uint32_t lps = (kLpsRow[state] >> (8 * ((r >> 6) & 3u))) & 0xFFu, rmps = r - lps;
+        const uint32_t nl = clz32(lps) - 23u, nm = clz32(rmps) - 23u;
+        const uint32_t vl = nl + best[cur][lps << nl], vm = nm + best[cur][rmps << nm];
+        b = vl > b ? vl : b;
+        b = vm > b ? vm : b;
+      }
+      best[cur ^ 1][r] = b;
+    }
+  }
+  uint32_t m = 0;
+  for (uint32_t r = 256; r <= 510; r++) m = best[cur][r] > m ? best[cur][r] : m;
+  return m;
+}
 
 // flush_every: bins between enc_flush calls (1 = reference cadence, 4 = kernel cadence)
 // flush_every < 0: same cadence, but every bin goes through the combined enc_bin_any step
@@ -99,6 +127,9 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   if (any) flush_every = -flush_every;
   const bool quads = flush_every == 40;
   if (quads) flush_every = 4;
+  // 18: the kernel's plain path -- an aligned word of four context bins adds to `low` once (EncWordAcc / enc_word_close)
+  const bool wordacc = flush_every == 18;
+  if (wordacc) flush_every = 17;
   const bool memtab = flush_every == 17;  // ... with the kernel's byte-table bin step (enc_bin_at_mem)
   if (memtab) flush_every = 16;
   const bool digits16 = flush_every == 16;  // the batch kernel's output path: 16-bit digits, checked every 4 bins
@@ -119,6 +150,18 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
       if (e.W > mw) mw = e.W;
       i += 3;
       enc_flush(e, sink);
+      continue;
+    }
+    if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
+        ctx[i + 3] != kBypass) {
+      EncWordAcc acc;
+      for (int k = 0; k < 4; k++) enc_bin_at_mem_acc(e, acc, k == 0, HostBin{bins[i + k]}, st.addr(ctx[i + k]), st);
+      if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
+      enc_word_close(e, acc);
+      if (e.W > mw) mw = e.W;
+      i += 3;
+      if (e.W >= 39) enc_flush16_wave(e, sink);
+      if (e.W > 62) return -2;
       continue;
     }
     if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);

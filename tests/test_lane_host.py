@@ -29,6 +29,9 @@ def lane():
     L.lane_decode_stream.restype = C.c_uint32
     L.lane_decode_stream.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
                                      C.c_int, u8p, u8p, C.POINTER(C.c_uint32)]
+    L.lane_word_shift_max.restype = C.c_uint32
+    L.lane_max_shift_sum.restype = C.c_uint32
+    L.lane_max_shift_sum.argtypes = [C.c_int]
     L.sym_encode_stream.restype = C.c_long
     L.sym_encode_stream.argtypes = [u8p, C.c_uint32, C.POINTER(C.c_uint32), u8p, C.c_int, u8p, C.c_size_t,
                                     C.POINTER(C.c_uint32)]
@@ -67,13 +70,13 @@ def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
-@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40, 16, 17])
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 40, 16, 17, 18])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
         out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
         assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
-        assert mw <= (62 if flush_every in (16, 17) else 20 + 6 * min(abs(flush_every), 4) + 1)
+        assert mw <= (62 if flush_every in (16, 17, 18) else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
 @pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (5, 9, 40), (6, 2, 2), (1, 7, -2), (2, 6, 3)])
@@ -99,7 +102,7 @@ def test_fuzz_vs_oracle(lane, oracle):
         skew = rng.random(Cn + 1) ** (1 + it % 4)
         bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        got, fin, _ = lane_encode(lane, bins, ctx, init, (40, 4, 16, 17)[it % 4])
+        got, fin, _ = lane_encode(lane, bins, ctx, init, (40, 4, 16, 17, 18)[it % 5])
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
@@ -107,6 +110,28 @@ def test_fuzz_vs_oracle(lane, oracle):
         assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes()
         slow += cnt[2]
     assert slow > 0  # the in-chunk refill path was exercised
+
+
+def test_word_accumulator_bound(lane, oracle):
+    """The plain path adds a word's four bins to `low` at once from a 32-bit accumulator (EncWordAcc): exact because four
+    context bins never shift by more than 22 bits.  The bound is searched exhaustively on the product's own table, and the
+    worst words (LPS runs at states 58..62) are coded through that path and compared with the oracle."""
+    assert [lane.lane_max_shift_sum(k) for k in (1, 2, 3, 4)] == [6, 11, 17, 22]
+    rng = np.random.default_rng(5)
+    for it in range(60):
+        n = 64 * int(rng.integers(1, 9))
+        ctx = (np.arange(n) % 64).astype(np.uint8)
+        if it % 2:
+            ctx = rng.permutation(ctx)
+        init = (2 * rng.integers(58, 63, 64) + rng.integers(0, 2, 64)).astype(np.uint8)  # states 58..62, any mps
+        mps = init & 1
+        bins = (1 - mps[ctx]).astype(np.uint8)  # the first visit of every context is an LPS
+        flip = rng.random(n) < 0.1 * (it % 4)
+        bins[flip] ^= 1
+        want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
+        got, fin, mw = lane_encode(lane, bins, ctx, init, 18)
+        assert got.tobytes() == want.tobytes() and fin.tobytes() == want_fin.tobytes() and mw <= 62
+    assert lane.lane_word_shift_max() == 22  # the worst case was among them
 
 
 def test_all_lps_worst_case_width(lane, oracle, golden):
