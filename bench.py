@@ -210,20 +210,34 @@ def main():
 
     # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
     gather_ms = None
+    gather_hung = False
     if multi:
-        try:
-            from isscabac_amd import sharding
-            fence()
-            g0 = time.perf_counter()
-            p_all, o_all = sharding.gather_payload(payload[:total], offsets, dist)
-            fence()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            if rank == 0:
-                assert int(o_all[-1]) == p_all.numel() and o_all.numel() == world * S + 1
-            del p_all, o_all
-        except Exception as exc:  # the gather is reported apart from `value`; never let it take the run down
-            sys.stderr.write("bitstream gather failed: %r\n" % (exc,))
-            gather_ms = None
+        # runs on a helper thread under a deadline: a stuck exchange must cost the run its gather_ms, not its result line
+        import threading
+        box = {}
+
+        def do_gather():
+            try:
+                from isscabac_amd import sharding
+                torch.cuda.set_device(local_rank)  # the current device is per thread
+                fence()
+                g0 = time.perf_counter()
+                p_all, o_all = sharding.gather_payload(payload[:total], offsets, dist)
+                fence()
+                box["ms"] = (time.perf_counter() - g0) * 1e3
+                if rank == 0:
+                    assert int(o_all[-1]) == p_all.numel() and o_all.numel() == world * S + 1
+                del p_all, o_all
+            except Exception as exc:  # the gather is reported apart from `value`; never let it take the run down
+                sys.stderr.write("bitstream gather failed: %r\n" % (exc,))
+
+        th = threading.Thread(target=do_gather, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("ISSCABAC_GATHER_DEADLINE_S", "120")))
+        gather_hung = th.is_alive()
+        if gather_hung:
+            sys.stderr.write("bitstream gather did not finish before its deadline (rank %d)\n" % rank)
+        gather_ms = box.get("ms")
 
     if rank == 0:
         bins_total = float(S) * B * world * args.steps
@@ -283,6 +297,9 @@ def main():
         elif args.cpu_seconds > 0:
             line["cpu_baseline"] = None
         print(json.dumps(line))
+    if gather_hung:
+        sys.stdout.flush()
+        os._exit(0)  # the exchange is stuck inside the process group: leave without waiting for it
     if multi:
         dist.destroy_process_group()
 
