@@ -586,3 +586,41 @@ def test_garbage_offsets_in_device_memory_are_clipped_not_followed(engine):
     engine.decode_dev(payload.data_ptr(), payload.numel(), offs.data_ptr(), ctx.data_ptr(), S, B, B, np.zeros(1, np.uint8),
                       out.data_ptr(), status.data_ptr())
     assert int((status != 0).sum()) > S // 2 and int(out.max()) <= 1
+
+
+def test_distinct_engines_on_distinct_host_threads(oracle):
+    """SURVEY 8(b) threading: a handle is not thread-safe, but distinct handles may be driven from distinct host threads
+    at the same time (own stream, own scratch).  Four threads, each with its own engine and its own batches."""
+    import threading
+    from isscabac_amd import Engine
+    errors = []
+
+    def worker(tid):
+        try:
+            eng = Engine(0)
+            rng = np.random.default_rng(1000 + tid)
+            for it in range(6):
+                S, B, C = int(rng.integers(65, 700)), 16 * int(rng.integers(1, 40)), int(rng.choice([3, 23, 64, 200]))
+                ctx = rng.integers(0, C, (S, B), dtype=np.uint8)
+                if it % 2:
+                    ctx[rng.random((S, B)) < 0.3] = 0xFF
+                bins = (rng.random((S, B)) < rng.random(C + 1)[np.where(ctx == 0xFF, C, ctx)]).astype(np.uint8)
+                init = rng.integers(0, 126, C).astype(np.uint8)
+                nb = rng.integers(0, B + 1, S).astype(np.uint32)
+                payload, offsets = eng.encode(bins, ctx, init, nbins=nb)
+                want_p, want_o = oracle.encode_batch(bins, ctx, init, nbins=nb)
+                assert (offsets == want_o).all() and payload.tobytes() == want_p.tobytes()
+                dec, status = eng.decode(payload, offsets, ctx, init, nbins=nb)
+                assert (status == 0).all()
+                for s in range(S):
+                    assert (dec[s, :nb[s]] == bins[s, :nb[s]]).all()
+            eng.close()
+        except BaseException as exc:  # noqa: BLE001 - reported by the main thread
+            errors.append((tid, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
