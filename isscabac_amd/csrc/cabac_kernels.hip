@@ -71,11 +71,11 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
 template <int CM>
 constexpr uint32_t not_plain_mask() { return CM == 1 ? 0xC0C0C0C0u : 0x80808080u; }
 template <int CM>
-__device__ __forceinline__ bool is_ctx_byte(uint32_t c) { return CM == 1 ? c < 64u : c != 0xFFu; }
+__device__ __forceinline__ bool is_ctx_byte(uint32_t c) { return CM == 1 ? c < 64u : CM == 3 ? c < 128u : c != 0xFFu; }
 
-// waves per workgroup: 4, except with more than 64 contexts (16 KiB of states per wave): single-wave workgroups then let
-// 7 waves share a CU's LDS instead of 4
-constexpr int waves_per_block(int cm) { return cm == 2 ? 1 : 4; }
+// waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
+// let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
+constexpr int waves_per_block(int cm) { return cm == 1 ? 4 : 1; }
 constexpr int kTabBytes = 1280;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
                                  // entries, [768,1024) successor bytes by (packed state, bin), [1024,1280) by (.., path)
 constexpr int kTab16Off = 512, kTabBinOff = 768, kTabPathOff = 1024;
@@ -309,7 +309,7 @@ struct EncArgs {
 // LDS bytes of one wave: context states, two half tiles, (encoder) the output staging
 template <int CM>
 struct WaveLds {
-  static constexpr uint32_t SB = CM == 1 ? 4096u : 16384u;  // CM 1: <= 64 contexts, CM 2: <= 255
+  static constexpr uint32_t SB = CM == 1 ? 4096u : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE;
@@ -1012,6 +1012,7 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
 #define ISSCABAC_DISPATCH(FN, ARGS)             \
   do {                                          \
     if (sh.nctx <= 64) return FN<1>(ARGS, stream); \
+    if (sh.nctx <= 128) return FN<3>(ARGS, stream); \
     return FN<2>(ARGS, stream);                 \
   } while (0)
 

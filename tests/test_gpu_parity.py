@@ -65,6 +65,8 @@ def test_golden_streams_as_one_ragged_batch(engine, golden, oracle):
     (2048, 4096, 64, 0xCABAC003, False),        # config 3 shape
     (1024, 8192, 64, 0xCABAC005, True),         # config 5 shape, 50% bypass
     (300, 1000, 255, 0x1234, False),            # 255 contexts -> big LDS state variant, B % 16 != 0
+    (333, 2000, 100, 0x4321, False),            # 65..128 contexts -> the 8 KiB state variant
+    (130, 500, 128, 0x99, True),
     (65, 40, 4, 0x77, False),
     (1, 16, 1, 0x5, False),
 ])
@@ -90,7 +92,7 @@ def test_golden_synthetic_payloads(engine, golden, oracle):
 
 def test_ragged_random_lengths_and_inits(engine, oracle):
     rng = np.random.default_rng(42)
-    for C, B in [(3, 700), (64, 1500), (200, 333)]:
+    for C, B in [(3, 700), (64, 1500), (200, 333), (97, 450)]:
         S = 257
         init = rng.integers(0, 126, C).astype(np.uint8)
         ctx = rng.integers(0, C, (S, B)).astype(np.uint8)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel-only round-trip rate for different context counts (which select the <=4 / <=64 / >64 context kernels)."""
+"""Kernel-only round-trip rate for different context counts (which select the <= 64 / <= 128 / <= 255 context kernels)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +12,7 @@ cap = S * 1100
 payload = torch.empty(cap, dtype=torch.uint8, device=dev); offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
 out = torch.empty((S, B), dtype=torch.uint8, device=dev); status = torch.empty((S,), dtype=torch.int32, device=dev)
 eng.set_profiling(True)
-for C, mul in ((3, 1), (4, 1), (64, 1), (190, 3)):
+for C, mul in ((3, 1), (4, 1), (64, 1), (127, 2), (190, 3)):
     eng.synth_dev(0xCABAC003, 0, S, B, B, 3 if C == 3 else (64 if C > 4 else 64), False, bins.data_ptr(), ctx.data_ptr())
     if C == 4:
         ctx.bitwise_and_(3)
