@@ -211,18 +211,9 @@ struct LdsStates {
   __device__ __forceinline__ void store_at(lds_u8 *a, uint32_t p) const { *a = (uint8_t)p; }
   __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
-#ifdef ISSCABAC_ABL_NO_STATE_LDS
-  __device__ __forceinline__ uint32_t load(uint32_t c) const { return (c * 37u) & 0xFCu; }
-  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { asm volatile("" ::"v"(c), "v"(p)); }
-#else
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
-#endif
   // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
-#ifdef ISSCABAC_ABL_NO_BPERM
-  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return row_tab ^ (q * 0x01010101u & 0x0F0F0F0Fu) | 0x10101010u; }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return next_tab + q; }
-#else
   __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
   }
@@ -234,7 +225,6 @@ struct LdsStates {
     if (NEXT16) return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(kTab16Off + q));
     return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
   }
-#endif
   // byte-table lookups by absolute LDS address (see next_entry): the rangeTabLps rows at LDS 0 are a [state][column]
   // byte table, and the 16-bit next-state table is a [packed state][lps] byte table
   __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
@@ -243,9 +233,6 @@ struct LdsStates {
   // successor bytes by [packed state][path], path 0 = LPS, 1 = MPS
   __device__ __forceinline__ uint32_t path_index(uint32_t q) const { return kTabPathOff + q; }  // = the LDS address
   __device__ __forceinline__ uint32_t next_path_mem(uint32_t addr) const {
-#ifdef ISSCABAC_ABL_NO_NEXTMEM
-    return addr & 0xFEu;  // timing only: no successor lookup, the state never moves
-#endif
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)addr);
   }
   __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
