@@ -112,6 +112,26 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
                               const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out,
                               uint32_t *d_status);
 
+/* ---- the same two calls without the host in the loop ---------------------------------------------------
+ * The *_async forms only enqueue work on the engine's stream and return: nothing is read back, the host does not wait.
+ * A caller that chains encode -> decode (or many batches) keeps the GPU busy back to back, independent of host wake-up
+ * latency.  isscabac_sync waits for everything enqueued so far and reports what the synchronous forms report at once:
+ *   - *total_bytes (may be NULL) = offsets[S] of the most recent encode; ISSCABAC_ERR_CAPACITY if that exceeded its
+ *     payload_cap (streams that did not fit were skipped by the gather, the offsets are complete);
+ *   - decode: payload_bytes may be any upper bound of offsets[S] that the buffer really has (e.g. its capacity) --
+ *     it only bounds memory accesses; streams are delimited by d_offsets.
+ * Buffers must stay valid until isscabac_sync (or another synchronising call on this engine) has returned.  The
+ * synchronous forms above are the async form + isscabac_sync. */
+int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx,
+                                    const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                    const uint8_t *ctx_init, int nctx, uint8_t *d_payload,
+                                    uint64_t payload_cap, uint64_t *d_offsets);
+int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
+                                    const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins,
+                                    uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                    uint8_t *d_bins_out, uint32_t *d_status);
+int isscabac_sync(isscabac_engine *e, uint64_t *total_bytes);
+
 /* ---- batch coding on host buffers (what a MEX / FFI caller holding host arrays uses) --------------
  * same semantics; the engine stages through its own device buffers (H2D, kernels, D2H).
  * payload_cap in bytes; on ISSCABAC_ERR_CAPACITY nothing is written but *total_bytes is set. */
@@ -248,7 +268,10 @@ int isscabac_stream_decode_finish(isscabac_stream *s, uint32_t *status);
 int isscabac_set_profiling(isscabac_engine *e, int enabled);
 /* kernel times of the last batch call in ms: [0] encode kernel, [1] offsets scan, [2] payload gather,
  * [3] decode kernel; unused entries are 0 */
-int isscabac_last_kernel_ms(const isscabac_engine *e, float ms[4]);
+int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]);
+/* mean kernel times (same four slots) over the batch calls since the previous call of this function, and how many
+ * launches each mean covers; waits for the enqueued work first.  Up to 128 calls are kept between reads (a full ring is read out early, which waits for the stream). */
+int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4]);
 
 /* synthetic workload generator of SURVEY.md section 8(d) (counter based, identical to
  * oracle/cabac_oracle.c:orc_synth_fill), filling device buffers for global streams s0 .. s0+S-1 */

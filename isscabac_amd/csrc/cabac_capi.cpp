@@ -77,8 +77,12 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->flag) (void)hipFree(e->flag);
   for (void *p : e->stage)
     if (p) (void)hipFree(p);
-  if (e->ev_ready)
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->prof) {
+    for (int i = 0; i < isscabac_engine::kProfRing; i++)
+      for (hipEvent_t ev : e->prof[i].ev) (void)hipEventDestroy(ev);
+    delete[] e->prof;
+  }
+  if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -154,24 +158,64 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
 
 static bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
-static int prof_begin(isscabac_engine *e) {
-  if (!e->profiling) return ISSCABAC_OK;
-  if (!e->ev_ready) {
-    for (hipEvent_t &ev : e->ev) HIP_TRY(e, hipEventCreate(&ev));
-    e->ev_ready = true;
+// ---- profiling: one event set per batch call, read back only at synchronisation points ---------------------------
+// read the recorded-but-unread slots (everything enqueued has completed: the caller synchronised the stream)
+static int prof_drain(isscabac_engine *e) {
+  while (e->prof_count > 0) {
+    const int i = (e->prof_head - e->prof_count + isscabac_engine::kProfRing) % isscabac_engine::kProfRing;
+    isscabac_engine::ProfSlot &p = e->prof[i];
+    float ms = 0;
+    if (p.kind == 0) {
+      for (int k = 0; k < 3; k++) {
+        HIP_TRY(e, hipEventElapsedTime(&ms, p.ev[k], p.ev[k + 1]));
+        e->last_ms[k] = ms;
+        e->sum_ms[k] += ms;
+        e->sum_n[k]++;
+      }
+    } else {
+      HIP_TRY(e, hipEventElapsedTime(&ms, p.ev[0], p.ev[1]));
+      e->last_ms[3] = ms;
+      e->sum_ms[3] += ms;
+      e->sum_n[3]++;
+    }
+    e->prof_count--;
   }
-  for (float &m : e->last_ms) m = 0;
   return ISSCABAC_OK;
 }
-#define PROF_MARK(e, i)                                           \
-  do {                                                            \
-    if ((e)->profiling) HIP_TRY(e, hipEventRecord((e)->ev[i], (e)->stream)); \
+// next slot of the ring (nullptr when profiling is off); a full ring is read out first, which waits for the stream
+static int prof_slot(isscabac_engine *e, int kind, isscabac_engine::ProfSlot **out) {
+  *out = nullptr;
+  if (!e->profiling) return ISSCABAC_OK;
+  if (!e->prof) {
+    e->prof = new isscabac_engine::ProfSlot[isscabac_engine::kProfRing]();
+    for (int i = 0; i < isscabac_engine::kProfRing; i++)
+      for (hipEvent_t &ev : e->prof[i].ev) HIP_TRY(e, hipEventCreate(&ev));
+  }
+  if (e->prof_count == isscabac_engine::kProfRing) {
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const int rc = prof_drain(e);
+    if (rc) return rc;
+  }
+  *out = &e->prof[e->prof_head];
+  (*out)->kind = kind;
+  e->prof_head = (e->prof_head + 1) % isscabac_engine::kProfRing;
+  e->prof_count++;
+  return ISSCABAC_OK;
+}
+#define PROF_MARK(e, slot, i)                                                   \
+  do {                                                                          \
+    if (slot) HIP_TRY(e, hipEventRecord((slot)->ev[i], (e)->stream));           \
   } while (0)
+// wait for everything enqueued on the engine's stream, then collect what became readable
+static int engine_sync(isscabac_engine *e) {
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return e->prof_count ? prof_drain(e) : ISSCABAC_OK;
+}
 
 // ---- batch encode, device buffers ---------------------------------------------------------------------
-int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
-                              uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
-                              uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes) {
+int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
+                                    uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                    uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets) {
   BatchShape sh;
   int rc = check_shape(e, "isscabac_encode_batch_dev", S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
@@ -179,36 +223,55 @@ int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const u
   if (misaligned(d_bins) || misaligned(d_ctx)) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch_dev: bins/ctx must be 16-byte aligned");
   HIP_TRY(e, hipSetDevice(e->device));
   const uint64_t stride = slot_stride_for(nbins);
+  // (growing the scratch frees the old one, which waits for the device: only the first call of a size pays that)
   if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
-  if ((rc = prof_begin(e))) return rc;
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  isscabac_engine::ProfSlot *ps;
+  if ((rc = prof_slot(e, 0, &ps))) return rc;
 
-  PROF_MARK(e, 0);
+  PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
-  PROF_MARK(e, 1);
+  PROF_MARK(e, ps, 1);
   HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
-  PROF_MARK(e, 2);
+  PROF_MARK(e, ps, 2);
   HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
-  PROF_MARK(e, 3);
-  uint64_t total = 0;
-  HIP_TRY(e, hipMemcpyAsync(&total, d_offsets + S, sizeof total, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (e->profiling) {
-    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[0], e->ev[0], e->ev[1]));
-    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[1], e->ev[1], e->ev[2]));
-    HIP_TRY(e, hipEventElapsedTime(&e->last_ms[2], e->ev[2], e->ev[3]));
-  }
-  if (total_bytes) *total_bytes = total;
-  if (total > payload_cap)
-    return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch_dev: payload needs %llu bytes, capacity is %llu",
-                (unsigned long long)total, (unsigned long long)payload_cap);
+  PROF_MARK(e, ps, 3);
+  HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  e->pending_total = true;
+  e->pending_cap = payload_cap;
   return ISSCABAC_OK;
 }
 
-int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
-                              const uint8_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
-                              const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out, uint32_t *d_status) {
+int isscabac_sync(isscabac_engine *e, uint64_t *total_bytes) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int rc = engine_sync(e);
+  if (rc) return rc;
+  if (e->pending_total) {
+    e->pending_total = false;
+    const uint64_t total = *e->h_total;
+    if (total_bytes) *total_bytes = total;
+    if (total > e->pending_cap)
+      return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch_dev: payload needs %llu bytes, capacity is %llu",
+                  (unsigned long long)total, (unsigned long long)e->pending_cap);
+  }
+  return ISSCABAC_OK;
+}
+
+int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
+                              uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                              uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes) {
+  const int rc = isscabac_encode_batch_dev_async(e, d_bins, d_ctx, d_nbins, S, nbins, pitch, ctx_init, nctx, d_payload,
+                                                 payload_cap, d_offsets);
+  return rc ? rc : isscabac_sync(e, total_bytes);
+}
+
+int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
+                                    const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint64_t S,
+                                    uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out,
+                                    uint32_t *d_status) {
   BatchShape sh;
   int rc = check_shape(e, "isscabac_decode_batch_dev", S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
@@ -217,22 +280,28 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
   HIP_TRY(e, hipSetDevice(e->device));
   if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
-  if ((rc = prof_begin(e))) return rc;
+  isscabac_engine::ProfSlot *ps;
+  if ((rc = prof_slot(e, 1, &ps))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
-  PROF_MARK(e, 0);
+  PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag, e->stream));
-  PROF_MARK(e, 1);
-  uint32_t need_exact = 0;
-  HIP_TRY(e, hipMemcpyAsync(&need_exact, e->flag, sizeof need_exact, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (e->profiling) HIP_TRY(e, hipEventElapsedTime(&e->last_ms[3], e->ev[0], e->ev[1]));
-  if (need_exact) {
-    // some stream starts with 0xFF (corrupt input): the reference's value register overflows on those, and only its own
-    // formulation reproduces what it then decodes (cabac_lane.h: RefDec).  One thread per such stream, rare and slow.
-    HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
-  }
+  PROF_MARK(e, ps, 1);
+  // streams that start with 0xFF (corrupt input): the reference's value register overflows on those, and only its own
+  // formulation reproduces what it then decodes (cabac_lane.h: RefDec).  The kernel looks at the flag the decode kernel
+  // left on the device and returns at once when it is clear, so the host never has to read it.
+  HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag,
+                                 e->stream));
   return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                              const uint8_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                              const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out, uint32_t *d_status) {
+  const int rc = isscabac_decode_batch_dev_async(e, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, S, nbins, pitch,
+                                                 ctx_init, nctx, d_bins_out, d_status);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  return engine_sync(e);
 }
 
 // ---- batch coding, host buffers -----------------------------------------------------------------------
@@ -313,9 +382,30 @@ int isscabac_set_profiling(isscabac_engine *e, int enabled) {
   return ISSCABAC_OK;
 }
 
-int isscabac_last_kernel_ms(const isscabac_engine *e, float ms[4]) {
+int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]) {
   if (!e || !ms) return ISSCABAC_ERR_ARG;
+  if (e->prof_count) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int rc = engine_sync(e);
+    if (rc) return rc;
+  }
   for (int i = 0; i < 4; i++) ms[i] = e->last_ms[i];
+  return ISSCABAC_OK;
+}
+
+int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4]) {
+  if (!e || !ms) return ISSCABAC_ERR_ARG;
+  if (e->prof_count) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int rc = engine_sync(e);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < 4; i++) {
+    ms[i] = e->sum_n[i] ? (float)(e->sum_ms[i] / e->sum_n[i]) : 0.f;
+    if (launches) launches[i] = e->sum_n[i];
+    e->sum_ms[i] = 0;
+    e->sum_n[i] = 0;
+  }
   return ISSCABAC_OK;
 }
 

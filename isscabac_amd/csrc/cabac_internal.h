@@ -27,11 +27,22 @@ struct isscabac_engine {
   // staging for the host-buffer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
-  // profiling
+  // what isscabac_sync has to report about the most recent (async) encode
+  uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]
+  uint64_t pending_cap = 0;
+  bool pending_total = false;
+  // profiling: a ring of event sets, one per batch call, read back at synchronisation points
+  static constexpr int kProfRing = 128;
+  struct ProfSlot {
+    hipEvent_t ev[4];
+    int kind;  // 0 encode (ev 0..3: start, kernel end, scan end, gather end), 1 decode (ev 0..1)
+  };
   bool profiling = false;
-  hipEvent_t ev[8] = {};
-  bool ev_ready = false;
+  ProfSlot *prof = nullptr;  // kProfRing slots, created on first use
+  int prof_head = 0, prof_count = 0;  // next slot to record into, recorded-but-unread slots
   float last_ms[4] = {0, 0, 0, 0};
+  double sum_ms[4] = {0, 0, 0, 0};
+  uint32_t sum_n[4] = {0, 0, 0, 0};
 };
 
 
@@ -70,15 +81,16 @@ hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, 
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,
                          uint64_t S, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 // decode: payload/offsets/ctx -> bins (+status)
-// *d_flag (zeroed by the caller) is set when a stream starts with 0xFF: such streams (corrupt input only) must be
-// decoded again with launch_decode_exact to reproduce the reference's 32-bit register wrap-around
+// *d_flag (zeroed by the caller) is set when a stream starts with 0xFF: such streams (corrupt input only) are
+// decoded again by launch_decode_exact to reproduce the reference's 32-bit register wrap-around
 hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
                          const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out, uint32_t *d_status,
                          uint32_t *d_flag, hipStream_t stream);
-// one thread per stream, reference formulation (cabac_lane.h: RefDec); touches only streams that start with 0xFF
+// one thread per stream, reference formulation (cabac_lane.h: RefDec); touches only streams that start with 0xFF, and
+// returns at once when *d_flag (written by launch_decode on the same stream) is 0
 hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
                                const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
-                               uint32_t *d_status, hipStream_t stream);
+                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream);
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);

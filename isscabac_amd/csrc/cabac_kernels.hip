@@ -755,6 +755,7 @@ struct PrivateStates {
 };
 
 __global__ void __launch_bounds__(64) k_decode_exact(DecArgs a) {
+  if (a.exact_flag && *a.exact_flag == 0u) return;  // k_decode saw no such stream: the usual case, a few microseconds
   const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
   uint64_t start = a.offsets[s];
@@ -1040,9 +1041,10 @@ static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_pay
 
 hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
                                const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
-                               uint32_t *d_status, hipStream_t stream) {
+                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream) {
   DecArgs a;
-  fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, nullptr);
+  fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status,
+                const_cast<uint32_t *>(d_flag));
   hipLaunchKernelGGL(k_decode_exact, dim3((unsigned)((sh.S + 63) / 64)), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

@@ -93,6 +93,11 @@ def _load():
                                             _vp, C.c_uint64, _vp, _u64p]
     L.isscabac_decode_batch_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
                                             _u8p, C.c_int, _vp, _vp]
+    L.isscabac_encode_batch_dev_async.argtypes = [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                                  _vp, C.c_uint64, _vp]
+    L.isscabac_decode_batch_dev_async.argtypes = L.isscabac_decode_batch_dev.argtypes
+    L.isscabac_sync.argtypes = [_vp, _u64p]
+    L.isscabac_kernel_ms_mean.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.isscabac_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
                                         _u8p, C.c_uint64, _u64p, _u64p]
     L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
@@ -209,7 +214,37 @@ class Engine:
         self._check(self._L.isscabac_last_kernel_ms(self._h, ms))
         return dict(encode=ms[0], scan=ms[1], gather=ms[2], decode=ms[3])
 
+    def kernel_ms_mean(self):
+        """Mean kernel times over the batch calls since the previous call of this method (waits for the stream first):
+        ({'encode','scan','gather','decode'} in ms, the same keys -> number of launches averaged)."""
+        ms, n = (C.c_float * 4)(), (C.c_uint32 * 4)()
+        self._check(self._L.isscabac_kernel_ms_mean(self._h, ms, n))
+        keys = ("encode", "scan", "gather", "decode")
+        return {k: ms[i] for i, k in enumerate(keys)}, {k: int(n[i]) for i, k in enumerate(keys)}
+
     # ---- device-buffer hot path ------------------------------------------------------------------------
+    def encode_dev_async(self, d_bins, d_ctx, S, nbins, pitch, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0):
+        """Enqueue only (no host wait, nothing read back): sync() reports the total and a capacity overflow."""
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_encode_batch_dev_async(self._h, _vp(d_bins), _vp(d_ctx), _vp(d_nbins or 0), int(S),
+                                                            int(nbins), int(pitch), _ptr(ci, _u8p), ci.size,
+                                                            _vp(d_payload), int(payload_cap), _vp(d_offsets)))
+
+    def decode_dev_async(self, d_payload, payload_bytes, d_offsets, d_ctx, S, nbins, pitch, ctx_init, d_bins_out,
+                         d_status=0, d_nbins=0):
+        """Enqueue only.  payload_bytes: offsets[S], or any upper bound of it the buffer really has (its capacity)."""
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_decode_batch_dev_async(self._h, _vp(d_payload), int(payload_bytes), _vp(d_offsets),
+                                                            _vp(d_ctx), _vp(d_nbins or 0), int(S), int(nbins),
+                                                            int(pitch), _ptr(ci, _u8p), ci.size, _vp(d_bins_out),
+                                                            _vp(d_status or 0)))
+
+    def sync(self):
+        """Wait for everything enqueued; returns the payload size of the most recent encode."""
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_sync(self._h, C.byref(total)))
+        return int(total.value)
+
     def encode_dev(self, d_bins, d_ctx, S, nbins, pitch, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0):
         ci = _np(ctx_init, np.uint8)
         total = C.c_uint64(0)

@@ -626,3 +626,69 @@ def test_distinct_engines_on_distinct_host_threads(oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_async_entry_points_chain_without_the_host(engine, oracle):
+    """isscabac_*_batch_dev_async + isscabac_sync: several encode -> decode rounds are enqueued with no host wait in
+    between (the decoder gets the payload buffer's capacity, not the size of the payload); results, the total reported at
+    sync, the 0xFF-led streams (redone on the device without a host round trip) and the deferred capacity error all
+    match the synchronous calls.  Kernel times come out of the event ring, one set per call."""
+    import isscabac_amd
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    S, B, C = 700, 1024, 64
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    cap = S * ((6 * B + 9 + 7) // 8)
+    engine.set_profiling(True)
+    engine.kernel_ms_mean()
+    batches = []
+    for r in range(3):
+        ctx = rng.integers(0, C, (S, B)).astype(np.uint8)
+        if r == 1:
+            ctx[rng.random((S, B)) < 0.2] = 0xFF
+        bins = (rng.random((S, B)) < 0.3).astype(np.uint8)
+        b = dict(bins=bins, ctx=ctx, d_bins=torch.from_numpy(bins).to(dev), d_ctx=torch.from_numpy(ctx).to(dev),
+                 payload=torch.zeros(cap, dtype=torch.uint8, device=dev),
+                 offsets=torch.empty(S + 1, dtype=torch.int64, device=dev),
+                 out=torch.full((S, B), 7, dtype=torch.uint8, device=dev),
+                 status=torch.full((S,), 9, dtype=torch.int32, device=dev))
+        batches.append(b)
+    torch.cuda.synchronize()
+    for b in batches:  # nothing below waits for the GPU
+        engine.encode_dev_async(b["d_bins"].data_ptr(), b["d_ctx"].data_ptr(), S, B, B, init, b["payload"].data_ptr(), cap,
+                                b["offsets"].data_ptr())
+        engine.decode_dev_async(b["payload"].data_ptr(), cap, b["offsets"].data_ptr(), b["d_ctx"].data_ptr(), S, B, B, init,
+                                b["out"].data_ptr(), b["status"].data_ptr())
+    total = engine.sync()
+    ms, n = engine.kernel_ms_mean()
+    assert n == dict(encode=3, scan=3, gather=3, decode=3) and all(v > 0 for v in ms.values())
+    for i, b in enumerate(batches):
+        want_p, want_o = oracle.encode_batch(b["bins"], b["ctx"], init)
+        assert (b["offsets"].cpu().numpy().astype(np.uint64) == want_o).all()
+        assert b["payload"][:want_p.size].cpu().numpy().tobytes() == want_p.tobytes()
+        assert torch.equal(b["out"], b["d_bins"]) and int(b["status"].abs().sum()) == 0
+        if i == 2:
+            assert total == want_p.size
+    # corrupt first bytes: the exact decoder runs behind the decode kernel on the device, no flag is read by the host
+    b = batches[0]
+    want_p, want_o = oracle.encode_batch(b["bins"], b["ctx"], init)
+    bad = want_p.copy()
+    for s in range(0, S, 5):
+        bad[int(want_o[s])] = 0xFF
+    d_bad = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_bad[:bad.size] = torch.from_numpy(bad).to(dev)
+    engine.decode_dev_async(d_bad.data_ptr(), cap, b["offsets"].data_ptr(), b["d_ctx"].data_ptr(), S, B, B, init,
+                            b["out"].data_ptr(), b["status"].data_ptr())
+    engine.sync()
+    want_bins, want_status = oracle.decode_batch(bad, want_o, b["ctx"], init)
+    assert (b["status"].cpu().numpy().astype(np.uint32) == want_status).all() and (want_status[::5] != 0).any()
+    assert (b["out"].cpu().numpy() == want_bins).all()
+    # a payload buffer that is too small: reported by sync, with the size that was needed
+    engine.encode_dev_async(b["d_bins"].data_ptr(), b["d_ctx"].data_ptr(), S, B, B, init, b["payload"].data_ptr(), 1000,
+                            b["offsets"].data_ptr())
+    with pytest.raises(isscabac_amd.EngineError) as ei:
+        engine.sync()
+    assert ei.value.code == 4 and str(want_p.size) in str(ei.value)
+    engine.sync()  # the error is reported once
+    engine.set_profiling(False)
