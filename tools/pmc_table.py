@@ -4,7 +4,7 @@ import json, subprocess, sys
 d = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py", sys.argv[1]]))
 steps = 16384 * 4096
 for k, x in d.items():
-    if "encode" in k or "decode" in k:
+    if k.startswith(("k_encode<", "k_decode<")):  # the coder kernels proper (not k_decode_exact: returns at once)
         g = lambda n: x.get(n, float("nan"))
         print("%-14s FETCH %.2f GB WRITE %.2f GB | per wave-bin: VALU %.1f SALU %.1f LDS %.2f | LDS conflict %.0f%% | "
               "wave cyc/bin %.0f active %.0f%% wait_any %.0f%% wait_inst %.0f%% | waves/SIMD avg %.2f" % (

@@ -12,7 +12,7 @@ d = json.load(open(src + "/pmc_summary.json"))
 t = json.load(open("profiles/pmc_traffic.json"))
 for k, x in d.items():
     for name in ("k_decode", "k_encode"):
-        if name in k:
+        if k.startswith(name + "<"):
             f, w = x["FETCH_SIZE"] * 1024, x["WRITE_SIZE"] * 1024
             t["config3"][name].update(fetch_bytes=f, write_bytes=w, hbm_bytes_per_launch=f + w)
 json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
