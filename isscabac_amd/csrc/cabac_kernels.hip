@@ -657,7 +657,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #else
               src.cend = src.bpos + 64u;
 #endif
-              const uint32_t cw = word_of(wc, g);
+              // the word comes from LDS again rather than out of wc: picking one of four registers by the loop counter
+              // costs the rolled loop a chain of scalar branches (1% of the kernel)
+              const uint32_t cw = *reinterpret_cast<const uint32_t *>(tile_c + Tile::lds_off(lane, j) + 4 * g);
               dec_topup_nocheck(d, src);
               const CtxQuad z = stx.prep4(cw);
               if (plain) {
