@@ -305,6 +305,9 @@ struct WaveLds {
 // ------------------------------------------------------------------------------------------------
 // encode kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef ISSCABAC_FLUSH_AT
+#define ISSCABAC_FLUSH_AT 39  // four more bins add at most 22 (context) bits: W stays <= 62
+#endif
 #ifndef ISSCABAC_FLUSH_FN
 #define ISSCABAC_FLUSH_FN enc_flush16_wave  // or enc_flush16: the general loop only
 #endif
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)
-            if ((k & 3) == 3 && wave_any(e.W >= 39)) ISSCABAC_FLUSH_FN(e, sink);
+            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
 #else
             if ((k & 3) == 3) { e.W &= 15; }
 #endif
@@ -439,7 +442,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
                 enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
               }
             }
-            if ((k & 3) == 3 && wave_any(e.W >= 39)) ISSCABAC_FLUSH_FN(e, sink);
+            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
           }
         }
       }
@@ -653,7 +656,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
             for (int g = 0; g < 4; g++) {
 #ifndef ISSCABAC_ABL_NO_PAYLOAD
-              if (g >= 2) src.ensure(24);  // boundary() has just re-based: 64 bits cover the top-ups of g = 0 and 1
+              // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check
+              // then covers words 2 and 3
+              if (g == 2) src.ensure(47);
 #else
               src.cend = src.bpos + 64u;
 #endif
@@ -692,7 +697,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
        // guarded loop with LDS tables for ragged ends (bpermute cannot read inactive lanes)
           if (full) {
             for (int g = 0; g < 4; g++) {
-              if (g >= 2) src.ensure(24);
+              if (g == 2) src.ensure(47);
               const uint32_t cw = word_of(wc, g);
               dec_topup_nocheck(d, src);
               const CtxQuad z = stx.prep4(cw);

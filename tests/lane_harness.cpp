@@ -223,7 +223,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   dec_start(d, src);
   for (uint32_t i = 0; i < n; i++) {
     if (i % (uint32_t)chunk == 0) src.boundary();
-    else if (noguard && i % 16 >= 8 && i % 4 == 0) src.ensure(24);  // 64 bits after boundary() cover two top-ups
+    else if (noguard && i % 16 == 8) src.ensure(47);  // 64 bits after boundary() cover two top-ups; one check for the next two
     if (i % (uint32_t)group == 0) {
       if (noguard) {
         if (src.avail_bits() < 23 - d.sh) return 0xDEAD1000u | i;  // the no-check top-up would be wrong
