@@ -263,7 +263,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "Gbin/s encode+decode round-trip, 1M streams x 4K bins; bit-exact vs HM CPU",
+            "metric": "Gbin/s encode+decode round-trip, 1M streams\u00d74K bins; bit-exact vs HM CPU",  # BASELINE.json, verbatim
             "value": value,
             "unit": "Gbin/s",
             "n_gpus": world,

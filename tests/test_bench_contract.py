@@ -22,6 +22,7 @@ def test_bench_json_line_contract():
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(d[key], typ), (key, d[key])
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     assert d["unit"] == "Gbin/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
