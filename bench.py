@@ -234,7 +234,7 @@ def main():
 
         th = threading.Thread(target=do_gather, daemon=True)
         th.start()
-        th.join(float(os.environ.get("ISSCABAC_GATHER_DEADLINE_S", "120")))
+        th.join(float(os.environ.get("ISSCABAC_GATHER_DEADLINE_S", "60")))
         gather_hung = th.is_alive()
         if gather_hung:
             sys.stderr.write("bitstream gather did not finish before its deadline (rank %d)\n" % rank)
