@@ -278,50 +278,6 @@ CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   enc_bin_at(e, BinB1{b1}, st.addr(ctx), st);
 }
 
-// Four context bins of one stream at once, state bytes read up front and forwarded in registers where
-// contexts repeat inside the quad (more LDS/lookup overlap, ~4 more VALU per bin: pays only when the kernel is
-// latency- rather than issue-bound).  bw / cw: the quad's bin and ctx bytes (bin k in byte k).
-template <class States>
-CABAC_HD void enc_quad(EncCore &e, uint32_t bw, uint32_t cw, States &st) {
-  const uint32_t c0 = cw & 0xFFu, c1 = (cw >> 8) & 0xFFu, c2 = (cw >> 16) & 0xFFu, c3 = cw >> 24;
-  const auto a0 = st.addr(c0), a1 = st.addr(c1), a2 = st.addr(c2), a3 = st.addr(c3);
-  const uint32_t r0 = st.load_at(a0), r1 = st.load_at(a1), r2 = st.load_at(a2), r3 = st.load_at(a3);
-  const uint32_t q0 = r0;
-  const uint32_t row0 = st.lps_row(q0), nx0 = st.next_entry(q0);
-  const uint32_t m0 = mask_from_bit1((bw << 1) ^ q0);
-  const uint32_t qn0 = next_state_q(q0, m0, nx0) & 0xFFu;
-  const uint32_t q1 = c1 == c0 ? qn0 : r1;
-  const uint32_t row1 = st.lps_row(q1), nx1 = st.next_entry(q1);
-  const uint32_t m1 = mask_from_bit1((bw >> 7) ^ q1);
-  const uint32_t qn1 = next_state_q(q1, m1, nx1) & 0xFFu;
-  const uint32_t q2 = c2 == c1 ? qn1 : (c2 == c0 ? qn0 : r2);
-  const uint32_t row2 = st.lps_row(q2), nx2 = st.next_entry(q2);
-  const uint32_t m2 = mask_from_bit1((bw >> 15) ^ q2);
-  const uint32_t qn2 = next_state_q(q2, m2, nx2) & 0xFFu;
-  const uint32_t q3 = c3 == c2 ? qn2 : (c3 == c1 ? qn1 : (c3 == c0 ? qn0 : r3));
-  const uint32_t row3 = st.lps_row(q3), nx3 = st.next_entry(q3);
-  const uint32_t m3 = mask_from_bit1((bw >> 23) ^ q3);
-  const uint32_t qn3 = next_state_q(q3, m3, nx3) & 0xFFu;
-  st.store_at(a0, qn0);
-  st.store_at(a1, qn1);
-  st.store_at(a2, qn2);
-  st.store_at(a3, qn3);
-  const uint32_t rows[4] = {row0, row1, row2, row3};
-  const uint32_t ms[4] = {m0, m1, m2, m3};
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-  for (int k = 0; k < 4; k++) {
-    const uint32_t lps = lps_of(rows[k], e.range);
-    const uint32_t rmps = e.range - lps;
-    const uint32_t r = rmps ^ ((rmps ^ lps) & ms[k]);
-    const uint32_t n = clz32(r) - 23u;
-    e.low = (e.low + (rmps & ms[k])) << n;
-    e.range = r << n;
-    e.W += (int32_t)n;
-  }
-}
-
 // context-coded or bypass bin in one branch-free step (ctx == kBypass selects encodeBinEP); lets a wave
 // whose lanes mix both kinds stay convergent
 template <class States>
@@ -629,50 +585,6 @@ CABAC_HD uint32_t pair_of_bin(uint32_t bin) { return (bin << 1) | 1u; }
 template <class States>
 CABAC_HD uint32_t dec_bin(DecCore &d, uint32_t ctx, States &st) {
   return (dec_bin_at_b1(d, st.addr(ctx), st) >> 1) & 1u;
-}
-
-// Four context bins at once, decoder side: state bytes read up front and forwarded like enc_quad.  The per-bin
-// look-ahead guard (sh >= 8) stays between the bins as a wave-uniform, rarely taken branch.  Returns the four
-// decoded bins, bin k in byte k.
-template <class States, class Src>
-CABAC_HD uint32_t dec_quad(DecCore &d, uint32_t cw, States &st, Src &src) {
-  const uint32_t c0 = cw & 0xFFu, c1 = (cw >> 8) & 0xFFu, c2 = (cw >> 16) & 0xFFu, c3 = cw >> 24;
-  const auto a0 = st.addr(c0), a1 = st.addr(c1), a2 = st.addr(c2), a3 = st.addr(c3);
-  const uint32_t r0 = st.load_at(a0), r1 = st.load_at(a1), r2 = st.load_at(a2), r3 = st.load_at(a3);
-  uint32_t out = 0;
-  uint32_t qn0, qn1, qn2, qn3;
-#define ISSCABAC_DEC_STEP(Q, QN, SHIFT)                              \
-  {                                                                  \
-    const uint32_t row = st.lps_row(Q), nx = st.next_entry(Q);       \
-    if (CABAC_WAVE_ANY(d.sh < 8)) {                                  \
-      if (d.sh < 8) dec_refill(d, src);                              \
-    }                                                                \
-    const uint32_t lps = lps_of(row, d.range);  \
-    const uint32_t rmps = d.range - lps;                             \
-    const uint32_t scaled = rmps << d.sh;                            \
-    const uint32_t m = d.v >= scaled ? ~0u : 0u;                     \
-    const uint32_t r = rmps ^ ((rmps ^ lps) & m);                    \
-    const uint32_t n = clz32(r) - 23u;                               \
-    d.v -= scaled & m;                                               \
-    d.range = r << n;                                                \
-    d.sh -= (int32_t)n;                                              \
-    QN = next_state_q((Q), m, nx) & 0xFFu;                           \
-    out |= ((((Q) >> 1) ^ m) & 1u) << (SHIFT);                       \
-  }
-  const uint32_t q0 = r0;
-  ISSCABAC_DEC_STEP(q0, qn0, 0)
-  const uint32_t q1 = c1 == c0 ? qn0 : r1;
-  ISSCABAC_DEC_STEP(q1, qn1, 8)
-  const uint32_t q2 = c2 == c1 ? qn1 : (c2 == c0 ? qn0 : r2);
-  ISSCABAC_DEC_STEP(q2, qn2, 16)
-  const uint32_t q3 = c3 == c2 ? qn2 : (c3 == c1 ? qn1 : (c3 == c0 ? qn0 : r3));
-  ISSCABAC_DEC_STEP(q3, qn3, 24)
-#undef ISSCABAC_DEC_STEP
-  st.store_at(a0, qn0);
-  st.store_at(a1, qn1);
-  st.store_at(a2, qn2);
-  st.store_at(a3, qn3);
-  return out;
 }
 
 template <class States>

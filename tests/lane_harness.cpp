@@ -125,8 +125,6 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
                         int flush_every, uint8_t *out, size_t cap, uint8_t *ctx_final, int *max_w) {
   const bool any = flush_every < 0;
   if (any) flush_every = -flush_every;
-  const bool quads = flush_every == 40;
-  if (quads) flush_every = 4;
   // 18: the kernel's plain path -- an aligned word of four context bins adds to `low` once (EncWordAcc / enc_word_close)
   const bool wordacc = flush_every == 18;
   if (wordacc) flush_every = 17;
@@ -141,17 +139,6 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   enc_start(e);
   int mw = 0;
   for (uint32_t i = 0; i < n; i++) {
-    if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
-        ctx[i + 3] != kBypass) {
-      uint32_t bw, cw;
-      std::memcpy(&bw, bins + i, 4);
-      std::memcpy(&cw, ctx + i, 4);
-      enc_quad(e, bw, cw, st);
-      if (e.W > mw) mw = e.W;
-      i += 3;
-      enc_flush(e, sink);
-      continue;
-    }
     if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
         ctx[i + 3] != kBypass) {
       EncWordAcc acc;
@@ -197,8 +184,6 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
                             uint8_t *ctx_final, uint32_t *counters /* [fast, slow, slow_refills] */) {
   const bool any = group < 0;
   if (any) group = -group;
-  const bool quads = group == 40;
-  if (quads) group = 4;
   // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
   bool memtab = group == 3;  // ... with the byte-table bin step and (mps, lps) pair collection of the kernel
   if (memtab) group = 2;
@@ -233,15 +218,6 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       }
     }
     if (noguard && i % 4 == 3) dec_guard(d, src, min_sh);
-    if (quads && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
-        ctx[i + 3] != kBypass) {
-      uint32_t cw;
-      std::memcpy(&cw, ctx + i, 4);
-      const uint32_t o = dec_quad(d, cw, st, src);
-      std::memcpy(bins_out + i, &o, 4);
-      i += 3;
-      continue;
-    }
     if (noguard) {
       if (d.sh < (ctx[i] == kBypass ? 8 : 7)) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
     } else if (d.sh < 8) {
