@@ -151,5 +151,63 @@ struct SymWalk {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The binarisation as a code tree with the selectors folded in (small alphabets: nq <= 16).
+// A symbol is a path from the root; the context of the bin coded AT a node depends on the node and on the symbol one row
+// up only -- iss_ctx / demo_ctx look at nothing else -- so both become one byte look-up per bin:
+//   ctx[node * kTrieUp + up]   up = value of the symbol one row up, kTrieNoUp = there is none
+//   child[node * 2 + bin]      next node (< kTrieNodes), 0x80 | symbol at the end of a code word, 0xFF = no code word goes on
+// Built on the host from the functions above (sym_trie_build), so it cannot drift from them; a walk that leaves the tree
+// (0xFF: corrupt stream) hands the stream to the general kernel, which parses any bin string.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kTrieNodes = 64, kTrieUp = 17, kTrieNoUp = 16, kTrieNone = 0xFFu;
+struct SymTrie {
+  uint8_t child[kTrieNodes * 2];
+  uint8_t ctx[kTrieNodes * kTrieUp];
+  uint32_t nodes;
+};
+// false: the alphabet does not fit (nq > 16, more than kTrieNodes inner nodes) -- the caller keeps the general kernels
+inline bool sym_trie_build(const SymParams &P, SymTrie *T) {
+  if (P.nq < 2 || P.nq > 16) return false;
+  for (uint32_t i = 0; i < kTrieNodes * 2; i++) T->child[i] = (uint8_t)kTrieNone;
+  for (uint32_t i = 0; i < kTrieNodes * kTrieUp; i++) T->ctx[i] = 0;
+  bool seen[kTrieNodes] = {};
+  T->nodes = 1;
+  for (uint32_t v = 0; v < P.nq; v++) {
+    const BinString g = binarize(v, P);
+    if (g.len == 0 || g.len > 32) return false;
+    uint32_t node = 0;
+    for (uint32_t n = 1; n <= g.len; n++) {
+      const uint32_t bit = (g.bits >> (n - 1)) & 1u;
+      for (uint32_t up = 0; up < kTrieUp; up++) {
+        BinString ub;
+        ub.bits = ub.len = ub.np = 0;
+        const bool has = up < P.nq;
+        if (has) ub = binarize(up, P);
+        if (!has && up != kTrieNoUp) continue;
+        const uint32_t c = P.selector == 0 ? demo_ctx(n, has, ub.bits & 1u) : iss_ctx(n, g, ub, P);
+        if (c > 255u) return false;
+        if (seen[node] && T->ctx[node * kTrieUp + up] != (uint8_t)c) return false;  // two symbols disagree: not a tree code
+        T->ctx[node * kTrieUp + up] = (uint8_t)c;
+      }
+      seen[node] = true;
+      uint8_t &slot = T->child[node * 2 + bit];
+      if (n == g.len) {
+        if (slot != kTrieNone) return false;  // a code word that is a prefix of another
+        slot = (uint8_t)(0x80u | v);
+      } else {
+        if (slot == kTrieNone) {
+          if (T->nodes == kTrieNodes) return false;
+          slot = (uint8_t)T->nodes++;
+        } else if (slot & 0x80u) {
+          return false;
+        }
+        node = slot;
+      }
+    }
+  }
+  return true;
+}
+
 }  // namespace isscabac
 #endif

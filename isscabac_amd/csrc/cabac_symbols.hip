@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "cabac_internal.h"
@@ -37,6 +38,12 @@ constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
 // bytes by (packed state, bin), [768,1024) by (packed state, path), then {bits, len | np << 8} per symbol value
 constexpr uint32_t kSymByBin = 512, kSymByPath = 768, kSymBinTab = 1024, kSymTab = 1024 + 256 * 8;
 constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
+// the code-tree kernels (cabac_symbols.h: SymTrie) keep the tree behind the binarisation table
+// ... and, made from it in the kernel, the table the loop actually reads: for (node, bin, symbol above) the 16-bit pair
+// {where the walk goes (SymTrie::child), context of the bin coded there} -- one LDS round trip per bin instead of two in a row
+constexpr uint32_t kSymTrieChild = kSymTab, kSymTrieCtx = kSymTab + kTrieNodes * 2;
+constexpr uint32_t kSymTrieStep = (kSymTrieCtx + kTrieNodes * kTrieUp + 15u) & ~15u;
+constexpr uint32_t kSymTabTrie = (kSymTrieStep + kTrieNodes * 2 * kTrieUp * 2 + 255u) & ~255u;
 
 // states in LDS (same conflict-free layout as the bin kernels), tables in LDS memory (lanes finish at different times)
 struct SymStates {
@@ -93,7 +100,8 @@ struct SymEncArgs {
   uint32_t ctx_init[16];
 };
 
-__device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, uint8_t *&wbase, int tid) {
+__device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, uint8_t *&wbase, int tid,
+                                                uint32_t tab_bytes = kSymTab) {
   tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = y_lps_rows[tid];
@@ -102,7 +110,7 @@ __device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, u
     tab[192 + tid] = y_next.ep[tid];
   }
   __syncthreads();
-  wbase = smem + kSymTab + (tid >> 6) * kSymWaveBytes;
+  wbase = smem + tab_bytes + (tid >> 6) * kSymWaveBytes;
 }
 
 __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
@@ -188,8 +196,9 @@ struct SymDevMem {
       const Q4 q = *reinterpret_cast<const Q4 *>(base + off);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
       hi = (uint64_t)q.w[2] | ((uint64_t)q.w[3] << 32);
-    } else {
+    } else {  // the last few bytes of the whole payload buffer: never read past its end (rolled: rare, keep the loop small)
       lo = hi = 0;
+#pragma unroll 1
       for (uint32_t i = 0; i < 16; i++) {
         const uint64_t b = (uint64_t)off + i < avail ? base[off + i] : 0;
         if (i < 8) lo |= b << (8 * i);
@@ -205,6 +214,10 @@ struct SymDecArgs {
   const uint32_t *nsym_per_stream;
   uint8_t *sym_out;
   uint32_t *status;
+  // code-tree path: redo[s] != 0 marks a stream the tree kernel could not finish, *redo_any != 0 says there is one.  The
+  // tree kernel writes them; the general kernel, launched behind it, then decodes exactly those streams (and returns at once
+  // when there are none)
+  uint32_t *redo, *redo_any;
   uint64_t S, payload_bytes;
   uint32_t nsym, pitch, nctx;
   SymParams P;
@@ -213,6 +226,7 @@ struct SymDecArgs {
 
 __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (a.redo_any && *a.redo_any == 0u) return;  // (uniform) the code-tree kernel finished every stream itself
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t *tab;
   uint8_t *wbase;
@@ -223,6 +237,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   SymStates st{wbase + lane * 4, tab};
   if (!valid) return;
+  if (a.redo && a.redo[s] == 0u) return;  // behind the code-tree kernel: only the streams it handed over
   uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   uint64_t start = a.offsets[s];
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
@@ -270,6 +285,201 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     const uint8_t *p = a.payload + start;
     a.status[s] = exact ? ref_dec_finish(r, rd, len)
                         : dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+  }
+}
+
+// ---- the same two kernels on the code tree (SymTrie): binarisation walk and context selection are two byte look-ups per
+// bin instead of ~100 VALU of per-lane string handling.  Small alphabets only (nq <= 16: every reference configuration);
+// no statistics (they want the reference's write-out cadence, see k_encode_symbols).
+struct SymTrieEncArgs {
+  SymEncArgs a;
+  SymTrie trie;
+};
+struct SymTrieDecArgs {
+  SymDecArgs a;
+  SymTrie trie;
+};
+// (all 256 threads; ends with a barrier)
+__device__ __forceinline__ void sym_trie_to_lds(uint8_t *smem, const SymTrie &T, int tid) {
+  for (uint32_t i = tid; i < kTrieNodes * 2; i += 256) smem[kSymTrieChild + i] = T.child[i];
+  for (uint32_t i = tid; i < kTrieNodes * kTrieUp; i += 256) smem[kSymTrieCtx + i] = T.ctx[i];
+  __syncthreads();
+  // step[(node * 2 + bin) * kTrieUp + up] = child | ctx of the next bin << 8.  After an inner node that is the child's
+  // context under the same symbol above; after a leaf it is the root's context with the symbol just finished above.
+  uint16_t *step = reinterpret_cast<uint16_t *>(smem + kSymTrieStep);
+  for (uint32_t i = tid; i < kTrieNodes * 2 * kTrieUp; i += 256) {
+    const uint32_t nb = i / kTrieUp, up = i - nb * kTrieUp;
+    const uint32_t nx = smem[kSymTrieChild + nb];
+    const uint32_t v = nx & 0x7Fu;
+    uint32_t c = 0;
+    if (nx == kTrieNone) c = 0;
+    else if (nx & 0x80u) c = v < kTrieUp ? smem[kSymTrieCtx + v] : 0;  // root is node 0
+    else c = smem[kSymTrieCtx + nx * kTrieUp + up];
+    step[i] = (uint16_t)(nx | (c << 8));
+  }
+  __syncthreads();
+}
+typedef __attribute__((address_space(3))) uint8_t sym_lds_u8;
+__device__ __forceinline__ uint32_t trie_ctx(uint32_t node, uint32_t up) {
+  return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)(kSymTrieCtx + node * kTrieUp + up));
+}
+__device__ __forceinline__ uint32_t trie_child(uint32_t node, uint32_t bin) {
+  return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)(kSymTrieChild + node * 2u + bin));
+}
+typedef __attribute__((address_space(3))) uint16_t sym_lds_u16;
+__device__ __forceinline__ uint32_t trie_step(uint32_t node, uint32_t bin, uint32_t up) {
+  return *reinterpret_cast<const sym_lds_u16 *>((uintptr_t)(kSymTrieStep + ((node * 2u + bin) * kTrieUp + up) * 2u));
+}
+
+__global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SymEncArgs &a = ta.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t *tab;
+  uint8_t *wbase;
+  {
+    uint2 *bt = reinterpret_cast<uint2 *>(smem + kSymBinTab);
+    const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);
+    bt[tid] = make_uint2(g.bits, g.len);
+  }
+  sym_trie_to_lds(smem, ta.trie, tid);
+  sym_init_common(smem, tab, wbase, tid, kSymTabTrie);
+  const uint2 *bintab = reinterpret_cast<const uint2 *>(smem + kSymBinTab);
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const bool valid = s < a.S;
+  uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
+  for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+  SymStates st{wbase + lane * 4, tab};
+  if (!valid) return;
+  const uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
+  const uint8_t *row_in = a.sym + s * a.pitch;
+  EncCore e;
+  enc_start(e);
+  SymSink sink{wbase + kSymStateBytes + lane * 16, a.slots + s * a.slot_stride, 0};
+  uint32_t idx = 0, n = 1, node = 0, up = kTrieNoUp, row = 0, nbins = 0, bits = 0, len = 0, v = 0;
+  uint4 buf = make_uint4(0, 0, 0, 0);
+  const uint32_t vmax = a.P.nq - 1;
+  const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
+  uint32_t c = c_top;
+  while (idx < n_my) {
+    if (n == 1) {
+      if ((idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row_in + idx);
+      const uint32_t wi = (idx >> 2) & 3u;
+      const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
+      v = min((word >> (8 * (idx & 3u))) & 0xFFu, vmax);  // (values >= nq cannot be coded: they go out as nq - 1, like the general kernel)
+      const uint2 g = bintab[v];
+      bits = g.x;
+      len = g.y;
+      node = 0;
+    }
+    const uint32_t bin = (bits >> (n - 1)) & 1u;
+    const uint32_t step = trie_step(node, bin, up);  // does not wait for the coder: its latency hides behind the bin
+    enc_bin_at_mem(e, SymBin{bin}, st.addr(c), st);
+    if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);  // bytes are the same at any cadence, see k_encode_symbols
+    nbins++;
+    c = step >> 8;
+    if (n == len) {
+      idx++;
+      n = 1;
+      up = v;
+      row++;
+      if (row == a.P.col_rows) {  // first row of the next column: no symbol above (the demo selector keeps its predecessor)
+        row = 0;
+        if (a.P.selector != 0) {
+          up = kTrieNoUp;
+          c = c_top;
+        }
+      }
+    } else {
+      node = step & 0xFFu;
+      n++;
+    }
+  }
+  enc_finish(e, sink);
+  sink.close();
+  a.lens[s] = sink.pos;
+  if (a.nbins_out) a.nbins_out[s] = nbins;
+}
+
+__global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SymDecArgs &a = ta.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint32_t *tab;
+  uint8_t *wbase;
+  sym_trie_to_lds(smem, ta.trie, tid);
+  sym_init_common(smem, tab, wbase, tid, kSymTabTrie);
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const bool valid = s < a.S;
+  uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
+  for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+  SymStates st{wbase + lane * 4, tab};
+  if (!valid) return;
+  const uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
+  uint64_t start = a.offsets[s];
+  const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
+  const uint64_t abase = start & ~3ull;
+  const uint32_t skew = (uint32_t)(start - abase);
+  WindowSrc<SymDevMem> src;
+  src.mem.base = a.payload + abase;
+  src.mem.avail = a.payload_bytes > abase ? a.payload_bytes - abase : 0;
+  src.len = skew + len;
+  src.start(skew);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  // streams this kernel does not finish go to the general kernel behind it: a first byte of 0xFF (reference-formulation
+  // decoder, see RefDec) and bin strings that are no code word of the alphabet -- corrupt input both
+  bool handed_over = needs_ref_decoder(d.v >> 24);
+  uint8_t *row_out = a.sym_out + s * a.pitch;
+  uint8_t *stage = wbase + kSymStateBytes + lane * 16;  // this lane's 16 bytes of output staging
+  uint32_t idx = 0, node = 0, up = kTrieNoUp, row = 0, it = 0;
+  const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
+  uint32_t c = c_top;
+  const bool cols = a.P.col_rows != 0 && a.P.selector != 0;  // (uniform) the symbol above restarts with every column
+  while (!handed_over && idx < n_my) {
+    // every pass tops v up to sh = 23 for all lanes (one bin takes at most 6 bits): no per-lane refill branch.  The window
+    // is re-based from the prefetched piece every 16 passes and, wave-uniformly, whenever a lane is short of a top-up
+    if ((it++ & 15u) == 0) src.boundary();
+    else src.ensure(24);
+    dec_topup_nocheck(d, src);
+    const uint32_t pair = dec_bin_at_mem(d, st.addr(c), st);  // bit 1 = mps, bit 0 = MPS path
+    const uint32_t bin = ((pair >> 1) ^ ~pair) & 1u;
+    const uint32_t step = trie_step(node, bin, up);  // where the walk goes | context of the next bin << 8
+    const uint32_t nx = step & 0xFFu;
+    c = step >> 8;
+    const bool leaf = (nx & 0x80u) != 0;  // end of a code word (or no code word at all: handed over below)
+    const uint32_t v = nx & 0x7Fu;
+    if (leaf) {  // symbols leave 16 at a time: a byte store per symbol costs the memory pipe one transaction per lane and pass
+      stage[idx & 15u] = (uint8_t)v;
+      if ((idx & 15u) == 15u) *reinterpret_cast<uint4 *>(row_out + (idx & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+    }
+    handed_over = nx == kTrieNone;
+    idx += leaf ? 1u : 0u;
+    node = leaf ? 0u : nx;
+    up = leaf ? v : up;
+    if (cols) {
+      row += leaf ? 1u : 0u;
+      const bool top = leaf && row == a.P.col_rows;
+      row = top ? 0u : row;
+      up = top ? kTrieNoUp : up;
+      c = top ? c_top : c;
+    }
+  }
+  a.redo[s] = handed_over ? 1u : 0u;
+  if (handed_over) {
+    *a.redo_any = 1u;
+    return;
+  }
+  // the last, incomplete group of 16 and the symbols the stream does not have: zeros (rows are padded to a multiple of 16)
+  if (n_my & 15u) {
+    for (uint32_t i = n_my & 15u; i < 16u; i++) stage[i] = 0;
+    *reinterpret_cast<uint4 *>(row_out + (n_my & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+  }
+  for (uint32_t i = (n_my + 15u) & ~15u; i < a.nsym; i++) row_out[i] = 0;
+  if (a.status) {
+    const uint8_t *p = a.payload + start;
+    a.status[s] = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
 }
 
@@ -492,6 +702,16 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *p) {
   return m > 32 ? 0 : m;
 }
 
+// the code-tree kernels serve small alphabets (cabac_symbols.h: sym_trie_build); ISSCABAC_SYM_NO_TRIE=1 keeps the general
+// kernels for A/B runs
+static bool sym_use_trie(const SymParams &P, SymTrie *T) {
+  static const bool off = [] {
+    const char *v = getenv("ISSCABAC_SYM_NO_TRIE");
+    return v && v[0] && v[0] != '0';
+  }();
+  return !off && sym_trie_build(P, T);
+}
+
 // the symbol kernels read their tables by absolute LDS address: their dynamic LDS must start at 0
 static int sym_check_no_static_lds(isscabac_engine *e, const void *fn) {
   hipFuncAttributes fa;
@@ -537,10 +757,16 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   a.nsym = nsym;
   a.pitch = pitch;
   a.nctx = (uint32_t)nctx;
-  const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
   const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
-  if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
-  hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
+  SymTrieEncArgs ta;
+  if (!d_stats && sym_use_trie(a.P, &ta.trie)) {
+    ta.a = a;
+    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie)))) return rc;
+    hipLaunchKernelGGL(k_encode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * kSymWaveBytes, e->stream, ta);
+  } else {
+    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
+    hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), kSymTab + kSymWaves * kSymWaveBytes, e->stream, a);
+  }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
   HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
@@ -577,6 +803,22 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
   a.nctx = (uint32_t)nctx;
   const size_t lds = kSymTab + kSymWaves * kSymWaveBytes;
   const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
+  a.redo = nullptr;
+  a.redo_any = nullptr;
+  SymTrieDecArgs ta;
+  if ((reinterpret_cast<uintptr_t>(d_sym_out) & 15u) == 0 && sym_use_trie(a.P, &ta.trie)) {  // (it stores 16 symbols at a time)
+    // the code-tree kernel first; whatever it hands over (corrupt streams only) is decoded by the general kernel behind it,
+    // which finds the hand-over marks on the device and returns at once when there are none
+    if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
+    if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+    HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+    a.redo = e->lens;
+    a.redo_any = e->flag;
+    ta.a = a;
+    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie)))) return rc;
+    hipLaunchKernelGGL(k_decode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * kSymWaveBytes, e->stream, ta);
+    HIP_TRY(e, hipGetLastError());
+  }
   if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols)))) return rc;
   hipLaunchKernelGGL(k_decode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
   HIP_TRY(e, hipGetLastError());

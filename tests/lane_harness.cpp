@@ -321,6 +321,44 @@ long sym_encode_stream(const uint8_t *sym, uint32_t nsym, const uint32_t *params
   return sink.len <= cap ? (long)sink.len : -1;
 }
 
+// The code tree of the symbol kernels' fast path (cabac_symbols.h: SymTrie) against the general walker: for the symbol
+// sequence `sym`, the context of every bin and the symbol found at every leaf must be what SymWalk / binarize give.
+// Returns the number of tree nodes, 0 if the parameters do not get a tree, -1 - (bin index) at the first disagreement.
+long sym_trie_check(const uint8_t *sym, uint32_t nsym, const uint32_t *params) {
+  const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5], params[6]};
+  static SymTrie T;
+  if (!sym_trie_build(P, &T)) return 0;
+  SymWalk w;
+  w.start();
+  uint32_t node = 0, up = kTrieNoUp, row = 0;
+  long nb = 0;
+  while (w.idx < nsym) {
+    if (w.n == 1) {
+      w.cur = binarize(sym[w.idx], P);
+      node = 0;
+    }
+    if (T.ctx[node * kTrieUp + up] != w.ctx(P)) return -1 - nb;
+    const uint32_t bin = (w.cur.bits >> (w.n - 1)) & 1u;
+    const uint32_t nx = T.child[node * 2 + bin];
+    nb++;
+    if (w.n == w.cur.len) {
+      if (nx != (0x80u | sym[w.idx])) return -1 - nb;
+      up = sym[w.idx];
+      row++;
+      if (row == P.col_rows) {
+        row = 0;
+        up = P.selector == 0 ? up : kTrieNoUp;
+      }
+      w.next_symbol(P);
+    } else {
+      if (nx & 0x80u) return -1 - nb;
+      node = nx;
+      w.n++;
+    }
+  }
+  return (long)T.nodes;
+}
+
 uint32_t sym_decode_stream(const uint8_t *payload, uint32_t len, uint32_t nsym, const uint32_t *params,
                            const uint8_t *ctx_init, int nctx, uint8_t *sym_out) {
   const SymParams P{params[0], params[1], params[2], params[3], params[4], params[5], params[6]};

@@ -37,6 +37,8 @@ def lane():
                                     C.POINTER(C.c_uint32)]
     L.sym_decode_stream.restype = C.c_uint32
     L.sym_decode_stream.argtypes = [u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), u8p, C.c_int, u8p]
+    L.sym_trie_check.restype = C.c_long
+    L.sym_trie_check.argtypes = [u8p, C.c_uint32, C.POINTER(C.c_uint32)]
     return L
 
 
@@ -299,3 +301,28 @@ def test_reference_formulation_decoder_matches_oracle_even_on_streams_starting_w
         else:
             assert (got2 == want).all() and st2 == st_want, it
     assert led > 100 and differ > 0  # the case RefDec exists for is real
+
+
+def test_symbol_code_tree_matches_the_general_walker(lane):
+    """The symbol kernels' fast path walks a code tree built on the host from binarize / iss_ctx / demo_ctx (SymTrie).  For
+    every parameter set the tests and the reference use: contexts and leaves along random symbol sequences equal the
+    general walker's, with and without a column structure; big alphabets get no tree (general kernels)."""
+    rng = np.random.default_rng(8)
+    cases = []
+    for nq in (2, 3, 4, 8, 13, 16):
+        for method, k in ((0, 0), (1, 0), (1, 1), (1, 2)):
+            for selector, types, nlbp in ((0, 0, 0), (1, 15, 3), (1, 31, 2), (1, 5, 1), (1, 0, 4), (1, 15, 8)):
+                for col_rows in (0, 1, 7, 40):
+                    cases.append((method, k, nq, selector, types, nlbp, col_rows))
+    built = 0
+    for c in cases:
+        params = (C.c_uint32 * 7)(*c)
+        sym = rng.integers(0, c[2], 600).astype(np.uint8)
+        r = lane.sym_trie_check(_p(sym), sym.size, params)
+        assert r >= 0, (c, r)
+        built += r > 0
+    assert built == len(cases)  # every alphabet up to 16 symbols gets a tree
+    for nq in (17, 64, 200):
+        params = (C.c_uint32 * 7)(1, 0, nq, 1, 15, 3, 0)
+        sym = rng.integers(0, nq, 50).astype(np.uint8)
+        assert lane.sym_trie_check(_p(sym), sym.size, params) == 0
