@@ -218,6 +218,7 @@ struct SymDecArgs {
   // tree kernel writes them; the general kernel, launched behind it, then decodes exactly those streams (and returns at once
   // when there are none)
   uint32_t *redo, *redo_any;
+  uint32_t out16;  // sym_out is 16-byte aligned: symbols are stored 16 at a time
   uint64_t S, payload_bytes;
   uint32_t nsym, pitch, nctx;
   SymParams P;
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   RefDec r;
   if (exact) ref_dec_start(r, rd);
   uint8_t *row = a.sym_out + s * a.pitch;
+  uint8_t *stage = wbase + kSymStateBytes + lane * 16;  // this lane's 16 bytes of output staging
   SymWalk w;
   w.start();
   uint32_t it = 0;
@@ -274,13 +276,25 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
     w.cur = append_bin(w.cur, w.n, bin);
     const bool finished = symbol_finished(w.cur, a.P);
     if (finished || w.n == 32) {  // 32 bins without an end: corrupt stream; the symbol is cut there and reads as 0
-      row[w.idx] = finished ? (uint8_t)debinarize(w.cur, a.P) : (uint8_t)0;
+      const uint8_t sv = finished ? (uint8_t)debinarize(w.cur, a.P) : (uint8_t)0;
+      if (a.out16) {  // symbols leave 16 at a time: a byte store per symbol costs the memory pipe a transaction per lane and pass
+        stage[w.idx & 15u] = sv;
+        if ((w.idx & 15u) == 15u) *reinterpret_cast<uint4 *>(row + (w.idx & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+      } else {
+        row[w.idx] = sv;
+      }
       w.next_symbol(a.P);
     } else {
       w.n++;
     }
   }
-  for (uint32_t i = n_my; i < a.nsym; i++) row[i] = 0;
+  uint32_t zfrom = n_my;
+  if (a.out16 && (n_my & 15u)) {  // the last, incomplete group of 16 (rows are padded to a multiple of 16)
+    for (uint32_t i = n_my & 15u; i < 16u; i++) stage[i] = 0;
+    *reinterpret_cast<uint4 *>(row + (n_my & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
+    zfrom = (n_my + 15u) & ~15u;
+  }
+  for (uint32_t i = zfrom; i < a.nsym; i++) row[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
     a.status[s] = exact ? ref_dec_finish(r, rd, len)
@@ -805,8 +819,9 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
   const uint64_t nblk = (S + 64 * kSymWaves - 1) / (64 * kSymWaves);
   a.redo = nullptr;
   a.redo_any = nullptr;
+  a.out16 = (reinterpret_cast<uintptr_t>(d_sym_out) & 15u) == 0 ? 1u : 0u;
   SymTrieDecArgs ta;
-  if ((reinterpret_cast<uintptr_t>(d_sym_out) & 15u) == 0 && sym_use_trie(a.P, &ta.trie)) {  // (it stores 16 symbols at a time)
+  if (a.out16 && sym_use_trie(a.P, &ta.trie)) {  // (it stores 16 symbols at a time)
     // the code-tree kernel first; whatever it hands over (corrupt streams only) is decoded by the general kernel behind it,
     // which finds the hand-over marks on the device and returns at once when there are none
     if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
