@@ -1,90 +1,127 @@
 classdef cabacWrapper < handle
-%-------------------------------------------------------------------------%
-% MATLAB class wrapper around SimpleCABACMex, the MEX gateway of the MI355X
-% batched CABAC engine.  Same constructor and methods as the reference class
-% (christianrohlfing/ISScabac, CABAC/cabacWrapper.m) so that cabacDemo.m and
-% ISS/+coder/cabac{Encode,Decode}.m run unchanged; encodeBatch / decodeBatch
-% are additive and code one independent stream per matrix column on the GPU.
-%-------------------------------------------------------------------------%
+% cabacWrapper  MATLAB front end of the MI355X batched CABAC engine.
+%
+%   w = cabacWrapper(ctxInit, fileName)            contexts initialised by p(0), one value per context
+%   w = cabacWrapper(ctxInit, fileName, false)     contexts initialised by [ctxID mps state ...] triples
+%
+% Per-bin calls (what CABAC/cabacDemo.m and ISS/+coder/cabacEncode.m / cabacDecode.m of christianrohlfing/ISScabac
+% use; same names, arguments and results as that repository's class, so those scripts run unchanged):
+%   encodeStart, encodeBin(bin, ctx), encodeFinish, getNumBits,
+%   decodeStart, bin = decodeBin(ctx), decodeFinish,
+%   [trace, stats] = getEncoderStats(ctx) / getDecoderStats(ctx)
+% Batch calls (new; one independent bitstream per matrix column, coded on the GPU in one go; ctx value 255 marks a
+% bypass bin; nbins optionally gives the number of bins actually coded in every column):
+%   [payload, offsets] = encodeBatch(bins, ctx [, nbins])
+%   [bins, status]     = decodeBatch(payload, offsets, ctx [, nbins])
+%
+% Every method is a thin call into the MEX gateway SimpleCABACMex (matlab/SimpleCABACMex.cpp), which forwards to the C
+% ABI of include/isscabac.h; no coding logic lives here.
+
   properties
-    bitStreamName;
-    cabac_handle;
-    contextModelInitOptions; % initByProb: p(0) per context; initByState: [ctxID mps state ...]
+    cabac_handle = [];          % engine handle returned by the gateway (a double)
+    bitStreamName = '';         % file the per-bin calls write to / read from
+    contextModelInitOptions;    % what the constructor was given (p(0) values or state triples)
   end
+
   methods
-    function obj = cabacWrapper(cm,fn,initByProb)
-      if nargin < 3, initByProb=1; end
-      if ischar(fn)
-        obj.bitStreamName = fn;
-      else
-        error('bitStreamName should be string')
+    % ---- life cycle ---------------------------------------------------------------------------------------------
+    function obj = cabacWrapper(ctxInit, fileName, byProbability)
+      if nargin < 3
+        byProbability = true;
       end
-      if ismatrix(cm)
-        obj.contextModelInitOptions = cm;
-      else
-        error('context model initialization options should be like this: [ctxID mps probIndex, ctxID mps probIndex, ...]')
+      if ~ischar(fileName)
+        error('cabacWrapper:fileName', 'the bitstream file name has to be a character array');
       end
-      obj.init(initByProb)
-    end
-    function init(obj,initByProb)
-      if nargin < 2, initByProb=1; end
-      if initByProb
-        obj.cabac_handle = SimpleCABACMex('initByProb', obj.bitStreamName,obj.contextModelInitOptions);
-      else
-        obj.cabac_handle = SimpleCABACMex('initByState', obj.bitStreamName,obj.contextModelInitOptions);
+      if ~ismatrix(ctxInit) || ~isnumeric(ctxInit)
+        error('cabacWrapper:ctxInit', ...
+              'context initialisation: p(0) per context, or [ctxID mps state, ctxID mps state, ...]');
       end
+      obj.contextModelInitOptions = ctxInit;
+      obj.bitStreamName = fileName;
+      obj.init(byProbability);
     end
-    function encodeStart(obj)
-      SimpleCABACMex('encodeStart', obj.cabac_handle);
-    end
-    function encodeBin(obj,binValue, ctxID)
-      if binValue == 1 || binValue == 0
-        SimpleCABACMex('encodeBin', obj.cabac_handle, binValue, ctxID);
+
+    function init(obj, byProbability)
+      % (re)creates the engine handle; the gateway keeps the command names of the reference MEX file
+      if nargin < 2 || byProbability
+        command = 'initByProb';
       else
-        error('bin value to be encoded should either be 1 or 0');
+        command = 'initByState';
       end
+      obj.cabac_handle = SimpleCABACMex(command, obj.bitStreamName, obj.contextModelInitOptions);
     end
-    function encodeFinish(obj)
-      SimpleCABACMex('encodeFinish', obj.cabac_handle);
-    end
-    function decodeStart(obj)
-      SimpleCABACMex('decodeStart', obj.cabac_handle);
-    end
-    function decodedBin = decodeBin(obj, ctxID)
-      decodedBin = SimpleCABACMex('decodeBin', obj.cabac_handle, ctxID);
-    end
-    function decodeFinish(obj)
-      SimpleCABACMex('decodeFinish', obj.cabac_handle);
-    end
-    function [trace, stats] = getEncoderStats(obj, ctxID)
-      [trace, stats] = SimpleCABACMex('getEncoderStats',obj.cabac_handle,ctxID);
-    end
-    function [trace, stats] = getDecoderStats(obj, ctxID)
-      [trace, stats] = SimpleCABACMex('getDecoderStats',obj.cabac_handle,ctxID);
-    end
-    function [bits] = getNumBits(obj)
-      [bits] = SimpleCABACMex('getNumBits',obj.cabac_handle);
-    end
-    % ---- batch extension: one independent stream per column, ctx 255 = bypass bin ----
-    function [payload, offsets] = encodeBatch(obj, bins, ctx, nbins)
-      if nargin < 4
-        [payload, offsets] = SimpleCABACMex('encodeBatch', obj.cabac_handle, uint8(bins), uint8(ctx));
-      else
-        [payload, offsets] = SimpleCABACMex('encodeBatch', obj.cabac_handle, uint8(bins), uint8(ctx), uint32(nbins));
-      end
-    end
-    function [bins, status] = decodeBatch(obj, payload, offsets, ctx, nbins)
-      if nargin < 5
-        [bins, status] = SimpleCABACMex('decodeBatch', obj.cabac_handle, uint8(payload), double(offsets), uint8(ctx));
-      else
-        [bins, status] = SimpleCABACMex('decodeBatch', obj.cabac_handle, uint8(payload), double(offsets), uint8(ctx), uint32(nbins));
-      end
-    end
+
     function delete(obj)
       if ~isempty(obj.cabac_handle)
-        SimpleCABACMex('delete', obj.cabac_handle);
+        obj.gateway('delete');
         obj.cabac_handle = [];
       end
+    end
+
+    % ---- per-bin encoder ----------------------------------------------------------------------------------------
+    function encodeStart(obj)
+      obj.gateway('encodeStart');
+    end
+
+    function encodeBin(obj, binValue, ctxID)
+      if ~(isequal(binValue, 0) || isequal(binValue, 1))
+        error('cabacWrapper:bin', 'a bin is 0 or 1');
+      end
+      obj.gateway('encodeBin', binValue, ctxID);
+    end
+
+    function encodeFinish(obj)
+      obj.gateway('encodeFinish');
+    end
+
+    function bits = getNumBits(obj)
+      bits = SimpleCABACMex('getNumBits', obj.cabac_handle);
+    end
+
+    % ---- per-bin decoder ----------------------------------------------------------------------------------------
+    function decodeStart(obj)
+      obj.gateway('decodeStart');
+    end
+
+    function bin = decodeBin(obj, ctxID)
+      bin = SimpleCABACMex('decodeBin', obj.cabac_handle, ctxID);
+    end
+
+    function decodeFinish(obj)
+      obj.gateway('decodeFinish');
+    end
+
+    % ---- state traces (the gateway answers "Invalid Command" like the reference's Linux build) -------------------
+    function [trace, stats] = getEncoderStats(obj, ctxID)
+      [trace, stats] = SimpleCABACMex('getEncoderStats', obj.cabac_handle, ctxID);
+    end
+
+    function [trace, stats] = getDecoderStats(obj, ctxID)
+      [trace, stats] = SimpleCABACMex('getDecoderStats', obj.cabac_handle, ctxID);
+    end
+
+    % ---- batches: B x S uint8 matrices, column s = stream s ------------------------------------------------------
+    function [payload, offsets] = encodeBatch(obj, bins, ctx, nbins)
+      args = {uint8(bins), uint8(ctx)};
+      if nargin >= 4
+        args{end + 1} = uint32(nbins);
+      end
+      [payload, offsets] = SimpleCABACMex('encodeBatch', obj.cabac_handle, args{:});
+    end
+
+    function [bins, status] = decodeBatch(obj, payload, offsets, ctx, nbins)
+      args = {uint8(payload), double(offsets), uint8(ctx)};
+      if nargin >= 5
+        args{end + 1} = uint32(nbins);
+      end
+      [bins, status] = SimpleCABACMex('decodeBatch', obj.cabac_handle, args{:});
+    end
+  end
+
+  methods (Access = private)
+    function gateway(obj, command, varargin)
+      % commands without a result
+      SimpleCABACMex(command, obj.cabac_handle, varargin{:});
     end
   end
 end
