@@ -32,7 +32,7 @@ def test_bench_json_line_contract():
     assert r["traffic"] is None  # PMC traffic is per launch of the full workload only
     c = d["cpu_baseline"]
     assert c["unit"] == "Gbin/s" and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and c["sample"]
-    assert c["gpu_streams_checked_byte_exact"] == 256
+    assert c["gpu_streams_checked_byte_exact"] == 4096
     assert d["verified_bit_exact"] is True
     # value = bins / wall time, consistent with ms_per_step
     bins_per_step = d["config"]["streams_per_gpu"] * d["config"]["bins_per_stream"]
