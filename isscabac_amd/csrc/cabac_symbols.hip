@@ -154,7 +154,9 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
     if (w.n == 1) {
       if ((w.idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row + w.idx);
       const uint32_t wi = (w.idx >> 2) & 3u;
-      const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
+      // (two levels of selects: the chained comparison form compiled to nested branches)
+      const uint32_t w_lo = (wi & 1u) ? buf.y : buf.x, w_hi = (wi & 1u) ? buf.w : buf.z;
+      const uint32_t word = (wi & 2u) ? w_hi : w_lo;
       const uint2 g = bintab[(word >> (8 * (w.idx & 3u))) & 0xFFu];  // (values >= nq cannot be coded: undefined)
       w.cur.bits = g.x;
       w.cur.len = g.y & 0xFFu;
@@ -379,7 +381,9 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     if (n == 1) {
       if ((idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row_in + idx);
       const uint32_t wi = (idx >> 2) & 3u;
-      const uint32_t word = wi == 0 ? buf.x : wi == 1 ? buf.y : wi == 2 ? buf.z : buf.w;
+      // (two levels of selects: the chained comparison form compiled to nested branches)
+      const uint32_t w_lo = (wi & 1u) ? buf.y : buf.x, w_hi = (wi & 1u) ? buf.w : buf.z;
+      const uint32_t word = (wi & 2u) ? w_hi : w_lo;
       v = min((word >> (8 * (idx & 3u))) & 0xFFu, vmax);  // (values >= nq cannot be coded: they go out as nq - 1, like the general kernel)
       const uint2 g = bintab[v];
       bits = g.x;
