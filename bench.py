@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- encode+decode round-trip throughput of the batched CABAC engine on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config3|config5|config2] [--scaling strong|weak]
 
-One "step" = one pass of the hot path over one batch of synthetic bin streams: encode (kernel + offsets
-scan + payload gather) followed by decode, inputs already resident in HBM.  The steps are enqueued through the
-engine's asynchronous entry points (isscabac_*_batch_dev_async): the host reads nothing between kernels, so the
-figure does not depend on host wake-up latency; sizes, the capacity check and the kernel times are read after the
-closing fence.  Workload = BASELINE.json
-config 3 (1 Mi streams x 4 Ki bins, 64 contexts, SURVEY.md 8(d) generator) per GPU; with N > 1 every rank
-codes its own shard of the global stream range (streams are independent: no data-path collective,
-"weak" scaling), and the final bitstream gather to rank 0 is timed separately (gather_ms), outside `value`.
+One "step" = one pass of the hot path over the workload: encode (kernel + offsets scan + payload gather) followed by
+decode, inputs already resident in HBM.  The steps are enqueued through the engine's asynchronous entry points
+(isscabac_*_batch_dev_async): the host reads nothing between kernels, so the figure does not depend on host wake-up
+latency; sizes, the capacity check and the kernel times are read after the closing fence.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longer of the encode / decode
-kernels), its duration measured with HIP events on the launch stream inside the engine; algorithmic bytes
-follow SURVEY.md 8(d): encode reads 2 B/bin and writes P + 8 B/stream, decode reads 1 B/bin + P + 8 B/stream
-and writes 1 B/bin (P = measured payload bytes).  `cpu_baseline` times the real reference classes
-(oracle/_ref, kind "reference") or, where that build is absent, the C restatement (kind "port") on a bounded
-sample of the same workload on the host cores of this box, and -- the only place bench.py touches oracle/ -- checks
-the GPU payload of the sampled streams byte for byte against the CPU coder.  The always-on gate is the device-side
-round trip: decoded bins == input bins for every stream, decoder integrity flags all zero.
+Workloads are BASELINE.json's configurations, named by their GLOBAL shape:
+    config3   1 Mi streams x 4 Ki bins, 64 contexts                        (the shape `metric` is quoted on; default)
+    config5   8 Mi streams x 8 Ki bins, 64 contexts, 50 % bypass bins      (one GPU runs it 1 Mi streams at a time)
+    config2   64 Ki streams x 1 Ki bins, 3 contexts
+Streams are independent, so N ranks split the stream range and nothing is exchanged while coding:
+    --scaling strong   the global shape is fixed, rank r codes sharding.shard_range(S, r, N) -- the mode under which the
+                       metric's "1M streams x 4K bins" stays true for every N, and the north star's efficiency figure;
+                       the default
+    --scaling weak     every rank codes the workload's per-GPU shape (config3: 1 Mi streams; config5: 1 Mi; config2:
+                       64 Ki); the job grows with N
+`value` = bins coded by all ranks / wall time between two fences (barrier + device synchronise), MAX over ranks.  The
+final bitstream gather to rank 0 (the north star's only exchange) is timed apart (gather_ms), outside `value`; if it does
+not complete the line says "gather_ok": false and the process exits non-zero after the line is flushed.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longer of the encode / decode kernels), its
+duration measured with HIP events on the launch stream inside the engine; algorithmic bytes per launch follow SURVEY.md
+8(d): encode reads 2 B/bin and writes P + 8 B/stream, decode reads 1 B/bin + P + 8 B/stream and writes 1 B/bin (P =
+measured payload bytes of one launch).  `cpu_baseline` (rank 0) times the real reference classes (oracle/_ref, kind
+"reference") or, where that build is absent, the C restatement (kind "port") on a bounded sample of the same workload on
+the host cores of this box, and -- the only place bench.py touches oracle/ -- checks the GPU payload of the sampled
+streams byte for byte against the CPU coder.  The always-on gate is the device-side round trip: decoded bins == input
+bins for every stream, decoder integrity flags all zero.
 """
 import argparse
 import json
@@ -31,13 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+BASELINE_METRIC = "Gbin/s encode+decode round-trip, 1M streams×4K bins; bit-exact vs HM CPU"  # BASELINE.json, verbatim
 
 WORKLOADS = {
-    # name: (S, B, C, seed, ep_half)
-    "config3": (1 << 20, 4096, 64, 0xCABAC003, False),
-    "config2": (1 << 16, 1024, 3, 0xCABAC002, False),
-    "config5_per_gpu": (1 << 20, 8192, 64, 0xCABAC005, True),
+    # name: global streams, per-GPU streams of the weak mode, bins per stream, contexts, SURVEY 8(d) seed, 50 % bypass
+    "config3": dict(S=1 << 20, per_gpu=1 << 20, B=4096, C=64, seed=0xCABAC003, ep=False),
+    "config5": dict(S=8 << 20, per_gpu=1 << 20, B=8192, C=64, seed=0xCABAC005, ep=True),
+    "config2": dict(S=1 << 16, per_gpu=1 << 16, B=1024, C=3, seed=0xCABAC002, ep=False),
 }
+WORKLOADS["config5_per_gpu"] = dict(WORKLOADS["config5"], S=1 << 20)  # round-1 name: one GPU's share of config 5
+CHUNK_STREAMS = 1 << 20  # streams per launch: 1 Mi x 8 Ki bins = 8 GiB per array, so a whole config-5 share fits 288 GB
 
 
 def _cpu_worker(seed, B, C, ep, budget_s, s_first, s_step, tag, out):
@@ -72,7 +85,8 @@ def _cpu_worker(seed, B, C, ep, budget_s, s_first, s_step, tag, out):
 
 def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
     """Reference (or port) round trip on a bounded sample of the same synthetic workload: one host core (the headline
-    `value`, like the single-threaded reference), then all host cores with the streams split evenly.
+    `value`, like the single-threaded reference), then all host cores -- the reference classes with one scratch file per
+    stream (what the reference does), and the in-memory C restatement on native threads (SURVEY 8(d)'s CPU ceiling).
     gpu_payload_of(s) -> bytes of GPU-coded stream s: the first 4 096 streams (SURVEY 8(d)'s sampled subset) are also coded
     by the CPU restatement here and must match the GPU payload byte for byte (the oracle stays inside this leg)."""
     import threading
@@ -80,8 +94,8 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
     from oracle import pyoracle
     use_ref = pyoracle.have_reference()
     checked = 0
+    orc = pyoracle.Oracle()
     if gpu_payload_of is not None:
-        orc = pyoracle.Oracle()
         hb, hc = orc.synth(seed, 0, nchk, B, C, ep)
         init = np.zeros(C, np.uint8)
         for s in range(nchk):
@@ -89,7 +103,7 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
             assert gpu_payload_of(s) == want, "GPU payload of stream %d differs from the CPU coder" % s
             checked += 1
     res = []
-    _cpu_worker(seed, B, C, ep, budget_s * 0.5, 0, 256, "ref1", res)
+    _cpu_worker(seed, B, C, ep, budget_s * 0.4, 0, 256, "ref1", res)
     done, t_enc, t_dec, _wall = res[0]
     total_bins = done * B
     out = {
@@ -108,7 +122,7 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
     if ncores > 1:
         res, threads = [], []
         for i in range(ncores):  # ctypes calls release the GIL: real parallelism
-            th = threading.Thread(target=_cpu_worker, args=(seed, B, C, ep, budget_s * 0.5, 1 << 20 | i * 256, ncores * 256,
+            th = threading.Thread(target=_cpu_worker, args=(seed, B, C, ep, budget_s * 0.3, 1 << 20 | i * 256, ncores * 256,
                                                             "refm%d" % i, res))
             th.start()
             threads.append(th)
@@ -118,6 +132,17 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
         out["all_cores"] = {"value": rate / 1e9, "unit": "Gbin/s", "cores": ncores,
                             "note": "sum of the coding rates of %d concurrent threads, each with its own streams and "
                                     "scratch file" % ncores}
+        if hasattr(orc, "roundtrip_threads"):
+            # the restatement with an in-memory sink on native threads, streams split evenly: no files, no Python between
+            # streams -- the honest all-core CPU figure
+            nstreams = max(ncores * 8, int(budget_s * 0.3 * 0.03e9 * ncores / B))  # ~30 Mbin/s per core
+            nstreams = (nstreams + ncores - 1) // ncores * ncores
+            wall, ok = orc.roundtrip_threads(seed, 1 << 21, nstreams, B, C, ep, ncores)
+            assert ok, "in-memory restatement round trip failed"
+            out["all_cores_in_memory"] = {"value": nstreams * B / wall / 1e9, "unit": "Gbin/s", "cores": ncores,
+                                          "kind": "port",
+                                          "note": "C restatement, in-memory sink, %d native threads, %d streams split "
+                                                  "evenly, wall time of the slowest thread" % (ncores, nstreams)}
     return out
 
 
@@ -127,9 +152,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (debug)")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--streams", type=int, default=0, help="override the workload's stream count (global in strong "
+                                                           "mode, per GPU in weak mode)")
+    ap.add_argument("--chunk-streams", type=int, default=CHUNK_STREAMS, help="streams per kernel launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the final bitstream gather (N > 1)")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,35 +177,45 @@ def main():
     if multi:
         dist.init_process_group("nccl", device_id=dev)
 
-    from isscabac_amd import Engine, stream_bound
-    S, B, C, seed, ep = WORKLOADS[args.workload]
+    from isscabac_amd import Engine, sharding, stream_bound
+    wl = dict(WORKLOADS[args.workload])
     if args.streams:
-        S = args.streams
+        wl["S"] = wl["per_gpu"] = args.streams
+    B, C, seed, ep = wl["B"], wl["C"], wl["seed"], wl["ep"]
+    chunks = sharding.plan(wl["S"], wl["per_gpu"], rank, world, args.scaling, args.chunk_streams)
+    job_streams = sharding.job_streams(wl["S"], wl["per_gpu"], world, args.scaling)
+    my_streams = sum(hi - lo for lo, hi in chunks)
     eng = Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_profiling(True)
 
     # ---- synthetic inputs, resident in HBM before anything is timed ----------------------------------
-    s0 = rank * S  # this rank's shard of the global stream range
-    bins = torch.empty((S, B), dtype=torch.uint8, device=dev)
-    ctx = torch.empty((S, B), dtype=torch.uint8, device=dev)
-    eng.synth_dev(seed, s0, S, B, B, C, ep, bins.data_ptr(), ctx.data_ptr())
     init = np.zeros(C, np.uint8)  # (mps 0, state 0) == initByProb(0.5), cabacDemo.m:49
-    cap = S * (B // 8 + B // 16 + 64)  # 1.5 bit/bin: EP-heavy streams stay below ~1.01
-    if os.environ.get("ISSCABAC_BENCH_FULL_CAP"):  # timing-only ablation builds emit garbage of any size
-        cap = S * stream_bound(B)
-    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
-    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
-    out = torch.empty((S, B), dtype=torch.uint8, device=dev)
-    status = torch.empty((S,), dtype=torch.int32, device=dev)
+    bufs = []
+    for lo, hi in chunks:
+        S = hi - lo
+        cap = S * (B // 8 + B // 16 + 64)  # 1.5 bit/bin: EP-heavy streams stay below ~1.01
+        if os.environ.get("ISSCABAC_BENCH_FULL_CAP"):  # timing-only ablation builds emit garbage of any size
+            cap = S * stream_bound(B)
+        b = dict(S=S, lo=lo, cap=cap,
+                 bins=torch.empty((S, B), dtype=torch.uint8, device=dev),
+                 ctx=torch.empty((S, B), dtype=torch.uint8, device=dev),
+                 payload=torch.empty(cap, dtype=torch.uint8, device=dev),
+                 offsets=torch.empty(S + 1, dtype=torch.int64, device=dev),
+                 out=torch.empty((S, B), dtype=torch.uint8, device=dev),
+                 status=torch.empty((S,), dtype=torch.int32, device=dev))
+        eng.synth_dev(seed, lo, S, B, B, C, ep, b["bins"].data_ptr(), b["ctx"].data_ptr())
+        bufs.append(b)
 
     def step():
-        # encode (kernel + offsets scan + payload gather) and decode are only enqueued: the GPU runs the steps back to back,
-        # the host reads nothing in between (the decoder bounds its reads by the buffer's capacity; streams are delimited by
-        # the offsets on the device).  Payload size, capacity check and kernel times are collected after the fence.
-        eng.encode_dev_async(bins.data_ptr(), ctx.data_ptr(), S, B, B, init, payload.data_ptr(), cap, offsets.data_ptr())
-        eng.decode_dev_async(payload.data_ptr(), cap, offsets.data_ptr(), ctx.data_ptr(), S, B, B, init, out.data_ptr(),
-                             status.data_ptr())
+        # encode (kernel + offsets scan + payload gather) and decode are only enqueued: the GPU runs the launches back to
+        # back, the host reads nothing in between (the decoder bounds its reads by the buffer's capacity; streams are
+        # delimited by the offsets on the device).  Sizes, capacity check and kernel times are collected after the fence.
+        for b in bufs:
+            eng.encode_dev_async(b["bins"].data_ptr(), b["ctx"].data_ptr(), b["S"], B, B, init, b["payload"].data_ptr(),
+                                 b["cap"], b["offsets"].data_ptr())
+            eng.decode_dev_async(b["payload"].data_ptr(), b["cap"], b["offsets"].data_ptr(), b["ctx"].data_ptr(), b["S"], B,
+                                 B, init, b["out"].data_ptr(), b["status"].data_ptr())
 
     def fence():
         if multi:
@@ -194,9 +233,12 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    total = eng.sync()  # payload bytes of the last step; raises if the payload buffer was too small
+    eng.sync()  # raises if a payload buffer was too small (reports the most recent encode; the others are checked below)
     kms, klaunches = eng.kernel_ms_mean()  # HIP events on the launch stream around every kernel of the timed steps
-    assert klaunches["encode"] == args.steps and klaunches["decode"] == args.steps
+    assert klaunches["encode"] == args.steps * len(bufs) and klaunches["decode"] == args.steps * len(bufs)
+    totals = [int(b["offsets"][-1]) for b in bufs]
+    for b, tot in zip(bufs, totals):
+        assert tot <= b["cap"], "payload buffer too small"
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,65 +247,74 @@ def main():
     # ---- correctness gate (outside the timed region): the round trip must reproduce every bin of every stream --------
     verified = None
     if not args.no_verify:
-        assert int(status.abs().sum()) == 0, "decoder integrity flags set"
-        assert torch.equal(out, bins), "decoded bins differ from the input"
+        for b in bufs:
+            assert int(b["status"].abs().sum()) == 0, "decoder integrity flags set"
+            assert torch.equal(b["out"], b["bins"]), "decoded bins differ from the input"
         verified = True
 
     # ---- final bitstream gather to rank 0 (north_star's only exchange), timed apart -----------------------
-    gather_ms = None
-    gather_hung = False
-    if multi:
-        # runs on a helper thread under a deadline: a stuck exchange must cost the run its gather_ms, not its result line
+    gather_ms, gather_ok, gather_bytes = None, None, None
+    if multi and not args.no_gather:
+        # runs on a helper thread under a deadline: a stuck exchange must not cost the run its result line -- it costs
+        # the run its exit status ("gather_ok": false, non-zero exit after the line is out)
         import threading
         box = {}
 
         def do_gather():
             try:
-                from isscabac_amd import sharding
                 torch.cuda.set_device(local_rank)  # the current device is per thread
+                p_mine, o_mine = sharding.concat_launches([(b["payload"][:t], b["offsets"]) for b, t in zip(bufs, totals)])
                 fence()
                 g0 = time.perf_counter()
-                p_all, o_all = sharding.gather_payload(payload[:total], offsets, dist)
+                p_all, o_all = sharding.gather_payload(p_mine, o_mine, dist)
                 fence()
                 box["ms"] = (time.perf_counter() - g0) * 1e3
                 if rank == 0:
-                    assert int(o_all[-1]) == p_all.numel() and o_all.numel() == world * S + 1
+                    assert int(o_all[-1]) == p_all.numel() and o_all.numel() == job_streams + 1
+                    box["bytes"] = int(p_all.numel())
                 del p_all, o_all
-            except Exception as exc:  # the gather is reported apart from `value`; never let it take the run down
-                sys.stderr.write("bitstream gather failed: %r\n" % (exc,))
+                box["ok"] = True
+            except Exception as exc:
+                sys.stderr.write("bitstream gather failed (rank %d): %r\n" % (rank, exc))
 
         th = threading.Thread(target=do_gather, daemon=True)
         th.start()
-        th.join(float(os.environ.get("ISSCABAC_GATHER_DEADLINE_S", "60")))
-        gather_hung = th.is_alive()
-        if gather_hung:
+        th.join(float(os.environ.get("ISSCABAC_GATHER_DEADLINE_S", "120")))
+        if th.is_alive():
             sys.stderr.write("bitstream gather did not finish before its deadline (rank %d)\n" % rank)
-        gather_ms = box.get("ms")
+        gather_ok = bool(box.get("ok"))
+        gather_ms, gather_bytes = box.get("ms"), box.get("bytes")
 
+    rc = 0 if gather_ok in (None, True) else 3
     if rank == 0:
-        bins_total = float(S) * B * world * args.steps
+        bins_total = float(job_streams) * B * args.steps
         value = bins_total / elapsed / 1e9
-        P = float(total)
+        S_l = my_streams / float(len(bufs))  # streams and payload bytes of one launch (the chunks are equal-sized)
+        P_l = sum(totals) / float(len(bufs))
         enc_ms, dec_ms = kms["encode"], kms["decode"]
-        enc_bytes = 2.0 * S * B + P + 8.0 * S
-        dec_bytes = 2.0 * S * B + P + 8.0 * S
+        enc_bytes = 2.0 * S_l * B + P_l + 8.0 * S_l
+        dec_bytes = 2.0 * S_l * B + P_l + 8.0 * S_l
         if enc_ms >= dec_ms:
             kname, kbytes, kms_avg = "k_encode", enc_bytes, enc_ms
         else:
             kname, kbytes, kms_avg = "k_decode", dec_bytes, dec_ms
         achieved = kbytes / (kms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                ent = tj.get(args.workload, {}).get(kname)
-                if ent and not args.streams:
-                    traffic = ent["hbm_bytes_per_launch"]
+        if os.path.exists(tpath) and not args.streams and bufs[0]["S"] == CHUNK_STREAMS:
+            try:  # per-launch HBM bytes of this kernel on this launch shape, from the committed rocprofv3 --pmc passes
+                ent = json.load(open(tpath)).get(args.workload.replace("_per_gpu", ""), {}).get(kname)
+                if ent:
+                    traffic, traffic_source = ent["hbm_bytes_per_launch"], ent.get("source")
             except Exception:
                 traffic = None
+        shape = "%d streams x %d bins, %d contexts%s" % (job_streams, B, C, ", 50% bypass" if ep else "")
+        if args.workload == "config3" and job_streams == 1 << 20:
+            metric = BASELINE_METRIC
+        else:
+            metric = "Gbin/s encode+decode round-trip, %s; bit-exact vs HM CPU" % shape
         line = {
-            "metric": "Gbin/s encode+decode round-trip, 1M streams\u00d74K bins; bit-exact vs HM CPU",  # BASELINE.json, verbatim
+            "metric": metric,
             "value": value,
             "unit": "Gbin/s",
             "n_gpus": world,
@@ -271,38 +322,44 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d streams x %d bins per GPU, %d contexts%s, SURVEY 8(d) generator seed 0x%X"
-                                   % (args.workload, S, B, C, ", 50% bypass" if ep else "", seed),
-                       "streams_per_gpu": S, "bins_per_stream": B, "contexts": C,
-                       "payload_bytes_per_gpu": int(total), "bits_per_bin": 8.0 * P / (float(S) * B)},
+            "config": {"workload": "%s: %s in all (%s scaling), %d streams on each of %d GPU%s in %d launch%s of <= %d "
+                                   "streams, SURVEY 8(d) generator seed 0x%X"
+                                   % (args.workload, shape, args.scaling, my_streams, world, "s" if world > 1 else "",
+                                      len(bufs), "es" if len(bufs) > 1 else "", args.chunk_streams, seed),
+                       "streams_total": job_streams, "streams_per_gpu": my_streams, "launches_per_step": len(bufs),
+                       "bins_per_stream": B, "contexts": C, "payload_bytes_per_gpu": int(sum(totals)),
+                       "bits_per_bin": 8.0 * sum(totals) / (float(my_streams) * B)},
             "verified_bit_exact": verified,
             "kernels_ms": kms,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": kbytes, "ms_per_launch": kms_avg},
             "gather_ms": gather_ms,
+            "gather_ok": gather_ok,
+            "gather_bytes": gather_bytes,
         }
-        if args.cpu_seconds > 0 and world == 1:
-            nchk = min(4096, S)
-            off = offsets[:nchk + 1].cpu().numpy().astype(np.uint64)
-            head = payload[:int(off[-1])].cpu().numpy()  # the sampled streams' bytes in one copy
+        if args.cpu_seconds > 0:
+            b0 = bufs[0]  # rank 0's first launch starts at global stream 0 in both modes
+            nchk = min(4096, b0["S"])
+            off = b0["offsets"][:nchk + 1].cpu().numpy().astype(np.uint64)
+            head = b0["payload"][:int(off[-1])].cpu().numpy()  # the sampled streams' bytes in one copy
 
             def gpu_payload_of(s):
                 return head[int(off[s]):int(off[s + 1])].tobytes()
 
             line["cpu_baseline"] = cpu_baseline(seed, B, C, ep, args.cpu_seconds,
                                                 None if args.no_verify else gpu_payload_of, nchk)
-        elif args.cpu_seconds > 0:
-            line["cpu_baseline"] = None
         print(json.dumps(line))
-    if gather_hung:
         sys.stdout.flush()
-        os._exit(0)  # the exchange is stuck inside the process group: leave without waiting for it
+    if rc:
+        sys.stderr.flush()
+        os._exit(rc)  # the exchange is stuck inside the process group: leave, visibly failed, without waiting for it
     if multi:
+        dist.barrier()  # the other ranks wait here while rank 0 runs its CPU leg
         dist.destroy_process_group()
 
 

@@ -346,7 +346,11 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   // doubled states q = m_ucState << 1, four per dword
   {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
-    const uint32_t ngrp = (a.nctx + 3) / 4;
+    // every group of the wave's state image, not only ceil(nctx / 4): a ctx byte in [nctx, image size) passes
+    // is_ctx_byte() and must find the reference's default ContextModel() (mps 1, state 0: the C ABI pads ctx_init
+    // with it), never a stale LDS byte -- a stale 0xFC..0xFF would be state 63, whose LPS of 2 shifts 7 bits per bin
+    // and overruns the slot bound of 6
+    constexpr uint32_t ngrp = WL::SB / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   EncStatesFor stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
@@ -548,7 +552,11 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   // doubled states q = m_ucState << 1, four per dword
   {
     uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
-    const uint32_t ngrp = (a.nctx + 3) / 4;
+    // every group of the wave's state image, not only ceil(nctx / 4): a ctx byte in [nctx, image size) passes
+    // is_ctx_byte() and must find the reference's default ContextModel() (mps 1, state 0: the C ABI pads ctx_init
+    // with it), never a stale LDS byte -- a stale 0xFC..0xFF would be state 63, whose LPS of 2 shifts 7 bits per bin
+    // and overruns the slot bound of 6
+    constexpr uint32_t ngrp = WL::SB / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   StatesFor<true> stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};

@@ -17,6 +17,34 @@ def shard_range(n_streams, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def chunk_ranges(lo, hi, chunk):
+    """[lo, hi) cut into consecutive launches of at most `chunk` streams (what fits one GPU's HBM at a time)."""
+    lo, hi, chunk = int(lo), int(hi), int(chunk)
+    assert chunk > 0 and hi >= lo
+    return [(a, min(a + chunk, hi)) for a in range(lo, hi, chunk)]
+
+
+def plan(global_streams, per_gpu_streams, rank, world, scaling, chunk):
+    """Which global streams `rank` of `world` codes, as a list of (first, last + 1) launches.
+
+    scaling == "strong": the workload is `global_streams` streams whatever the number of GPUs; rank r takes the
+    contiguous block shard_range(global_streams, r, world) (global order = concatenation of the shards).
+    scaling == "weak": every GPU codes `per_gpu_streams` streams; rank r's block starts at r * per_gpu_streams (the
+    job grows with the number of GPUs).  Either way the block is run `chunk` streams at a time."""
+    if scaling == "strong":
+        lo, hi = shard_range(global_streams, rank, world)
+    elif scaling == "weak":
+        lo, hi = rank * int(per_gpu_streams), (rank + 1) * int(per_gpu_streams)
+    else:
+        raise ValueError("scaling must be 'strong' or 'weak', not %r" % (scaling,))
+    return chunk_ranges(lo, hi, chunk)
+
+
+def job_streams(global_streams, per_gpu_streams, world, scaling):
+    """streams the whole job codes per step"""
+    return int(global_streams) if scaling == "strong" else int(per_gpu_streams) * int(world)
+
+
 def global_offsets(shard_offsets, shard_sizes):
     """Stitch per-rank offsets (each starting at 0, S_r + 1 entries) into the global S + 1 offsets array."""
     out = [np.zeros(1, np.uint64)]
@@ -27,6 +55,20 @@ def global_offsets(shard_offsets, shard_sizes):
         out.append(off[1:] + np.uint64(base))
         base += int(size)
     return np.concatenate(out)
+
+
+def concat_launches(parts):
+    """One rank's consecutive launches [(payload, offsets), ...] (torch tensors: uint8 payload of exactly offsets[-1]
+    bytes, int64 offsets with S_i + 1 entries starting at 0) as one (payload, offsets) pair in stream order."""
+    import torch
+    if len(parts) == 1:
+        return parts[0]
+    base, offs = 0, [torch.zeros(1, dtype=torch.int64, device=parts[0][1].device)]
+    for payload, offsets in parts:
+        assert int(offsets[-1]) == payload.numel()
+        offs.append(offsets[1:] + base)
+        base += payload.numel()
+    return torch.cat([p for p, _ in parts]), torch.cat(offs)
 
 
 def gather_payload(payload, offsets, dist, root=0):

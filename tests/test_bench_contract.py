@@ -22,9 +22,11 @@ def test_bench_json_line_contract():
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert isinstance(d[key], typ), (key, d[key])
-    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    # the BASELINE.json metric string is only true for its own shape: a reduced run names the shape it really coded
+    assert d["metric"] != json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] and "8192 streams x 4096 bins" in d["metric"]
+    assert d["gather_ok"] is None and d["gather_ms"] is None  # one rank: nothing to gather
     assert d["unit"] == "Gbin/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -35,8 +37,19 @@ def test_bench_json_line_contract():
     assert c["gpu_streams_checked_byte_exact"] == 4096
     assert d["verified_bit_exact"] is True
     # value = bins / wall time, consistent with ms_per_step
-    bins_per_step = d["config"]["streams_per_gpu"] * d["config"]["bins_per_stream"]
+    assert d["config"]["streams_total"] == 8192 and d["config"]["launches_per_step"] == 1
+    bins_per_step = d["config"]["streams_total"] * d["config"]["bins_per_stream"]
     assert abs(d["value"] - bins_per_step / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+
+
+def test_default_metric_string_is_baseline_json_verbatim():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.BASELINE_METRIC == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    w = bench.WORKLOADS
+    assert (w["config3"]["S"], w["config3"]["B"], w["config3"]["C"]) == (1 << 20, 4096, 64)
+    assert (w["config5"]["S"], w["config5"]["B"], w["config5"]["ep"]) == (8 << 20, 8192, True)
+    assert (w["config2"]["S"], w["config2"]["B"], w["config2"]["C"]) == (1 << 16, 1024, 3)
 
 
 def test_graft_entry_points_exist():

@@ -573,6 +573,33 @@ def test_out_of_range_context_bytes_do_not_disturb_other_streams(engine, oracle)
             assert status[s] == 0 and (dec[s] == bins[s]).all(), s
 
 
+def test_contexts_between_nctx_and_the_state_image_are_default_models(engine, oracle):
+    """ctx bytes in [nctx, 64) pass the kernels' plain-path test (the state image holds 64 contexts).  They must find
+    the reference's default ContextModel() (mps 1, state 0: ref CABAC/ContextModel.cpp:54, what an un-initialised
+    context of the reference's 1000-entry array is), never a stale LDS byte left by an earlier launch -- a stale 0xFF is
+    state 63, whose LPS of 2 shifts 7 bits per bin and would overrun the 6-bit slot bound into the next stream."""
+    rng = np.random.default_rng(77)
+    # 1. leave 0xFF bytes all over the CUs' LDS: a batch of bypass-only streams (the ctx tiles are full of 0xFF)
+    S0, B0 = 4096, 512
+    engine.encode(rng.integers(0, 2, (S0, B0)).astype(np.uint8), np.full((S0, B0), 0xFF, np.uint8), np.zeros(1, np.uint8))
+    # 2. streams that use contexts the caller did not initialise, always coding the LPS of the default model
+    for C in (1, 3, 5, 40):
+        S, B = 1024, 640
+        init = rng.integers(0, 126, C).astype(np.uint8)
+        padded = np.concatenate([init, np.ones(64 - C, np.uint8)])  # what the engine pads with
+        ctx = rng.integers(0, 64, (S, B)).astype(np.uint8)
+        ctx[::2] = rng.integers(C, 64, (S // 2, B))  # every other stream: only un-initialised contexts
+        bins = rng.integers(0, 2, (S, B)).astype(np.uint8)
+        bins[::4] = 0  # default mps is 1: all-LPS streams, the worst case for the slot bound
+        want_p, want_o = oracle.encode_batch(bins, ctx, padded)
+        got_p, got_o = engine.encode(bins, ctx, init)
+        assert (got_o == want_o).all(), C
+        assert got_p.tobytes() == want_p.tobytes(), C
+        assert int(np.diff(got_o.astype(np.int64)).max()) <= (6 * B + 9 + 7) // 8
+        dec, status = engine.decode(want_p, want_o, ctx, init)
+        assert (status == 0).all() and (dec == bins).all(), C
+
+
 def test_garbage_offsets_in_device_memory_are_clipped_not_followed(engine):
     """the device-pointer decode call cannot validate offsets that live in device memory: whatever they say, the kernels
     stay inside the payload buffer (streams clipped to it), flag the streams and return"""
