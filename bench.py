@@ -157,6 +157,8 @@ def main():
                                                            "mode, per GPU in weak mode)")
     ap.add_argument("--chunk-streams", type=int, default=CHUNK_STREAMS, help="streams per kernel launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency"),
+                    help="kernel instance (isscabac_set_tuning); auto picks by launch size")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final bitstream gather (N > 1)")
     args = ap.parse_args()
@@ -188,6 +190,7 @@ def main():
     eng = Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_profiling(True)
+    eng.set_tuning(args.tuning)
 
     # ---- synthetic inputs, resident in HBM before anything is timed ----------------------------------
     init = np.zeros(C, np.uint8)  # (mps 0, state 0) == initByProb(0.5), cabacDemo.m:49

@@ -63,6 +63,8 @@ int isscabac_create(int device, isscabac_engine **out) {
     return rc;
   }
   e->stream = e->own_stream;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->num_cus = cus;
   *out = e;
   return ISSCABAC_OK;
 }
@@ -88,6 +90,14 @@ void isscabac_destroy(isscabac_engine *e) {
 }
 
 const char *isscabac_last_error(const isscabac_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int isscabac_set_tuning(isscabac_engine *e, int mode) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (mode != ISSCABAC_TUNE_AUTO && mode != ISSCABAC_TUNE_THROUGHPUT && mode != ISSCABAC_TUNE_LATENCY)
+    return fail(e, ISSCABAC_ERR_ARG, "isscabac_set_tuning: unknown mode %d", mode);
+  e->tuning = mode;
+  return ISSCABAC_OK;
+}
 
 int isscabac_set_stream(isscabac_engine *e, void *hip_stream) {
   if (!e) return ISSCABAC_ERR_ARG;
@@ -147,6 +157,12 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   sh->nbins = nbins;
   sh->pitch = pitch;
   sh->nctx = (uint32_t)nctx;
+  // Kernel instance.  The throughput instance hides its three dependent LDS round trips per bin behind the other waves
+  // of the SIMD and needs four of them for that (4 workgroups x 4 waves per CU).  Measured on MI355X (tools/s_sweep.py,
+  // profiles/r02): with two waves per SIMD (128 Ki streams) the latency-oriented instance is 5 % faster, with one 17 %;
+  // with four or more the throughput instance wins by 5 %.  The switch sits at 2.5 waves per SIMD.
+  sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY ||
+                (e->tuning == ISSCABAC_TUNE_AUTO && 2 * S <= 5ull * (uint64_t)e->num_cus * 4 * 64);
   for (int c = 0; c < nctx; c++) {
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     sh->ctx_init[c] = ctx_init[c];

@@ -13,6 +13,8 @@
 // the engine handle of include/isscabac.h (host side only)
 struct isscabac_engine {
   int device = 0;
+  int num_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+  int tuning = 0;     // ISSCABAC_TUNE_*
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
   std::string err;
@@ -65,6 +67,7 @@ struct BatchShape {
   uint32_t nbins;    // bins per stream when d_nbins is null (<= pitch)
   uint32_t pitch;    // bytes between consecutive streams' rows, multiple of 16
   uint32_t nctx;     // contexts (1..255)
+  bool latency;      // run the latency-oriented kernel instance (few waves per SIMD), see isscabac_set_tuning
   uint8_t ctx_init[256];
 };
 

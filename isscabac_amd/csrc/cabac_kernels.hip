@@ -184,6 +184,17 @@ struct BinOfWord {
   }
 };
 
+// f(BinOfWord<k & 3>{w2, w1}) for a loop counter k that is a constant once the loop is unrolled
+template <class F>
+__device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1, F &&f) {
+  switch (k & 3) {
+    case 0: return f(BinOfWord<0>{w2, w1});
+    case 1: return f(BinOfWord<1>{w2, w1});
+    case 2: return f(BinOfWord<2>{w2, w1});
+    default: return f(BinOfWord<3>{w2, w1});
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // context-state policies (see cabac_lane.h: States)
 // ------------------------------------------------------------------------------------------------
@@ -241,6 +252,16 @@ struct LdsStates {
   __device__ __forceinline__ uint32_t next_q(uint32_t q, uint32_t lps_mask, uint32_t entry) const {
     return NEXT16 ? next_state_q16(lps_mask, entry) : next_state_q(q, lps_mask, entry);
   }
+  // lookups of the latency-oriented steps (cabac_lane.h: enc_bin_lat_acc / dec_bin_lat): everything by q alone
+  __device__ __forceinline__ uint32_t lps_row_mem(uint32_t q) const {  // the state's 4-byte rangeTabLps row
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(q & 0xFCu));
+  }
+  __device__ __forceinline__ uint32_t next_lps_mem(uint32_t q) const { return next_path_mem(kTabPathOff + q); }
+  __device__ __forceinline__ uint32_t next_mps_mem(uint32_t q) const { return next_path_mem(kTabPathOff + 1u + q); }
+  // state addresses as plain 32-bit LDS addresses (the latency-oriented paths compare them)
+  __device__ __forceinline__ uint32_t addr32_of(const CtxQuad &z, int k) const { return (uint32_t)(uintptr_t)addr_of(z, k); }
+  __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return *(const lds_u8 *)(uintptr_t)a; }
+  __device__ __forceinline__ void store_at(uint32_t a, uint32_t p) const { *(lds_u8 *)(uintptr_t)a = (uint8_t)p; }
 };
 // ------------------------------------------------------------------------------------------------
 // byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
@@ -316,7 +337,9 @@ template <bool XBAR>
 using StatesFor = LdsStates<XBAR>;
 using EncStatesFor = LdsStates<true, true>;
 
-template <int CM>
+// LAT: the latency-oriented instance for launches that leave fewer than four waves on a SIMD (see enc_bin_lat_acc):
+// the same bytes, three more VALU instructions per bin, one LDS round trip per bin instead of three behind each other
+template <int CM, bool LAT>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -390,7 +413,33 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const uint4 wc = Tile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
-        if (full && !hi) {
+        if (LAT && full && !hi) {
+          // every lane codes 16 context bins.  The state of bin k + 1 is read before the successor of bin k is stored
+          // (after the store of bin k - 1: LDS operations of a wave complete in order) and replaced by that successor
+          // in a register when both bins name the same context
+          EncWordAcc acc;
+          CtxQuad z = stx.prep4(wc.x);
+          uint32_t at = stx.addr32_of(z, 0), at_prev = 0, nx_prev = 0;
+          uint32_t qld = stx.load_at(at);
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+            const uint32_t q = (k > 0 && at == at_prev) ? nx_prev : qld;
+            uint32_t at_next = 0;
+            if (k < 15) {
+              if ((k & 3) == 3) z = stx.prep4(word_of(wc, (k + 1) >> 2));
+              at_next = stx.addr32_of(z, (k + 1) & 3);
+              qld = stx.load_at(at_next);
+            }
+            nx_prev = with_bin_of_word(k, w2, w1, [&](auto bin) { return enc_bin_lat_acc(e, acc, (k & 3) == 0, bin, at, q, stx); });
+            at_prev = at;
+            at = at_next;
+            if ((k & 3) == 3) {
+              enc_word_close(e, acc);
+              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+            }
+          }
+        } else if (full && !hi) {
           // every lane codes 16 context bins: convergent, tables through the crossbar
           EncWordAcc acc;
 #pragma unroll
@@ -523,7 +572,7 @@ constexpr bool kDecNT = true;  // decode kernel: ctx loads and bin stores are st
 #define ISSCABAC_DEC_ROLLED 0  // 1: loop over the chunk's four words, 0: all 16 bins unrolled (1% faster, 113 VGPRs)
 #endif
 
-template <int CM>
+template <int CM, bool LAT>
 __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -657,6 +706,14 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             // Otherwise -- bypass bins in the chunk, or streams that end inside it -- every lane takes its own branch
             // under the exec mask: context bin, bypass bin, or nothing (its output reads 0) once its stream is over.
             const bool plain = full && !hi;
+            // latency-oriented instance (see dec_bin_lat): the state of the next bin is loaded one bin ahead, the
+            // successor forwarded in a register for a repeated context
+            uint32_t at = 0, at_prev = 0, nx_prev = 0, qld = 0;
+            CtxQuad zl = stx.prep4(wc.x);
+            if (LAT && plain) {
+              at = stx.addr32_of(zl, 0);
+              qld = stx.load_at(at);
+            }
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #else
@@ -679,7 +736,22 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #endif
               dec_topup_nocheck(d, src);
               const CtxQuad z = stx.prep4(cw);
-              if (plain) {
+              if (LAT && plain) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const uint32_t q = (4 * g + k > 0 && at == at_prev) ? nx_prev : qld;
+                  uint32_t at_next = 0;
+                  if (4 * g + k < 15) {
+                    if (k == 3) zl = stx.prep4(word_of(wc, (g + 1) & 3));
+                    at_next = stx.addr32_of(zl, (k + 1) & 3);
+                    qld = stx.load_at(at_next);
+                  }
+                  if (k == 3) dec_guard(d, src, 7);
+                  ob = collect_bin(ob, dec_bin_lat(d, at, q, stx, nx_prev));
+                  at_prev = at;
+                  at = at_next;
+                }
+              } else if (plain) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 7);
@@ -977,50 +1049,52 @@ static size_t coder_lds_bytes() {
   return kTabBytes + waves_per_block(CM) * WaveLds<CM>::BYTES;
 }
 
-template <int CM>
+template <int CM, bool LAT>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
   const size_t lds = coder_lds_bytes<CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   // LdsStates<.., NEXT16> addresses its table by absolute LDS address: the dynamic LDS must start at 0
   static int static_lds = -1;
   if (static_lds < 0) {
     hipFuncAttributes fa;
-    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode<CM>));
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode<CM, LAT>));
     if (err != hipSuccess) return err;
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_encode<CM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  hipLaunchKernelGGL((k_encode<CM, LAT>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
-template <int CM>
+template <int CM, bool LAT>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   const size_t lds = coder_lds_bytes<CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   static int static_lds = -1;  // absolute LDS addresses, as in run_encode
   if (static_lds < 0) {
     hipFuncAttributes fa;
-    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode<CM>));
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode<CM, LAT>));
     if (err != hipSuccess) return err;
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_decode<CM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  hipLaunchKernelGGL((k_decode<CM, LAT>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
-#define ISSCABAC_DISPATCH(FN, ARGS)             \
-  do {                                          \
-    if (sh.nctx <= 64) return FN<1>(ARGS, stream); \
-    if (sh.nctx <= 128) return FN<3>(ARGS, stream); \
-    return FN<2>(ARGS, stream);                 \
+// sh.latency selects the latency-oriented instance (<= 64 contexts only: the bigger state images run single-wave
+// workgroups whose occupancy is set by LDS, not by the number of streams)
+#define ISSCABAC_DISPATCH(FN, ARGS)                                      \
+  do {                                                                   \
+    if (sh.nctx <= 64) return sh.latency ? FN<1, true>(ARGS, stream) : FN<1, false>(ARGS, stream); \
+    if (sh.nctx <= 128) return FN<3, false>(ARGS, stream);               \
+    return FN<2, false>(ARGS, stream);                                   \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,

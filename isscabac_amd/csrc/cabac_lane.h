@@ -273,6 +273,29 @@ CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
   e.W += (int32_t)g.S;
 }
 
+// Latency-oriented form of enc_bin_at_mem_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides
+// an LDS round trip, so none may sit on a bin-to-bin dependency chain).  The caller hands in the state q -- loaded one
+// bin ahead, with the previous bin's successor forwarded in a register when both bins use the same context -- and both
+// lookups depend on q only: the successor by (q, bin) and the state's whole 4-byte rangeTabLps row, whose column is
+// picked in a register (lps_of), so the range -> LPS -> range recurrence never touches memory.  Same arithmetic, same
+// results.  Returns the successor state (what the caller forwards).
+// States policy: lps_row_mem(q) -> the row, next_mem(q | bin), store_at.
+template <class States, class Addr, class Bin>
+CABAC_HD uint32_t enc_bin_lat_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, uint32_t q, States &st) {
+  const uint32_t nx = st.next_mem(bin.or_q(q));
+  const uint32_t row = st.lps_row_mem(q);
+  st.store_at(at, nx);
+  const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
+  const uint32_t lps = lps_of(row, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t n = clz32(r) - 23u;
+  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
+  g.S = (first ? 0u : g.S) + n;
+  e.range = r << n;
+  return nx;
+}
+
 template <class States>
 CABAC_HD void enc_bin(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
   enc_bin_at(e, BinB1{b1}, st.addr(ctx), st);
@@ -576,6 +599,28 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   d.range = r << n;
   d.sh -= (int32_t)n;
   return idx;
+}
+// Latency-oriented form of dec_bin_at_mem (see enc_bin_lat_acc): q comes from the caller (loaded one bin ahead, the
+// previous successor forwarded for a repeated context); the row and BOTH successors are fetched as soon as q is known,
+// so the decision needs no lookup behind it and the next bin's state is one select away.  nx receives the successor.
+// States policy: lps_row_mem(q), next_lps_mem(q), next_mps_mem(q), store_at.
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_lat(DecCore &d, Addr at, uint32_t q, States &st, uint32_t &nx) {
+  const uint32_t row = st.lps_row_mem(q);
+  const uint32_t nx_l = st.next_lps_mem(q), nx_m = st.next_mps_mem(q);
+  const uint32_t lps = lps_of(row, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  uint32_t diff;
+  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
+  nx = mps_path ? nx_m : nx_l;
+  st.store_at(at, nx);
+  const uint32_t r = mps_path ? rmps : lps;
+  const uint32_t n = clz32(r) - 23u;
+  d.v = mps_path ? d.v : diff;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return q + (uint32_t)mps_path;  // low two bits = (mps, path), as dec_bin_at_mem returns them
 }
 // collected (mps, path) pairs -> the collect_bin() format: bin = mps ^ !path at the odd bits, even bits 0
 CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return ~(acc ^ (acc << 1)) & 0xAAAAAAAAu; }

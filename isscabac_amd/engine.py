@@ -85,6 +85,7 @@ def _load():
     L.isscabac_last_error.argtypes = [_vp]
     L.isscabac_last_error.restype = C.c_char_p
     L.isscabac_set_stream.argtypes = [_vp, _vp]
+    L.isscabac_set_tuning.argtypes = [_vp, C.c_int]
     L.isscabac_init_by_prob.argtypes = [_f64p, C.c_int, _u8p]
     L.isscabac_init_by_state.argtypes = [_f64p, C.c_int, _u8p]
     L.isscabac_stream_bound.argtypes = [C.c_uint32]
@@ -205,6 +206,11 @@ class Engine:
     def set_stream(self, hip_stream):
         """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 = engine's own."""
         self._check(self._L.isscabac_set_stream(self._h, _vp(hip_stream or 0)))
+
+    def set_tuning(self, mode):
+        """mode: 'auto' | 'throughput' | 'latency' (or the ISSCABAC_TUNE_* integer): which kernel instance runs."""
+        m = {"auto": 0, "throughput": 1, "latency": 2}.get(mode, mode)
+        self._check(self._L.isscabac_set_tuning(self._h, int(m)))
 
     def set_profiling(self, on):
         self._check(self._L.isscabac_set_profiling(self._h, int(bool(on))))

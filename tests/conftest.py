@@ -51,9 +51,12 @@ def golden():
     return doc
 
 
-@pytest.fixture(scope="session")
-def engine():
-    """The HIP engine through its C ABI (GPU tests only)."""
+@pytest.fixture(scope="session", params=["throughput", "latency"])
+def engine(request):
+    """The HIP engine through its C ABI (GPU tests only), once per kernel instance: the test batches are small, so under
+    automatic tuning every one of them would run the latency-oriented instance only."""
     import torch  # noqa: F401  (load torch's HIP runtime first so both share one libamdhip64)
     from isscabac_amd import Engine
-    return Engine(device=0)
+    eng = Engine(device=0)
+    eng.set_tuning(request.param)
+    return eng

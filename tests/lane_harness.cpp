@@ -44,6 +44,10 @@ struct HostStates {
   // the byte tables of the kernels' fast paths (cabac_kernels.hip: LdsStates::lps_mem / next_mem / next_lps_mem)
   uint32_t lps_mem(uint32_t q, uint32_t range) const { return (kLpsRow[q >> 2] >> (8 * ((range >> 6) & 3u))) & 0xFFu; }
   uint32_t next_mem(uint32_t q_or_bin) const { return next_state_by_bin(q_or_bin >> 1, q_or_bin & 1u, kTransLps[q_or_bin >> 2]); }
+  // ... and of the latency-oriented instance (LdsStates::lps_row_mem / next_lps_mem / next_mps_mem)
+  uint32_t lps_row_mem(uint32_t q) const { return kLpsRow[q >> 2]; }
+  uint32_t next_lps_mem(uint32_t q) const { return next_path_mem(q); }
+  uint32_t next_mps_mem(uint32_t q) const { return next_path_mem(q + 1u); }
   uint32_t path_index(uint32_t q) const { return q; }
   uint32_t next_path_mem(uint32_t q_plus_path) const {  // path 1 = MPS
     return (next_state_entry16(q_plus_path >> 1, kTransLps[q_plus_path >> 2]) >> (8 * (1u - (q_plus_path & 1u)))) & 0xFFu;
@@ -125,6 +129,9 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
                         int flush_every, uint8_t *out, size_t cap, uint8_t *ctx_final, int *max_w) {
   const bool any = flush_every < 0;
   if (any) flush_every = -flush_every;
+  // 19: the latency-oriented instance of that path: state read one bin ahead, successor forwarded for a repeated context
+  const bool lat = flush_every == 19;
+  if (lat) flush_every = 18;
   // 18: the kernel's plain path -- an aligned word of four context bins adds to `low` once (EncWordAcc / enc_word_close)
   const bool wordacc = flush_every == 18;
   if (wordacc) flush_every = 17;
@@ -142,7 +149,22 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
         ctx[i + 3] != kBypass) {
       EncWordAcc acc;
-      for (int k = 0; k < 4; k++) enc_bin_at_mem_acc(e, acc, k == 0, HostBin{bins[i + k]}, st.addr(ctx[i + k]), st);
+      if (lat) {  // the kernel's order: read bin k + 1's state, then store bin k's successor, forward on equal addresses
+        uint32_t at = st.addr(ctx[i]), at_prev = 0, nx_prev = 0, qld = st.load_at(at);
+        for (int k = 0; k < 4; k++) {
+          const uint32_t q = (k > 0 && at == at_prev) ? nx_prev : qld;
+          uint32_t at_next = 0;
+          if (k < 3) {
+            at_next = st.addr(ctx[i + k + 1]);
+            qld = st.load_at(at_next);
+          }
+          nx_prev = enc_bin_lat_acc(e, acc, k == 0, HostBin{bins[i + k]}, at, q, st);
+          at_prev = at;
+          at = at_next;
+        }
+      } else {
+        for (int k = 0; k < 4; k++) enc_bin_at_mem_acc(e, acc, k == 0, HostBin{bins[i + k]}, st.addr(ctx[i + k]), st);
+      }
       if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
       enc_word_close(e, acc);
       if (e.W > mw) mw = e.W;
@@ -185,8 +207,12 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   const bool any = group < 0;
   if (any) group = -group;
   // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
+  const bool lat = group == 5;  // ... in the latency-oriented instance's order (state one bin ahead, forwarding)
+  if (lat) group = 3;
   bool memtab = group == 3;  // ... with the byte-table bin step and (mps, lps) pair collection of the kernel
   if (memtab) group = 2;
+  uint32_t lat_at_prev = 0, lat_nx_prev = 0, lat_qld = 0;
+  bool lat_have_prev = false, lat_have_qld = false;
   const bool noguard = group == 2;
   if (noguard) group = 4;
   uint32_t pairs = 0;
@@ -225,7 +251,19 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       slow_refills++;
     }
     if (memtab) {  // bypass bins join the pair format as (bin, 0), like the kernel's mixed chunks
-      pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
+      if (lat && ctx[i] != kBypass) {
+        const uint32_t at = st.addr(ctx[i]);
+        if (!lat_have_qld) lat_qld = st.load_at(at);  // first bin of a run: nothing was read ahead
+        const uint32_t q = (lat_have_prev && at == lat_at_prev) ? lat_nx_prev : lat_qld;
+        lat_have_qld = i + 1 < n && ctx[i + 1] != kBypass && (i + 1) % 16 != 0;  // the kernel reads ahead inside a chunk only
+        if (lat_have_qld) lat_qld = st.load_at(st.addr(ctx[i + 1]));             // before this bin's store
+        pairs = collect_bin(pairs, dec_bin_lat(d, at, q, st, lat_nx_prev));
+        lat_at_prev = at;
+        lat_have_prev = lat_have_qld;  // forwarding only ever pairs with a read-ahead value
+      } else {
+        lat_have_prev = lat_have_qld = false;
+        pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
+      }
       if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
         const uint32_t done = i % 16 + 1;
         const uint32_t bw = pairs_to_bins(pairs) >> (2 * (16 - done));  // a short last chunk sits at the top

@@ -27,11 +27,13 @@ def main():
     ap.add_argument("--ep", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--streams", default="1048576,524288,262144,131072,65536,32768")
+    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency"))
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     eng = Engine(0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_tuning(args.tuning)
     B, C = args.bins, args.ctx
     init = np.zeros(C, np.uint8)
     rows = []
@@ -72,7 +74,7 @@ def main():
         assert int(status.abs().sum()) == 0 and torch.equal(out, bins)
         rate = S * B * steps / el / 1e9
         krate = S * B / ((kms["encode"] + kms["scan"] + kms["gather"] + kms["decode"]) * 1e-3) / 1e9
-        rows.append(dict(streams=S, bins=B, contexts=C, steps=steps, ms_per_step=el / steps * 1e3, Gbin_s=rate,
+        rows.append(dict(tuning=args.tuning, streams=S, bins=B, contexts=C, steps=steps, ms_per_step=el / steps * 1e3, Gbin_s=rate,
                          kernels_only_Gbin_s=krate, kernels_ms=kms, waves_per_simd=S / 64.0 / 1024.0))
         del bins, ctx, payload, offsets, out, status
     base = rows[0]["Gbin_s"]
