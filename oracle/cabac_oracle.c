@@ -215,6 +215,44 @@ void orc_enc_bin_ep(orc_encoder *e, uint32_t bin) {
   enc_test_write_out(e);
 }
 
+/* sm_aucLPSTProbTable[49][4], CABAC_ArithmeticEncoder.cpp:494-547 (= CABAC_ArithmeticDecoder.cpp:554-): one dword per
+ * row, byte q = column q.  Row i serves an MPS probability of 51 + i percent. */
+static const uint32_t k_prob_row[49] = {
+  0xEACAAB8Bu, 0xE5C6A788u, 0xE0C2A486u, 0xDCBEA083u, 0xD7BA9D80u, 0xD2B6997Du, 0xCDB2967Au,
+  0xC9AE9277u, 0xC4A98F74u, 0xBFA58B72u, 0xBAA1886Fu, 0xB59D846Cu, 0xB1998169u, 0xAC957E66u,
+  0xA7917A63u, 0xA28C7761u, 0x9E88735Eu, 0x9984705Bu, 0x94806C58u, 0x8F7C6955u, 0x8A786552u,
+  0x86746250u, 0x81705E4Du, 0x7C6B5B4Au, 0x77675747u, 0x73635444u, 0x6E5F5041u, 0x695B4D3Eu,
+  0x6457493Cu, 0x5F534639u, 0x5B4E4236u, 0x564A3F33u, 0x51463B30u, 0x4C42382Du, 0x483E342Bu,
+  0x433A3128u, 0x3E362D25u, 0x39322A22u, 0x352D261Fu, 0x3029231Cu, 0x2B251F1Au, 0x26211C17u,
+  0x211D1814u, 0x1D191511u, 0x1815110Eu, 0x13110E0Bu, 0x0E0C0A09u, 0x0A080706u, 0x05040404u};
+uint8_t orc_prob_table(uint32_t row, uint32_t q) { return (uint8_t)(k_prob_row[row] >> (8 * q)); }
+
+/* encodeBinProb, CABAC_ArithmeticEncoder.cpp:180-243 (compiled only under RWTH_CABAC_FIXED_PROBABILITY).
+ * prob = probability of a ONE in percent, 1..99; 50 is an EP bin. */
+void orc_enc_bin_prob(orc_encoder *e, uint32_t bin, uint32_t prob) {
+  if (prob == 50) {
+    orc_enc_bin_ep(e, bin);
+    return;
+  }
+  e->bins_coded++;
+  uint32_t mps = prob > 50 ? 1 : 0;
+  uint32_t pm = prob < 50 ? 50 - prob : prob - 50;
+  uint32_t lps = orc_prob_table(pm - 1, (e->range >> 6) & 3);
+  e->range -= lps;
+  if (bin != mps) {
+    int n = orc_renorm_table(lps >> 3);
+    e->low = (e->low + e->range) << n;
+    e->range = lps << n;
+    e->bits_left -= n;
+  } else {
+    if (e->range >= 256) return;
+    e->low <<= 1;
+    e->range <<= 1;
+    e->bits_left--;
+  }
+  enc_test_write_out(e);
+}
+
 void orc_enc_bins_ep(orc_encoder *e, uint32_t bins, int nbins) {
   e->bins_coded += (uint32_t)nbins;
   while (nbins > 8) {
@@ -329,6 +367,38 @@ uint32_t orc_dec_bin(orc_decoder *d, uint8_t *ctx) {
   return bin;
 }
 
+static uint32_t orc_dec_bin_ep_fwd(orc_decoder *d);
+/* decodeBinProb, CABAC_ArithmeticDecoder.cpp:192-286 */
+uint32_t orc_dec_bin_prob(orc_decoder *d, uint32_t prob) {
+  if (prob == 50) return orc_dec_bin_ep_fwd(d);
+  uint32_t mps = prob > 50 ? 1 : 0, bin;
+  uint32_t pm = prob < 50 ? 50 - prob : prob - 50;
+  uint32_t lps = orc_prob_table(pm - 1, (d->range >> 6) & 3);
+  d->range -= lps;
+  uint32_t scaled = d->range << 7;
+  if (d->value < scaled) {
+    bin = mps;
+    if (scaled >= (256u << 7)) return bin;
+    d->range = scaled >> 6;
+    d->value += d->value;
+    if (++d->bits_needed == 0) {
+      d->bits_needed = -8;
+      d->value += dec_read_byte(d);
+    }
+  } else {
+    int n = orc_renorm_table(lps >> 3);
+    d->value = (d->value - scaled) << n;
+    d->range = lps << n;
+    bin = 1 - mps;
+    d->bits_needed += n;
+    if (d->bits_needed >= 0) {
+      d->value += dec_read_byte(d) << d->bits_needed;
+      d->bits_needed -= 8;
+    }
+  }
+  return bin;
+}
+
 uint32_t orc_dec_bin_ep(orc_decoder *d) {
   d->value += d->value;
   if (++d->bits_needed >= 0) {
@@ -342,6 +412,7 @@ uint32_t orc_dec_bin_ep(orc_decoder *d) {
   }
   return 0;
 }
+static uint32_t orc_dec_bin_ep_fwd(orc_decoder *d) { return orc_dec_bin_ep(d); }
 
 uint32_t orc_dec_bins_ep(orc_decoder *d, int nbins) {
   uint32_t bins = 0;
@@ -406,6 +477,7 @@ size_t orc_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t nbins
   orc_enc_start(&e, out, cap);
   for (uint32_t i = 0; i < nbins; i++) {
     if (ctx[i] == ORC_BYPASS_CTX) orc_enc_bin_ep(&e, bins[i]);
+    else if (nctx <= ORC_PROB_MAX_NCTX && ctx[i] > ORC_PROB_BASE) orc_enc_bin_prob(&e, bins[i], ctx[i] - ORC_PROB_BASE);
     else orc_enc_bin(&e, bins[i], &cm[ctx[i]]);
   }
   if (bits_before_finish) *bits_before_finish = orc_sink_bits(&e.sink);
@@ -424,6 +496,7 @@ uint32_t orc_decode_stream(const uint8_t *payload, size_t len, const uint8_t *ct
   orc_dec_start(&d, payload, len);
   for (uint32_t i = 0; i < nbins; i++) {
     if (ctx[i] == ORC_BYPASS_CTX) bins_out[i] = (uint8_t)orc_dec_bin_ep(&d);
+    else if (nctx <= ORC_PROB_MAX_NCTX && ctx[i] > ORC_PROB_BASE) bins_out[i] = (uint8_t)orc_dec_bin_prob(&d, ctx[i] - ORC_PROB_BASE);
     else bins_out[i] = (uint8_t)orc_dec_bin(&d, &cm[ctx[i]]);
   }
   if (ctx_final && nctx > 0) memcpy(ctx_final, cm, (size_t)nctx);
@@ -484,6 +557,28 @@ int orc_binarize_egk(uint32_t v, uint32_t k, uint8_t *bins) {
   for (int i = 0; i < n_p - 1; i++) bins[n++] = 1;
   bins[n++] = 0;
   for (int i = n_s - 1; i >= 0; i--) bins[n++] = (uint8_t)((v_s >> i) & 1); /* FLCode, :71-75 */
+  return n;
+}
+
+int orc_binarize_fl(uint32_t v, int nbits, uint8_t *bins) {
+  /* FLCode, cabacBinarizer.m:71-75: bit i = floor(v / 2^(nbits-i)) mod 2, MSB first ('DEC2FL32': nbits = 32) */
+  for (int i = 0; i < nbits; i++) bins[i] = (uint8_t)((nbits - 1 - i) < 32 ? (v >> (nbits - 1 - i)) & 1 : 0);
+  return nbits;
+}
+
+int orc_binarize_trk(uint32_t v, uint32_t k, uint32_t max_val, uint8_t *bins) {
+  /* TRCode, cabacBinarizer.m:39-54: floor(v / 2^k) ones, a zero, then k suffix bits -- the remainder MSB first, or all
+   * ones when v >= max_val (the reference's escape is a TODO that leaves the suffix as initialised) */
+  uint32_t n_p = (v >> k) + 1;
+  int n = 0;
+  for (uint32_t i = 0; i + 1 < n_p; i++) bins[n++] = 1;
+  bins[n++] = 0;
+  if (v >= max_val) {
+    for (uint32_t i = 0; i < k; i++) bins[n++] = 1;
+  } else {
+    uint32_t v_s = v - ((n_p - 1) << k);
+    n += orc_binarize_fl(v_s, (int)k, bins + n);
+  }
   return n;
 }
 
@@ -568,13 +663,16 @@ int orc_iss_ctx(int n, const uint8_t *g_prev, const uint8_t *g_up1, int len_up1,
   return id;
 }
 
-#define ORC_MAX_SYM_BINS 96
+#define ORC_MAX_SYM_BINS 320 /* TR0 of 255 has 256 bins */
 /* decoding: the reference has no limit on a symbol's bin string (MATLAB keeps appending), but a string longer than 32
  * bins cannot come from a uint8 symbol (EG2 of 255 has 17 bins); on corrupt streams the engine cuts a symbol at 32 bins
  * (its bin string is one 32-bit word) and the restatement does the same so that both stay in step afterwards */
 #define ORC_DEC_SYM_CAP 32
 
 static int binarize(uint32_t v, uint32_t nq, int method, uint32_t k, uint8_t *g) {
+  /* method: 0 TU, 1 EGk, 2 TRk, 3 FL32 (cabacBinarizer.m:10-27) */
+  if (method == 2) return orc_binarize_trk(v, k, nq - 1, g);
+  if (method == 3) return orc_binarize_fl(v, 32, g);
   return method == 0 ? orc_binarize_tu(v, nq - 1, g) : orc_binarize_egk(v, k, g);
 }
 
@@ -898,4 +996,46 @@ void orc_synth_fill(uint32_t seed, uint64_t s0, uint64_t nS, uint32_t B, uint32_
       ctx[r * B + i] = cb;
     }
   }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * State traces of the reference's Windows build (RWTH_TRACE_CABAC_STATES): what getEncoderStats /
+ * getDecoderStats return for one context, SimpleCABACMex.cpp:356-466.
+ *   trace state   ContextModel::addCabacStep, ContextModel.cpp:126-134: mps == 0 ? 63 - state : state + 64
+ *   step          [codedBin, trace state before, mps before, trace state after, mps after] for every bin coded with
+ *                 the context (SimpleCABACMex.cpp:231-242); on the DECODER side the gateway stores the bin variable
+ *                 before decodeBin has written it (:316-327), so codedBin is always 0 there
+ *   transitions   counts [trace state before][trace state after], 128 x 128
+ * The context state evolves with the bins alone (updateMPS / updateLPS), so no arithmetic coder is needed here.
+ * Returns the number of steps; trace5 receives the first cap_steps of them.
+ * ---------------------------------------------------------------------------------------- */
+uint8_t orc_trace_state(uint8_t p) { return (p & 1) == 0 ? (uint8_t)(63 - (p >> 1)) : (uint8_t)((p >> 1) + 64); }
+
+uint64_t orc_trace_stats(const uint8_t *bins, const uint8_t *ctx, uint64_t nbins, const uint8_t *ctx_init, int nctx,
+                         int which_ctx, int decoder_side, uint8_t *trace5, uint64_t cap_steps, uint32_t *trans) {
+  uint8_t cm[256];
+  memset(cm, orc_ctx_pack(1, 0), sizeof cm);
+  if (nctx > 0) memcpy(cm, ctx_init, (size_t)nctx);
+  if (trans) memset(trans, 0, 128 * 128 * sizeof(uint32_t));
+  uint64_t steps = 0;
+  for (uint64_t i = 0; i < nbins; i++) {
+    const uint32_t c = ctx[i];
+    if (c == ORC_BYPASS_CTX || (nctx <= ORC_PROB_MAX_NCTX && c > ORC_PROB_BASE)) continue; /* no context model involved */
+    const uint8_t p = cm[c];
+    const uint8_t a = bins[i] == (p & 1u) ? orc_ctx_next_mps(p) : orc_ctx_next_lps(p);
+    cm[c] = a;
+    if ((int)c != which_ctx) continue;
+    const uint8_t tp = orc_trace_state(p), ta = orc_trace_state(a);
+    if (trace5 && steps < cap_steps) {
+      uint8_t *t = trace5 + 5 * steps;
+      t[0] = decoder_side ? 0 : bins[i];
+      t[1] = tp;
+      t[2] = p & 1u;
+      t[3] = ta;
+      t[4] = a & 1u;
+    }
+    if (trans) trans[(size_t)tp * 128 + ta]++;
+    steps++;
+  }
+  return steps;
 }

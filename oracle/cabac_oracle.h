@@ -26,6 +26,10 @@ extern "C" {
 #endif
 
 #define ORC_BYPASS_CTX 0xFFu /* ctx byte that marks an equiprobable (EP) bin */
+/* ctx bytes 156..254 mark a fixed-probability bin with P(1) = byte - 155 percent (the engine's additive encoding of
+ * encodeBinProb's second argument) in batches of at most 128 contexts */
+#define ORC_PROB_BASE 155u
+#define ORC_PROB_MAX_NCTX 128
 
 /* ---- bit/byte sink: CABAC/CABAC_BitstreamFile.cpp:95-151 (write side), in memory ---- */
 typedef struct {
@@ -68,6 +72,8 @@ void orc_enc_start(orc_encoder *e, uint8_t *buf, size_t cap);          /* :54-68
 void orc_enc_bin(orc_encoder *e, uint32_t bin, uint8_t *ctx_packed);   /* :113-178 */
 void orc_enc_bin_ep(orc_encoder *e, uint32_t bin);                     /* :250-270 */
 void orc_enc_bins_ep(orc_encoder *e, uint32_t bins, int nbins);        /* :278-319 */
+void orc_enc_bin_prob(orc_encoder *e, uint32_t bin, uint32_t prob);    /* :180-243 (RWTH_CABAC_FIXED_PROBABILITY) */
+uint8_t orc_prob_table(uint32_t row, uint32_t q);                      /* sm_aucLPSTProbTable[row][q], :494-547 */
 void orc_enc_bin_trm(orc_encoder *e, uint32_t bin);                    /* :326-367 */
 void orc_enc_finish(orc_encoder *e);                                   /* :70-105 */
 size_t orc_enc_bytes(const orc_encoder *e); /* bytes in the sink so far */
@@ -94,6 +100,7 @@ void orc_dec_start(orc_decoder *d, const uint8_t *buf, size_t len);    /* :54-71
 uint32_t orc_dec_bin(orc_decoder *d, uint8_t *ctx_packed);             /* :87-190 */
 uint32_t orc_dec_bin_ep(orc_decoder *d);                               /* :288-331 */
 uint32_t orc_dec_bins_ep(orc_decoder *d, int nbins);                   /* :333-421 */
+uint32_t orc_dec_bin_prob(orc_decoder *d, uint32_t prob);              /* :192-286 (RWTH_CABAC_FIXED_PROBABILITY) */
 uint32_t orc_dec_bin_trm(orc_decoder *d);                              /* :423-472 */
 /* finish (:73-85) with the two asserts turned into a status word:
  * bit0 = terminate bin was not 1, bit1 = stop bit not where expected,
@@ -127,6 +134,8 @@ void orc_decode_batch(const uint8_t *payload, const uint64_t *offsets, const uin
 /* write the bin string of v, return its length */
 int orc_binarize_tu(uint32_t v, uint32_t max_val, uint8_t *bins);
 int orc_binarize_egk(uint32_t v, uint32_t k, uint8_t *bins);
+int orc_binarize_trk(uint32_t v, uint32_t k, uint32_t max_val, uint8_t *bins); /* TRCode, cabacBinarizer.m:39-54 */
+int orc_binarize_fl(uint32_t v, int nbits, uint8_t *bins);                     /* FLCode, :71-75 */
 uint32_t orc_debinarize_tu(const uint8_t *bins, int n, uint32_t max_val);
 uint32_t orc_debinarize_egk(const uint8_t *bins, int n, uint32_t k);
 
@@ -140,7 +149,8 @@ int orc_iss_ctx(int n, const uint8_t *g_prev, const uint8_t *g_up1, int len_up1,
 
 /* encode a column of symbols the way ISS/+coder/cabacEncode.m:45-70 walks ONE column
  * (d = 1..rows), EGk or TU binarisation, ISS context selection; and decode it back the way
- * cabacDecode.m:29-55 does.  method: 0 = TU (max_val = nq-1), 1 = EGk. */
+ * cabacDecode.m:29-55 does.  method: 0 = TU (max_val = nq-1), 1 = EGk; encode side only: 2 = TRk, 3 = FL32 (the
+ * reference cannot decode those: cabacDecodeSymbolFinished.m:12-30 knows TU and EG0-2). */
 size_t orc_iss_encode_column(const uint32_t *sym, int rows, uint32_t nq, int method, uint32_t k,
                              unsigned types, int nlbp, const uint8_t *ctx_init, int nctx,
                              uint8_t *out, size_t cap, uint32_t *nbins_out);
@@ -170,6 +180,11 @@ size_t orc_demo_encode(const uint32_t *sym, int nsym, uint32_t nq, const uint8_t
                        uint8_t *out, size_t cap, uint32_t *nbins_out);
 uint32_t orc_demo_decode(const uint8_t *payload, size_t len, int nsym, uint32_t nq,
                          const uint8_t *ctx_init, uint32_t *sym_out);
+
+/* ---- state traces (getEncoderStats / getDecoderStats of the reference's Windows build) ---- */
+uint8_t orc_trace_state(uint8_t packed); /* ContextModel.cpp:128-129 */
+uint64_t orc_trace_stats(const uint8_t *bins, const uint8_t *ctx, uint64_t nbins, const uint8_t *ctx_init, int nctx,
+                         int which_ctx, int decoder_side, uint8_t *trace5, uint64_t cap_steps, uint32_t *trans);
 
 /* ---- synthetic workload generator of SURVEY.md section 8(d) ---- */
 /* fills bins/ctx ([nS][B], stream-major) for global stream ids s0 .. s0+nS-1.

@@ -15,6 +15,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libcabac_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libcabac_ref.so")
+# the same sources with the reference's two compile-time switches on (state traces, fixed-probability bins)
+REF_FULL_SO = os.path.join(HERE, "_ref", "libcabac_ref_full.so")
+PROB_BASE = 155  # ctx byte of a fixed-probability bin = PROB_BASE + P(1) in percent (batches of <= 128 contexts)
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -31,12 +34,16 @@ def build(force=False):
     Never rebuilds an existing library implicitly: several bench ranks may import this at once."""
     if force or not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-C", HERE, "libcabac_oracle.so"], stdout=subprocess.DEVNULL)
-    if (force or not os.path.exists(REF_SO)) and os.path.isdir("/root/reference/CABAC"):
+    if (force or not os.path.exists(REF_SO) or not os.path.exists(REF_FULL_SO)) and os.path.isdir("/root/reference/CABAC"):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
 def have_reference():
     return os.path.exists(REF_SO)
+
+
+def have_reference_full():
+    return os.path.exists(REF_FULL_SO)
 
 
 def scratch_path(tag="s"):
@@ -122,6 +129,19 @@ class Oracle:
         L.orc_dec_bins_ep.argtypes = [C.c_void_p, C.c_int]
         L.orc_dec_finish.restype = C.c_uint32
         L.orc_dec_finish.argtypes = [C.c_void_p]
+        L.orc_enc_bin_prob.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_dec_bin_prob.restype = C.c_uint32
+        L.orc_dec_bin_prob.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_prob_table.restype = C.c_uint8
+        L.orc_prob_table.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_binarize_trk.restype = C.c_int
+        L.orc_binarize_trk.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u8p]
+        L.orc_binarize_fl.restype = C.c_int
+        L.orc_binarize_fl.argtypes = [C.c_uint32, C.c_int, u8p]
+        L.orc_trace_state.restype = C.c_uint8
+        L.orc_trace_state.argtypes = [C.c_uint8]
+        L.orc_trace_stats.restype = C.c_uint64
+        L.orc_trace_stats.argtypes = [u8p, u8p, C.c_uint64, u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_uint64, u32p]
 
     def counters(self, reset=False):
         class Cn(C.Structure):
@@ -189,7 +209,19 @@ class Oracle:
                                   _p(ctx_init, u8p), ctx_init.size, _p(bins, u8p), _p(status, u32p))
         return bins, status
 
-    # ---- op scripts (kind 0 ctx bin, 1 EP bin, 2 multi-EP) --------------------------------
+    # ---- state traces --------------------------------------------------------------------
+    def trace_stats(self, bins, ctx, ctx_init, which_ctx, decoder=False):
+        """(trace [N, 5] uint8, transitions [128, 128] uint32) of context `which_ctx`: getEncoderStats / getDecoderStats."""
+        bins = np.ascontiguousarray(bins, np.uint8)
+        ctx = np.ascontiguousarray(ctx, np.uint8)
+        ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
+        trace = np.zeros((max(1, bins.size), 5), np.uint8)
+        trans = np.zeros((128, 128), np.uint32)
+        n = self.lib.orc_trace_stats(_p(bins, u8p), _p(ctx, u8p), bins.size, _p(ctx_init, u8p), ctx_init.size,
+                                     int(which_ctx), int(bool(decoder)), _p(trace, u8p), trace.shape[0], _p(trans, u32p))
+        return trace[:n].copy(), trans
+
+    # ---- op scripts (kind 0 ctx bin, 1 EP bin, 2 multi-EP, 3 fixed-probability bin: arg = P(1) in percent) ---------
     def encode_ops(self, kind, val, arg, ctx_init):
         cm = np.array(ctx_init, np.uint8).copy()
         cap = self.stream_cap(int(np.sum(np.where(np.asarray(kind) == 2, arg, 1)))) + 64
@@ -202,6 +234,8 @@ class Oracle:
                 L.orc_enc_bin(enc, int(v), C.cast(cm.ctypes.data + int(a), u8p))
             elif k == 1:
                 L.orc_enc_bin_ep(enc, int(v))
+            elif k == 3:
+                L.orc_enc_bin_prob(enc, int(v), int(a))
             else:
                 L.orc_enc_bins_ep(enc, int(v), int(a))
         L.orc_enc_finish(enc)
@@ -220,6 +254,8 @@ class Oracle:
                 res.append(L.orc_dec_bin(dec, C.cast(cm.ctypes.data + int(a), u8p)))
             elif k == 1:
                 res.append(L.orc_dec_bin_ep(dec))
+            elif k == 3:
+                res.append(L.orc_dec_bin_prob(dec, int(a)))
             else:
                 res.append(L.orc_dec_bins_ep(dec, int(a)))
         st = L.orc_dec_finish(dec)
@@ -245,8 +281,13 @@ class Oracle:
     # ---- binarisation / selectors ----------------------------------------------------------
     def binarize(self, v, method, nq=0, k=0):
         buf = np.zeros(128, np.uint8)
+        buf = np.zeros(320, np.uint8)
         if method == "TU":
             n = self.lib.orc_binarize_tu(int(v), int(nq) - 1, _p(buf, u8p))
+        elif method == "TR":
+            n = self.lib.orc_binarize_trk(int(v), int(k), int(nq) - 1, _p(buf, u8p))
+        elif method == "FL32":
+            n = self.lib.orc_binarize_fl(int(v), 32, _p(buf, u8p))
         else:
             n = self.lib.orc_binarize_egk(int(v), int(k), _p(buf, u8p))
         return buf[:n].copy()
@@ -355,12 +396,19 @@ class Oracle:
 class Reference:
     """The real reference classes (oracle/_ref/libcabac_ref.so)."""
 
-    def __init__(self, tag="ref"):
-        if not have_reference():
+    def __init__(self, tag="ref", full=False):
+        """full=True: the build with RWTH_TRACE_CABAC_STATES and RWTH_CABAC_FIXED_PROBABILITY on (op kind 3, get_trace)."""
+        so = REF_FULL_SO if full else REF_SO
+        if not os.path.exists(so):
             build()
-        if not have_reference():
-            raise RuntimeError("oracle/_ref/libcabac_ref.so not built (needs /root/reference)")
-        L = self.lib = C.CDLL(REF_SO)
+        if not os.path.exists(so):
+            raise RuntimeError("%s not built (needs /root/reference)" % so)
+        L = self.lib = C.CDLL(so)
+        self.full = full
+        if full:
+            assert L.ref_has_fixed_prob() == 1 and L.ref_has_trace() == 1
+            L.ref_get_trace.restype = C.c_long
+            L.ref_get_trace.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, u32p]
         L.ref_encode_ops.restype = C.c_long
         L.ref_encode_ops.argtypes = [u8p, u32p, u32p, C.c_uint32, u8p, C.c_int, C.c_char_p, u8p, C.c_size_t,
                                      u32p, u32p, u8p]
@@ -410,6 +458,14 @@ class Reference:
                                      _p(ctx_init, u8p), ctx_init.size, self.scratch, _p(res, u32p), None, _p(fin, u8p))
         assert st >= 0, st
         return res, int(st), fin[:ctx_init.size]
+
+    def get_trace(self, decoder, ctx, cap=1 << 20):
+        """getEncoderStats / getDecoderStats of context `ctx` after the most recent encode_ops / decode_ops (full build)."""
+        trace = np.zeros((cap, 5), np.uint8)
+        trans = np.zeros((128, 128), np.uint32)
+        n = self.lib.ref_get_trace(int(bool(decoder)), int(ctx), _p(trace, u8p), cap, _p(trans, u32p))
+        assert 0 <= n <= cap, n
+        return trace[:n].copy(), trans
 
     def encode_stream(self, bins, ctx, ctx_init):
         """ctx byte 0xFF = EP bin (the shim maps it to encodeBinEP)."""

@@ -6,6 +6,11 @@
 //   * validate oracle/cabac_oracle.c bin by bin (tests/test_oracle_vs_ref.py),
 //   * generate the golden vectors in tests/golden/ (tests/golden/make_golden.py),
 //   * time the reference itself as bench.py's cpu_baseline (kind "reference").
+// oracle/Makefile builds it twice: _ref/libcabac_ref.so as the reference ships on Linux, and _ref/libcabac_ref_full.so
+// with the reference's two compile-time switches on -- RWTH_TRACE_CABAC_STATES (CommonDef.h:39-43: on under _WIN32, so
+// the build passes -D_WIN32) and RWTH_CABAC_FIXED_PROBABILITY (CommonDef.h:50: hard-defined 0, so the Makefile derives
+// a flipped copy of that one header with sed at build time and force-includes it; the include guard then skips the
+// original).  The second build pins the fixed-probability bins and the state traces.
 // The reference bit sink is an std::fstream (CABAC_BitstreamFile.cpp:50-86), so every stream goes
 // through a scratch file whose path the caller supplies (put it on /dev/shm).
 #include <cstdint>
@@ -39,6 +44,11 @@ void init_models(std::vector<ContextModel> &cm, const uint8_t *packed, int nctx)
   for (int c = 0; c < nctx; c++) cm[c].init(packed[c] & 1u, packed[c] >> 1);
 }
 
+#if RWTH_TRACE_CABAC_STATES
+// the context models of the most recent ref_encode_ops / ref_decode_ops run, for ref_get_trace
+std::vector<ContextModel> g_last_cm[2];
+#endif
+
 long slurp(const char *path, uint8_t *out, size_t cap) {
   FILE *f = std::fopen(path, "rb");
   if (!f) return -1;
@@ -66,9 +76,27 @@ long ref_encode_ops(const uint8_t *kind, const uint32_t *val, const uint32_t *ar
   enc.start();
   for (uint32_t i = 0; i < nops; i++) {
     switch (kind[i]) {
-      case 0: enc.encodeBin(val[i], &cm[arg[i]]); break;
+      case 0: {
+#if RWTH_TRACE_CABAC_STATES
+        // exactly what the MEX gateway does around encodeBin, SimpleCABACMex.cpp:231-242
+        ContextModel *m = &cm[arg[i]];
+        uint8_t bin = (uint8_t)val[i];
+        uint8_t mps_p = m->getMps();
+        uint8_t state_p = m->getState();
+#endif
+        enc.encodeBin(val[i], &cm[arg[i]]);
+#if RWTH_TRACE_CABAC_STATES
+        uint8_t mps_a = m->getMps();
+        uint8_t state_a = m->getState();
+        m->addCabacStep(bin, state_p, mps_p, state_a, mps_a);
+#endif
+        break;
+      }
       case 1: enc.encodeBinEP(val[i]); break;
       case 2: enc.encodeBinsEP(val[i], (int)arg[i]); break;
+#if RWTH_CABAC_FIXED_PROBABILITY
+      case 3: enc.encodeBinProb(val[i], arg[i]); break;  // arg = probability of a 1 in percent
+#endif
       default: return -3;
     }
     if (trace) enc.snapshot(trace + 5 * (size_t)i);
@@ -78,6 +106,9 @@ long ref_encode_ops(const uint8_t *kind, const uint32_t *val, const uint32_t *ar
   bs.closeFile();
   if (ctx_final)
     for (int c = 0; c < nctx; c++) ctx_final[c] = (uint8_t)((cm[c].getState() << 1) | cm[c].getMps());
+#if RWTH_TRACE_CABAC_STATES
+  g_last_cm[0] = cm;
+#endif
   return slurp(scratch, out, cap);
 }
 
@@ -103,9 +134,27 @@ long ref_decode_ops(const uint8_t *payload, size_t len, const uint8_t *kind, con
   for (uint32_t i = 0; i < nops; i++) {
     unsigned int r = 0;
     switch (kind[i]) {
-      case 0: dec.decodeBin(r, &cm[arg[i]]); break;
+      case 0: {
+#if RWTH_TRACE_CABAC_STATES
+        // SimpleCABACMex.cpp:316-328 -- note that the gateway records the bin variable BEFORE decoding (always 0)
+        ContextModel *m = &cm[arg[i]];
+        uint8_t bin = (uint8_t)r;
+        uint8_t mps_p = m->getMps();
+        uint8_t state_p = m->getState();
+#endif
+        dec.decodeBin(r, &cm[arg[i]]);
+#if RWTH_TRACE_CABAC_STATES
+        uint8_t mps_a = m->getMps();
+        uint8_t state_a = m->getState();
+        m->addCabacStep(bin, state_p, mps_p, state_a, mps_a);
+#endif
+        break;
+      }
       case 1: dec.decodeBinEP(r); break;
       case 2: dec.decodeBinsEP(r, (int)arg[i]); break;
+#if RWTH_CABAC_FIXED_PROBABILITY
+      case 3: dec.decodeBinProb(r, arg[i]); break;
+#endif
       default: return -3;
     }
     result[i] = r;
@@ -119,8 +168,41 @@ long ref_decode_ops(const uint8_t *payload, size_t len, const uint8_t *kind, con
   bs.closeFile();
   if (ctx_final)
     for (int c = 0; c < nctx; c++) ctx_final[c] = (uint8_t)((cm[c].getState() << 1) | cm[c].getMps());
+#if RWTH_TRACE_CABAC_STATES
+  g_last_cm[1] = cm;
+#endif
   return status;
 }
+
+// which of the reference's compile-time switches this build has on
+int ref_has_fixed_prob(void) { return RWTH_CABAC_FIXED_PROBABILITY; }
+int ref_has_trace(void) { return RWTH_TRACE_CABAC_STATES; }
+
+#if RWTH_TRACE_CABAC_STATES
+// What getEncoderStats / getDecoderStats hand to MATLAB for context `ctx` (SimpleCABACMex.cpp:356-466) after the most
+// recent ref_encode_ops (decoder = 0) / ref_decode_ops (decoder = 1): trace5 = 5 bytes per step [codedBin, state_p,
+// mps_p, state_a, mps_a] (states remapped by ContextModel::addCabacStep), trans = 128 x 128 counts [state_p][state_a].
+// Returns the number of steps (the caller's trace5 holds cap_steps of them), -1 for a bad context index.
+long ref_get_trace(int decoder, int ctx, uint8_t *trace5, size_t cap_steps, uint32_t *trans) {
+  std::vector<ContextModel> &cm = g_last_cm[decoder ? 1 : 0];
+  if (ctx < 0 || (size_t)ctx >= cm.size()) return -1;
+  std::vector<CABACStep> *steps = cm[ctx].getCabacSteps();
+  std::vector<std::vector<unsigned int>> *tt = cm[ctx].getCabactTransitions();
+  for (size_t e = 0; e < steps->size() && e < cap_steps; e++) {
+    CABACStep t = steps->at(e);
+    trace5[e * 5 + 0] = t.codedBin;
+    trace5[e * 5 + 1] = t.state_p;
+    trace5[e * 5 + 2] = t.mps_p;
+    trace5[e * 5 + 3] = t.state_a;
+    trace5[e * 5 + 4] = t.mps_a;
+  }
+  if (trans)
+    for (int p = 0; p < RWTH_TRACE_CABAC_STATES_NUM_STATES; p++)
+      for (int a = 0; a < RWTH_TRACE_CABAC_STATES_NUM_STATES; a++)
+        trans[p * RWTH_TRACE_CABAC_STATES_NUM_STATES + a] = (*tt)[p][a];
+  return (long)steps->size();
+}
+#endif
 
 // Stream-major batch round trip with one scratch file per stream (what the reference does, one file per
 // handle: SimpleCABACMex.cpp:195,288).  ctx byte 0xFF = EP bin.  Used only for timing the reference.
