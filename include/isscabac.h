@@ -43,7 +43,20 @@ extern "C" {
 #endif
 
 #define ISSCABAC_BYPASS 0xFFu
-#define ISSCABAC_MAX_CTX 255
+#define ISSCABAC_MAX_CTX 255 /* contexts of a batch call (one byte per bin names the context) */
+/* The reference holds up to 999 context models per handle (ref: CABAC/CommonDef.h:56, CABAC_ContextModelsInit.cpp:53,84).
+ * The single-stream handle (isscabac_stream_*, what the reference's per-bin commands map to) takes as many; a batch call
+ * with more than ISSCABAC_MAX_CTX contexts is refused with ISSCABAC_ERR_ARG (its context indices are bytes). */
+#define ISSCABAC_STREAM_MAX_CTX 999
+/* Fixed-probability bins (ref: encodeBinProb / decodeBinProb, CABAC_ArithmeticEncoder.cpp:180-243,
+ * CABAC_ArithmeticDecoder.cpp:192-286; compiled into the reference only with RWTH_CABAC_FIXED_PROBABILITY, CommonDef.h:50).
+ * In a batch call of at most ISSCABAC_PROB_MAX_CTX contexts a ctx byte of ISSCABAC_PROB(p) codes the bin with a fixed
+ * probability of p percent of being 1, no context model involved; p = 50 is a bypass bin, as in the reference.
+ * p = 46..49 and 51..54 are not supported (see cabac_lane.h: prob_valid): like any invalid ctx byte they leave that
+ * stream's result unspecified.  With more contexts, bytes 129..254 are context indices. */
+#define ISSCABAC_PROB_BASE 155u
+#define ISSCABAC_PROB(p) (ISSCABAC_PROB_BASE + (p)) /* p = 1..99 -> 156..254 */
+#define ISSCABAC_PROB_MAX_CTX 128
 #define ISSCABAC_MAX_PITCH (1u << 25) /* bins per stream in one batch call */
 
 enum {
@@ -168,6 +181,10 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
  * Limits: nctx <= 64, at most 32 bins per symbol (TU: nq <= 33). */
 #define ISSCABAC_BIN_TU 0u
 #define ISSCABAC_BIN_EGK 1u
+/* encode side only -- the reference has no end-of-symbol rule for them (ref: CABAC/cabacDecodeSymbolFinished.m:12-30), so
+ * isscabac_decode_symbols* refuses them: */
+#define ISSCABAC_BIN_TRK 2u  /* truncated Rice, order k; suffix all ones from the maximum on (ref: CABAC/cabacBinarizer.m:39-54) */
+#define ISSCABAC_BIN_FL32 3u /* 32 bins, MSB first (ref: CABAC/cabacBinarizer.m:71-75, 'DEC2FL32') */
 #define ISSCABAC_SEL_DEMO 0u
 #define ISSCABAC_SEL_ISS 1u
 typedef struct {
@@ -205,6 +222,11 @@ typedef struct isscabac_symbol_stats {
   uint32_t *ctx_hist;
   uint32_t *ctx_cost;
   uint16_t *sym_bits;
+  /* optional state trace: bin_trace[s * bin_trace_pitch + i] = the 4-byte record of bin i of stream s (i < nbins_out[s]);
+   * isscabac_trace_stats turns one stream's records into getEncoderStats' two outputs.  bin_trace_pitch (in records)
+   * must be at least nsym x isscabac_symbol_max_bins. */
+  uint32_t *bin_trace;
+  uint32_t bin_trace_pitch;
 } isscabac_symbol_stats;
 /* as isscabac_encode_symbols_dev, d_stats->* are device pointers */
 int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
@@ -257,7 +279,13 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
  *   ('decodeStart', h)        -> isscabac_stream_decode_start      (ref: :280-300; caller passes the file's bytes)
  *   ('decodeBin', h, ctx)     -> isscabac_stream_decode_bins(n=1)  (ref: :301-335)
  *   ('decodeFinish', h)       -> isscabac_stream_decode_finish     (ref: :336-354; asserts become status flags)
- */
+ *   ('getEncoderStats'|'getDecoderStats', h, ctx) -> isscabac_stream_get_stats (ref: :356-466, Windows build only)
+ * nctx may be up to ISSCABAC_STREAM_MAX_CTX.  The u8 forms below name contexts 0..254 (0xFF = bypass; in handles of at
+ * most ISSCABAC_PROB_MAX_CTX contexts ISSCABAC_PROB(p) = fixed probability); the *_ops forms take 16-bit ops and reach
+ * every context. */
+#define ISSCABAC_OP_CTX(c) ((uint16_t)(c))                 /* context bin, c < nctx */
+#define ISSCABAC_OP_BYPASS ((uint16_t)0xFFFFu)              /* encodeBinEP / decodeBinEP */
+#define ISSCABAC_OP_PROB(p) ((uint16_t)(0x8000u | (p)))     /* encodeBinProb / decodeBinProb, p = 1..99 percent */
 typedef struct isscabac_stream isscabac_stream;
 int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, isscabac_stream **out);
 void isscabac_stream_close(isscabac_stream *s);
@@ -272,6 +300,26 @@ int isscabac_stream_encode_finish(isscabac_stream *s, uint8_t *out, uint64_t cap
 int isscabac_stream_decode_start(isscabac_stream *s, const uint8_t *payload, uint64_t nbytes);
 int isscabac_stream_decode_bins(isscabac_stream *s, const uint8_t *ctx, uint32_t n, uint8_t *bins_out);
 int isscabac_stream_decode_finish(isscabac_stream *s, uint32_t *status);
+/* the same with 16-bit ops (ISSCABAC_OP_*) */
+int isscabac_stream_encode_ops(isscabac_stream *s, const uint8_t *bins, const uint16_t *ops, uint32_t n);
+int isscabac_stream_decode_ops(isscabac_stream *s, const uint16_t *ops, uint32_t n, uint8_t *bins_out);
+
+/* ---- state traces: getEncoderStats / getDecoderStats of the reference's Windows build ---------------------------------
+ * ref: CABAC/SimpleCABACMex.cpp:231-242,316-327 (one step per context bin), :356-466 (the two outputs),
+ *      CABAC/ContextModel.cpp:126-134 (state numbering: mps 0 -> 63 - state, mps 1 -> state + 64).
+ * Tracing is off by default (4 bytes of device memory per bin); switch it before encodeStart / decodeStart.
+ *   trace5      : 5 bytes per step [codedBin, state before, mps before, state after, mps after] -- the 5 x N uint8 matrix;
+ *                 on the decoder side codedBin is always 0, as in the reference (its gateway stores the variable before
+ *                 decodeBin has written it)
+ *   cap_steps   : steps trace5 has room for; *nsteps receives the number of steps there are (call again if larger)
+ *   transitions : 128 x 128 uint32 counts [state before][state after], or NULL
+ * isscabac_trace_stats is the host-side reduction itself, for trace records obtained elsewhere (the symbol kernels'
+ * statistics variant writes the same 4-byte records: isscabac_symbol_stats.bin_trace). */
+int isscabac_stream_set_trace(isscabac_stream *s, int enabled);
+int isscabac_stream_get_stats(isscabac_stream *s, int decoder, int ctx, uint8_t *trace5, uint64_t cap_steps,
+                              uint64_t *nsteps, uint32_t *transitions);
+int isscabac_trace_stats(const uint32_t *records, uint64_t nrecords, int ctx, int decoder, uint8_t *trace5,
+                         uint64_t cap_steps, uint64_t *nsteps, uint32_t *transitions);
 
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* when enabled, every batch call brackets each of its kernels with hipEvents on the engine's stream */

@@ -44,7 +44,7 @@ static int grow(isscabac_engine *e, void **p, uint64_t *have, uint64_t need) {
 
 extern "C" {
 
-int isscabac_abi_version(void) { return 1; }
+int isscabac_abi_version(void) { return 2; }
 
 int isscabac_create(int device, isscabac_engine **out) {
   if (!out) return fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_create: out is null");

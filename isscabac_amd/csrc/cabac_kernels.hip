@@ -36,6 +36,7 @@
 namespace isscabac {
 
 __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
+__device__ const uint32_t c_prob_rows[49] = {ISSCABAC_PROB_ROWS};  // fixed-probability bins: rare, read from memory
 struct NextTab {
   uint32_t e[64];
   uint32_t e16[64];  // two 16-bit entries per dword: packed states 2i, 2i + 1
@@ -72,6 +73,9 @@ template <int CM>
 constexpr uint32_t not_plain_mask() { return CM == 1 ? 0xC0C0C0C0u : 0x80808080u; }
 template <int CM>
 __device__ __forceinline__ bool is_ctx_byte(uint32_t c) { return CM == 1 ? c < 64u : CM == 3 ? c < 128u : c != 0xFFu; }
+// fixed-probability bins exist in batches of at most 128 contexts (with more, bytes 129..254 are context indices)
+template <int CM>
+__device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 && is_prob_byte(c); }
 
 // waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
 // let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
@@ -491,8 +495,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
                 else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
                 else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
                 else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-              } else if (cb == kBypass) {
+              } else if (cb == kBypass || cb == kProbBase + 50u) {
                 enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
+              } else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase)) {
+                enc_bin_prob(e, (w1 >> (8 * (k & 3))) & 1u, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]);
               }
             }
             if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
@@ -765,7 +771,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   if (full || i0 + 4 * g + k < n) {
                     const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
                     if (is_ctx_byte<CM>(cb)) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                    else if (cb == kBypass) w = pair_of_bin(dec_bin_ep(d));
+                    else if (cb == kBypass || cb == kProbBase + 50u) w = pair_of_bin(dec_bin_ep(d));
+                    else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase))
+                      w = pair_of_bin(dec_bin_prob(d, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]));
                   }
                   ob = collect_bin(ob, w);
                 }
@@ -864,7 +872,10 @@ __global__ void __launch_bounds__(64) k_decode_exact(DecArgs a) {
   uint8_t *out = a.bins_out + s * a.pitch;
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t c = ctx[i];
-    out[i] = (uint8_t)(c == kBypass ? ref_dec_bin_ep(r, rd) : ref_dec_bin(r, c, st, rd));
+    const bool prob_ok = a.nctx <= 128u && is_prob_byte(c);  // what the batch kernels take as a fixed-probability bin
+    if (c == kBypass || (prob_ok && c == kProbBase + 50u)) out[i] = (uint8_t)ref_dec_bin_ep(r, rd);
+    else if (prob_ok) out[i] = prob_valid(c - kProbBase) ? (uint8_t)ref_dec_bin_prob(r, c - kProbBase, c_prob_rows[prob_row_index(c - kProbBase)], rd) : 0;
+    else out[i] = (uint8_t)ref_dec_bin(r, c, st, rd);
   }
   const uint32_t status = ref_dec_finish(r, rd, len);
   if (a.status) a.status[s] = status;

@@ -65,6 +65,28 @@ constexpr uint32_t kBypass = 0xFFu;
   22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34,    \
   35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63
 
+// sm_aucLPSTProbTable[49][4] (ref: CABAC/CABAC_ArithmeticEncoder.cpp:494-547, the decoder's copy CABAC_ArithmeticDecoder.cpp:554-):
+// the rangeTabLps rows of the fixed-probability bins, one dword per row, byte q = column q; row i serves an MPS
+// probability of 51 + i percent.
+#define ISSCABAC_PROB_ROWS                                                                           \
+  0xEACAAB8Bu, 0xE5C6A788u, 0xE0C2A486u, 0xDCBEA083u, 0xD7BA9D80u, 0xD2B6997Du, 0xCDB2967Au,         \
+  0xC9AE9277u, 0xC4A98F74u, 0xBFA58B72u, 0xBAA1886Fu, 0xB59D846Cu, 0xB1998169u, 0xAC957E66u,         \
+  0xA7917A63u, 0xA28C7761u, 0x9E88735Eu, 0x9984705Bu, 0x94806C58u, 0x8F7C6955u, 0x8A786552u,         \
+  0x86746250u, 0x81705E4Du, 0x7C6B5B4Au, 0x77675747u, 0x73635444u, 0x6E5F5041u, 0x695B4D3Eu,         \
+  0x6457493Cu, 0x5F534639u, 0x5B4E4236u, 0x564A3F33u, 0x51463B30u, 0x4C42382Du, 0x483E342Bu,         \
+  0x433A3128u, 0x3E362D25u, 0x39322A22u, 0x352D261Fu, 0x3029231Cu, 0x2B251F1Au, 0x26211C17u,         \
+  0x211D1814u, 0x1D191511u, 0x1815110Eu, 0x13110E0Bu, 0x0E0C0A09u, 0x0A080706u, 0x05040404u
+
+// Fixed-probability bins (ref: encodeBinProb / decodeBinProb, compiled under RWTH_CABAC_FIXED_PROBABILITY): a ctx byte of
+// kProbBase + p marks a bin whose probability of being 1 is p percent; no context model is involved.  p = 50 is a
+// bypass bin (ref: :188-192).  p = 46..49 and 51..54 are refused: with those four rows the LPS exceeds half of the
+// smallest range, the reference's MPS path then leaves m_uiRange below 256 (:228-236 shifts by exactly one bit) and its
+// decoder indexes sm_aucLPSTable out of bounds on the next context bin (CABAC_ArithmeticDecoder.cpp:94).
+constexpr uint32_t kProbBase = 155u;
+CABAC_HD bool is_prob_byte(uint32_t c) { return c > kProbBase && c != kBypass; }
+CABAC_HD bool prob_valid(uint32_t p) { return p >= 1u && p <= 99u && !(p >= 46u && p <= 54u && p != 50u); }
+CABAC_HD uint32_t prob_row_index(uint32_t p) { return (p < 50u ? 50u - p : p - 50u) - 1u; }  // p != 50
+
 CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 
 // Context states are kept "doubled": q = m_ucState << 1 = (state << 2) | (mps << 1).  q is directly the byte
@@ -325,6 +347,20 @@ CABAC_HD void enc_bin_any(EncCore &e, uint32_t b1, uint32_t ctx, States &st) {
 CABAC_HD void enc_bin_ep(EncCore &e, uint32_t bin) {  // ref: :250-270
   e.low = (e.low << 1) + (bin ? e.range : 0u);
   e.W += 1;
+}
+
+// encodeBinProb for p != 50 (ref: :180-243); row = ISSCABAC_PROB_ROWS[prob_row_index(p)].  For the rows prob_valid()
+// admits, rmps >= 128 and lps is 4..215, so the shift is the same clz32 - 23 as for a context bin (<= 6 bits).
+CABAC_HD void enc_bin_prob(EncCore &e, uint32_t bin, uint32_t p, uint32_t row) {
+  const uint32_t mps = p > 50u ? 1u : 0u;
+  const uint32_t lps = lps_of(row, e.range);
+  const uint32_t rmps = e.range - lps;
+  const bool is_lps = bin != mps;
+  const uint32_t r = is_lps ? lps : rmps;
+  const uint32_t n = clz32(r) - 23u;
+  e.low = (e.low + (is_lps ? rmps : 0u)) << n;
+  e.range = r << n;
+  e.W += (int32_t)n;
 }
 
 // one 9-bit lead value through the outstanding-byte logic of writeOut, ref: :388-411
@@ -666,6 +702,23 @@ CABAC_HD uint32_t dec_bin_ep(DecCore &d) {  // ref: :288-331
   return one ? 1u : 0u;
 }
 
+// decodeBinProb for p != 50 (ref: CABAC_ArithmeticDecoder.cpp:192-286) in the look-ahead formulation; needs sh >= 7 and
+// takes at most 6 bits, like a context bin
+CABAC_HD uint32_t dec_bin_prob(DecCore &d, uint32_t p, uint32_t row) {
+  const uint32_t mps = p > 50u ? 1u : 0u;
+  const uint32_t lps = lps_of(row, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  uint32_t diff;
+  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
+  const uint32_t r = mps_path ? rmps : lps;
+  const uint32_t n = clz32(r) - 23u;
+  d.v = mps_path ? d.v : diff;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return mps_path ? mps : 1u - mps;
+}
+
 // decodeBinTrm + the two asserts of finish() as flags; len = payload length of this stream.
 // last_byte_at(i) must return payload byte i (i < len).
 // nbits = payload bits merged into v so far (8 x the bytes taken from a byte source).
@@ -762,6 +815,33 @@ CABAC_HD uint32_t ref_dec_bin_ep(RefDec &r, Rd &rd) {  // ref: :288-331
     return 1u;
   }
   return 0u;
+}
+template <class Rd>
+CABAC_HD uint32_t ref_dec_bin_prob(RefDec &r, uint32_t p, uint32_t row, Rd &rd) {  // ref: :192-286, p != 50
+  const uint32_t mps = p > 50u ? 1u : 0u;
+  const uint32_t lps = (row >> (8u * ((r.range >> 6) & 3u))) & 0xFFu;
+  r.range -= lps;
+  const uint32_t scaled = r.range << 7;
+  if (r.value < scaled) {
+    if (scaled < (256u << 7)) {
+      r.range = scaled >> 6;
+      r.value += r.value;
+      if (++r.need == 0) {
+        r.need = -8;
+        r.value += rd();
+      }
+    }
+    return mps;
+  }
+  const uint32_t n = clz32(lps) - 23u;
+  r.value = (r.value - scaled) << n;
+  r.range = lps << n;
+  r.need += (int32_t)n;
+  if (r.need >= 0) {
+    r.value += rd() << r.need;
+    r.need -= 8;
+  }
+  return 1u - mps;
 }
 // decodeBinTrm + the two asserts of finish() as flags.  nread = payload bytes handed out by rd so far (it keeps counting
 // past the end), last = the byte the most recent rd() returned, len = payload length of the stream

@@ -18,7 +18,8 @@
 namespace isscabac {
 
 struct SymParams {
-  uint32_t method;    // 0 = TU (max value nq-1), 1 = EGk
+  uint32_t method;    // 0 = TU (max value nq-1), 1 = EGk; encode only: 2 = TRk, 3 = FL32 (cabacBinarizer.m:39-54,71-75;
+                      // the reference cannot decode those either: cabacDecodeSymbolFinished.m:12-30)
   uint32_t k;         // EG order
   uint32_t nq;        // number of quantisation levels (symbols are 0..nq-1)
   uint32_t selector;  // 0 = demo (3 contexts), 1 = ISS (7*nlbp+2 contexts)
@@ -56,6 +57,17 @@ CABAC_HD BinString binarize(uint32_t v, const SymParams &P) {
     g.bits = low_mask(v);
     g.len = v == mx ? mx : v + 1;
     g.np = v == mx ? 0u : v + 1;
+  } else if (P.method == 2) {  // TRCode: floor(v / 2^k) ones, a zero, k suffix bits (all ones from the maximum on: the
+                               // reference's escape branch is a TODO that leaves the suffix as initialised)
+    const uint32_t n_p = (v >> P.k) + 1;
+    const uint32_t v_s = v >= P.nq - 1 ? low_mask(P.k) : v - ((n_p - 1) << P.k);
+    g.bits = low_mask(n_p - 1) | (P.k ? bitrev(v_s, P.k) << n_p : 0u);
+    g.len = n_p + P.k;
+    g.np = n_p;
+  } else if (P.method == 3) {  // FLCode(v, 32): 32 bins, MSB first
+    g.bits = bitrev(v, 32);
+    g.len = 32;
+    g.np = first_zero_1based(g.bits, 32);
   } else {  // EGCode
     const uint32_t t = (v >> P.k) + 1;
     const uint32_t n_p = 32u - clz32(t);  // floor(log2(t)) + 1

@@ -94,6 +94,8 @@ struct SymEncArgs {
   uint32_t *lens, *nbins_out;
   uint32_t *ctx_hist, *ctx_cost;  // optional statistics (include/isscabac.h: isscabac_symbol_stats)
   uint16_t *sym_bits;
+  uint32_t *bin_trace;  // optional: one trace record per coded bin (cabac_stream.hip: trace_record), bin_trace_pitch per stream
+  uint32_t bin_trace_pitch;
   uint64_t S, slot_stride;
   uint32_t nsym, pitch, nctx;
   SymParams P;
@@ -133,7 +135,8 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   if (!valid) return;  // the only cross-lane operation below is a ballot over the lanes still coding
   uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   const uint8_t *row = a.sym + s * a.pitch;
-  const bool want_stats = a.ctx_hist || a.ctx_cost || a.sym_bits;
+  const bool want_stats = a.ctx_hist || a.ctx_cost || a.sym_bits || a.bin_trace;
+  uint32_t *btrace = a.bin_trace ? a.bin_trace + s * a.bin_trace_pitch : nullptr;
   EncCore e;
   enc_start(e);
   SymSink sink{wbase + kSymStateBytes + lane * 16, a.slots + s * a.slot_stride, 0};
@@ -165,7 +168,12 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
     }
     const uint32_t c = w.ctx(a.P);
     const uint32_t before = sink.pos;  // 8 * pos = the reference's getNumBits()
+    const uint32_t q_before = btrace ? st.load(c) : 0u;
     enc_bin_at_mem(e, SymBin{(w.cur.bits >> (w.n - 1)) & 1u}, st.addr(c), st);
+    // the record format of the per-bin handle's traces (isscabac_trace_stats reduces both)
+    if (btrace)
+      btrace[nbins] = c | (((w.cur.bits >> (w.n - 1)) & 1u) << 10) | (1u << 11) | (packed_from_q(q_before) << 16) |
+                      (packed_from_q(st.load(c)) << 24);
     // bytes leave at the reference's cadence (a write-out test per bin) when the statistics are wanted -- they are
     // defined through getNumBits() -- and otherwise only when some lane still coding could overflow `low` with its next
     // bins (W < 39 => W <= 62 after four more): the bytes are the same either way
@@ -592,6 +600,10 @@ static uint32_t max_bins_of(const SymParams &P) {
     uint32_t len;
     if (P.method == 0) {
       len = v == P.nq - 1 ? P.nq - 1 : v + 1;
+    } else if (P.method == 2) {
+      len = (v >> P.k) + 1 + P.k;
+    } else if (P.method == 3) {
+      len = 32;
     } else {
       const uint32_t t = (v >> P.k) + 1;
       uint32_t n_p = 0;
@@ -608,11 +620,13 @@ static uint32_t max_bins_of(const SymParams &P) {
 using namespace isscabac;
 
 static int sym_check(isscabac_engine *e, const char *who, uint64_t S, uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *p,
-                     const uint8_t *ctx_init, int nctx, SymParams *P, uint32_t *init_words, uint32_t *maxbins) {
+                     const uint8_t *ctx_init, int nctx, SymParams *P, uint32_t *init_words, uint32_t *maxbins, bool encoding) {
   if (!e) return ISSCABAC_ERR_ARG;
   if (!p || !ctx_init) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: null argument", who);
   if (S == 0 || pitch == 0 || (pitch & 15u) || nsym > pitch) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: bad S / nsym / pitch", who);
-  if (p->binarization > 1 || p->selector > 1 || p->k > 4) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: unsupported binarisation / selector", who);
+  if (p->binarization > ISSCABAC_BIN_FL32 || p->selector > 1 || p->k > 4) return engine_fail(e, ISSCABAC_ERR_ARG, "%s: unsupported binarisation / selector", who);
+  if (p->binarization > ISSCABAC_BIN_EGK && !encoding)  // ref: cabacDecodeSymbolFinished.m:12-30 knows TU and EG0..2 only
+    return engine_fail(e, ISSCABAC_ERR_ARG, "%s: TRk / FL32 bin strings cannot be decoded (the reference has no end-of-symbol rule for them)", who);
   P->method = p->binarization;
   P->k = p->k;
   P->nq = p->nq;
@@ -714,7 +728,7 @@ int isscabac_iss_init_context_model(isscabac_engine *e, const uint8_t *sym, uint
 }
 
 uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *p) {
-  if (!p || p->binarization > 1) return 0;
+  if (!p || p->binarization > ISSCABAC_BIN_FL32) return 0;
   SymParams P{p->binarization, p->k, p->nq, p->selector, p->iss_types, p->nlbp, p->col_rows};
   const uint32_t m = max_bins_of(P);
   return m > 32 ? 0 : m;
@@ -756,7 +770,11 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   a.ctx_cost = d_stats ? d_stats->ctx_cost : nullptr;
   a.sym_bits = d_stats ? d_stats->sym_bits : nullptr;
   uint32_t maxbins = 0;
-  int rc = sym_check(e, "isscabac_encode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins);
+  a.bin_trace = d_stats ? d_stats->bin_trace : nullptr;
+  a.bin_trace_pitch = d_stats ? d_stats->bin_trace_pitch : 0;
+  int rc = sym_check(e, "isscabac_encode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins, true);
+  if (!rc && a.bin_trace && a.bin_trace_pitch < (uint64_t)nsym * maxbins)
+    rc = engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols_dev: bin_trace_pitch (%u) is below nsym x %u bins", a.bin_trace_pitch, maxbins);
   if (rc) return rc;
   if (!d_sym || !d_payload || !d_offsets || (reinterpret_cast<uintptr_t>(d_sym) & 15u))
     return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols_dev: null or misaligned buffer");
@@ -804,7 +822,7 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
                                 uint32_t *d_status) {
   SymDecArgs a;
   uint32_t maxbins = 0;
-  int rc = sym_check(e, "isscabac_decode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins);
+  int rc = sym_check(e, "isscabac_decode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins, false);
   if (rc) return rc;
   if (!d_payload || !d_offsets || !d_sym_out || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols_dev: null or misaligned buffer");
@@ -871,14 +889,19 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, in_bytes, hipMemcpyHostToDevice, e->stream));
   if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
   // statistics: one device block behind the staged symbols' own buffer [hist | cost | sym_bits]
-  isscabac_symbol_stats dst = {nullptr, nullptr, nullptr};
-  const uint64_t hbytes = S * ISSCABAC_STAT_CTX * sizeof(uint32_t), sbytes = S * pitch * sizeof(uint16_t);
-  if (stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits)) {
-    if ((rc = sym_grow(e, &e->stage[1], &e->stage_bytes[1], 2 * hbytes + sbytes))) return rc;
+  isscabac_symbol_stats dst = {nullptr, nullptr, nullptr, nullptr, 0};
+  const uint64_t hbytes = S * ISSCABAC_STAT_CTX * sizeof(uint32_t), sbytes = (S * pitch * sizeof(uint16_t) + 3) & ~3ull;
+  const uint64_t tbytes = stats && stats->bin_trace ? S * (uint64_t)stats->bin_trace_pitch * sizeof(uint32_t) : 0;
+  if (stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits || stats->bin_trace)) {
+    if ((rc = sym_grow(e, &e->stage[1], &e->stage_bytes[1], 2 * hbytes + sbytes + tbytes))) return rc;
     uint8_t *b = static_cast<uint8_t *>(e->stage[1]);
     if (stats->ctx_hist) dst.ctx_hist = reinterpret_cast<uint32_t *>(b);
     if (stats->ctx_cost) dst.ctx_cost = reinterpret_cast<uint32_t *>(b + hbytes);
     if (stats->sym_bits) dst.sym_bits = reinterpret_cast<uint16_t *>(b + 2 * hbytes);
+    if (stats->bin_trace) {
+      dst.bin_trace = reinterpret_cast<uint32_t *>(b + 2 * hbytes + sbytes);
+      dst.bin_trace_pitch = stats->bin_trace_pitch;
+    }
   }
   uint64_t total = 0;
   rc = isscabac_encode_symbols_stats_dev(e, static_cast<uint8_t *>(e->stage[0]),
@@ -888,7 +911,8 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   if (rc) return rc;
   if (dst.ctx_hist) HIP_TRY(e, hipMemcpyAsync(stats->ctx_hist, dst.ctx_hist, hbytes, hipMemcpyDeviceToHost, e->stream));
   if (dst.ctx_cost) HIP_TRY(e, hipMemcpyAsync(stats->ctx_cost, dst.ctx_cost, hbytes, hipMemcpyDeviceToHost, e->stream));
-  if (dst.sym_bits) HIP_TRY(e, hipMemcpyAsync(stats->sym_bits, dst.sym_bits, sbytes, hipMemcpyDeviceToHost, e->stream));
+  if (dst.sym_bits) HIP_TRY(e, hipMemcpyAsync(stats->sym_bits, dst.sym_bits, S * pitch * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
+  if (dst.bin_trace) HIP_TRY(e, hipMemcpyAsync(stats->bin_trace, dst.bin_trace, tbytes, hipMemcpyDeviceToHost, e->stream));
   if (total_bytes) *total_bytes = total;
   if (total > payload_cap)
     return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols: payload needs %llu bytes, capacity is %llu",

@@ -14,6 +14,12 @@ import numpy as np
 from . import build as _build
 
 BYPASS = 0xFF
+PROB_BASE = 155  # ctx byte ISSCABAC_PROB(p) = PROB_BASE + p: fixed-probability bin (batches of at most 128 contexts)
+OP_BYPASS = 0xFFFF  # 16-bit ops of the single-stream handle (ISSCABAC_OP_*)
+
+
+def op_prob(p):
+    return 0x8000 | int(p)
 
 _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
@@ -35,15 +41,16 @@ class SymbolParams(C.Structure):
         return cls(0, 0, nq, 0, 0, 0, 0)
 
     @classmethod
-    def iss(cls, nq, method="EG", k=0, types=15, nlbp=3, col_rows=0):
+    def iss(cls, nq, method="EG", k=0, types=15, nlbp=3, col_rows=0):  # method: "TU", "EG", encode only: "TR", "FL32"
         """ISS defaults (ISS/ISS.m:49-53): EG0, {cond0, cond1, conds0, conds1}, Nlbp = 3 -> 23 contexts.
         col_rows > 0: whole-matrix stream (columns back to back), the reference's one-file-per-matrix mode."""
-        return cls(0 if method == "TU" else 1, k, nq, 1, types, nlbp, col_rows)
+        return cls({"TU": 0, "EG": 1, "TR": 2, "FL32": 3}[method], k, nq, 1, types, nlbp, col_rows)
 
 
 class SymbolStats(C.Structure):
     """isscabac_symbol_stats: the encoder-side statistics of +coder/cabacEncode.m (ctxHist, ctxCost, H)."""
-    _fields_ = [("ctx_hist", C.POINTER(C.c_uint32)), ("ctx_cost", C.POINTER(C.c_uint32)), ("sym_bits", C.POINTER(C.c_uint16))]
+    _fields_ = [("ctx_hist", C.POINTER(C.c_uint32)), ("ctx_cost", C.POINTER(C.c_uint32)), ("sym_bits", C.POINTER(C.c_uint16)),
+                ("bin_trace", C.POINTER(C.c_uint32)), ("bin_trace_pitch", C.c_uint32)]
 
 
 STAT_CTX = 64
@@ -130,6 +137,12 @@ def _load():
     L.isscabac_stream_decode_start.argtypes = [_vp, _u8p, C.c_uint64]
     L.isscabac_stream_decode_bins.argtypes = [_vp, _u8p, C.c_uint32, _u8p]
     L.isscabac_stream_decode_finish.argtypes = [_vp, _u32p]
+    _u16p = C.POINTER(C.c_uint16)
+    L.isscabac_stream_encode_ops.argtypes = [_vp, _u8p, _u16p, C.c_uint32]
+    L.isscabac_stream_decode_ops.argtypes = [_vp, _u16p, C.c_uint32, _u8p]
+    L.isscabac_stream_set_trace.argtypes = [_vp, C.c_int]
+    L.isscabac_stream_get_stats.argtypes = [_vp, C.c_int, C.c_int, _u8p, C.c_uint64, _u64p, _u32p]
+    L.isscabac_trace_stats.argtypes = [_u32p, C.c_uint64, C.c_int, C.c_int, _u8p, C.c_uint64, _u64p, _u32p]
     L.isscabac_set_profiling.argtypes = [_vp, C.c_int]
     L.isscabac_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
     L.isscabac_synth_fill_dev.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -169,6 +182,21 @@ def init_by_state(triples):
     if rc:
         raise EngineError(rc, "init_by_state: mps must be 0/1 and state 0..62")
     return out
+
+
+def trace_stats(records, ctx, decoder=False):
+    """isscabac_trace_stats: trace records (uint32) of one stream -> (trace [N, 5] uint8, transitions [128, 128] uint32)
+    of context `ctx`, the two outputs of the reference's getEncoderStats / getDecoderStats."""
+    L = _load()
+    rec = _np(records, np.uint32).ravel()
+    n = C.c_uint64(0)
+    trans = np.zeros((128, 128), np.uint32)
+    rc = L.isscabac_trace_stats(_ptr(rec, _u32p), rec.size, int(ctx), int(bool(decoder)), None, 0, C.byref(n), _ptr(trans, _u32p))
+    if rc:
+        raise EngineError(rc, "isscabac_trace_stats")
+    trace = np.zeros((max(1, int(n.value)), 5), np.uint8)
+    L.isscabac_trace_stats(_ptr(rec, _u32p), rec.size, int(ctx), int(bool(decoder)), _ptr(trace, _u8p), trace.shape[0], C.byref(n), None)
+    return trace[:int(n.value)].copy(), trans
 
 
 def stream_bound(nbins):
@@ -338,9 +366,10 @@ class Engine:
                                                     _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p)))
         return payload[:int(total.value)].copy(), offsets, nbins
 
-    def encode_symbols_stats(self, sym, params, ctx_init, nsym=None):
+    def encode_symbols_stats(self, sym, params, ctx_init, nsym=None, trace=False):
         """encode_symbols plus cabacEncode.m's statistics: returns (payload, offsets, bins_per_stream,
-        ctx_hist uint32[S, 64], ctx_cost uint32[S, 64], sym_bits uint16[S, R])."""
+        ctx_hist uint32[S, 64], ctx_cost uint32[S, 64], sym_bits uint16[S, R]) and, with trace=True, the per-bin state
+        trace records uint32[S, R * max_bins] (trace_stats() reduces one stream's records to getEncoderStats' outputs)."""
         sym = _np(sym, np.uint8)
         S, R = sym.shape
         pitch = max(16, (R + 15) // 16 * 16)
@@ -357,13 +386,17 @@ class Engine:
         hist = np.zeros((S, STAT_CTX), np.uint32)
         cost = np.zeros((S, STAT_CTX), np.uint32)
         hb = np.zeros((S, pitch), np.uint16)
+        rec = np.zeros((S, R * mb), np.uint32) if trace else None
         st = SymbolStats(hist.ctypes.data_as(C.POINTER(C.c_uint32)), cost.ctypes.data_as(C.POINTER(C.c_uint32)),
-                         hb.ctypes.data_as(C.POINTER(C.c_uint16)))
+                         hb.ctypes.data_as(C.POINTER(C.c_uint16)),
+                         rec.ctypes.data_as(C.POINTER(C.c_uint32)) if trace else None, R * mb if trace else 0)
         total = C.c_uint64(0)
         self._check(self._L.isscabac_encode_symbols_stats(self._h, _ptr(symp, _u8p), _ptr(ns, _u32p), S, R, pitch,
                                                           C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p),
                                                           cap, _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p),
                                                           C.byref(st)))
+        if trace:
+            return payload[:int(total.value)].copy(), offsets, nbins, hist, cost, hb[:, :R].copy(), rec
         return payload[:int(total.value)].copy(), offsets, nbins, hist, cost, hb[:, :R].copy()
 
     def decode_symbols(self, payload, offsets, R, params, ctx_init, nsym=None):
@@ -443,6 +476,32 @@ class Stream:
         b, c = _np(bins, np.uint8).ravel(), _np(ctx, np.uint8).ravel()
         assert b.size == c.size
         self._eng._check(self._L.isscabac_stream_encode_bins(self._s, _ptr(b, _u8p), _ptr(c, _u8p), b.size))
+
+    def encode_ops(self, bins, ops):
+        """16-bit ops (ISSCABAC_OP_*): a context index up to 998, OP_BYPASS, or op_prob(p)."""
+        b, o = _np(bins, np.uint8).ravel(), _np(ops, np.uint16).ravel()
+        assert b.size == o.size
+        self._eng._check(self._L.isscabac_stream_encode_ops(self._s, _ptr(b, _u8p), _ptr(o, C.POINTER(C.c_uint16)), b.size))
+
+    def decode_ops(self, ops):
+        o = _np(ops, np.uint16).ravel()
+        out = np.zeros(o.size, np.uint8)
+        self._eng._check(self._L.isscabac_stream_decode_ops(self._s, _ptr(o, C.POINTER(C.c_uint16)), o.size, _ptr(out, _u8p)))
+        return out
+
+    def set_trace(self, on=True):
+        self._eng._check(self._L.isscabac_stream_set_trace(self._s, int(bool(on))))
+
+    def get_stats(self, ctx, decoder=False):
+        """(trace [N, 5] uint8, transitions [128, 128] uint32): getEncoderStats / getDecoderStats of context `ctx`."""
+        n = C.c_uint64(0)
+        trans = np.zeros((128, 128), np.uint32)
+        self._eng._check(self._L.isscabac_stream_get_stats(self._s, int(bool(decoder)), int(ctx), None, 0, C.byref(n),
+                                                           _ptr(trans, _u32p)))
+        trace = np.zeros((max(1, int(n.value)), 5), np.uint8)
+        self._eng._check(self._L.isscabac_stream_get_stats(self._s, int(bool(decoder)), int(ctx), _ptr(trace, _u8p),
+                                                           trace.shape[0], C.byref(n), None))
+        return trace[:int(n.value)].copy(), trans
 
     def num_bits(self):
         v = C.c_uint64(0)

@@ -38,6 +38,7 @@ class cabacWrapper:
         flat = self.contextModelInitOptions.ravel(order="F")  # the MEX reads the MATLAB array column-major
         self.ctx_init = _engine.init_by_prob(flat) if initByProb else _engine.init_by_state(flat)
         self.cabac_handle = _engine.Stream(self._engine, self.ctx_init)
+        self.cabac_handle.set_trace(True)  # what the reference's Windows build always records (getEncoderStats)
 
     # ---- per-bin commands ----------------------------------------------------------------------------
     def encodeStart(self):
@@ -52,7 +53,7 @@ class cabacWrapper:
         # ref: cabacWrapper.m:45-52 (client-side check) and SimpleCABACMex.cpp:210-247
         if binValue not in (0, 1):
             raise ValueError("bin value to be encoded should either be 1 or 0")
-        self.cabac_handle.encode_bins([int(binValue)], [int(ctxID)])
+        self.cabac_handle.encode_ops([int(binValue)], [self._ctx_op(ctxID)])
 
     def getNumBits(self):
         return self.cabac_handle.num_bits()  # ref: SimpleCABACMex.cpp:248-264
@@ -71,17 +72,44 @@ class cabacWrapper:
         self.cabac_handle.decode_start(np.frombuffer(data, np.uint8))
 
     def decodeBin(self, ctxID):
-        return int(self.cabac_handle.decode_bins([int(ctxID)])[0])  # ref: :301-335
+        return int(self.cabac_handle.decode_ops([self._ctx_op(ctxID)])[0])  # ref: :301-335
 
     def decodeFinish(self):
         # ref: :336-354; the reference asserts on a broken stream, here the flags come back (0 = intact)
         return self.cabac_handle.decode_finish()
 
-    def getEncoderStats(self, ctxID):
-        # compiled only into the Windows MEX (ref: CommonDef.h:39-43); on Linux the reference falls through to this
-        raise RuntimeError("Error: Invalid Command")
+    def _ctx_op(self, ctxID):
+        # the reference does not range-check the context (ref: :223-224) and indexes a 1000-entry array with it; here an
+        # index outside the initialised contexts is an error, never an alias of another context or a bypass bin
+        c = float(ctxID)
+        if c != int(c) or not 0 <= c < self.ctx_init.size:
+            raise ValueError("Error: invalid context index")
+        return int(c)
 
-    getDecoderStats = getEncoderStats
+    def getEncoderStats(self, ctxID):
+        """[trace, stats] = getEncoderStats(ctxID) of the reference's Windows build (ref: cabacWrapper.m:68-70,
+        SimpleCABACMex.cpp:356-412): trace 5 x N uint8 (one column per bin coded with the context: bin, state before,
+        mps before, state after, mps after; states numbered like ContextModel.cpp:128-129), stats 128 x 128 uint32."""
+        trace, trans = self.cabac_handle.get_stats(self._ctx_op(ctxID), decoder=False)
+        return trace.T.copy(), trans
+
+    def getDecoderStats(self, ctxID):
+        trace, trans = self.cabac_handle.get_stats(self._ctx_op(ctxID), decoder=True)  # ref: :413-466
+        return trace.T.copy(), trans
+
+    # ---- additive: the engine's other two bin kinds, per bin (the reference's MEX reaches neither) -----------------
+    def encodeBinEP(self, binValue):
+        self.cabac_handle.encode_ops([int(binValue)], [_engine.OP_BYPASS])  # ref: CABAC_ArithmeticEncoder.cpp:250-270
+
+    def decodeBinEP(self):
+        return int(self.cabac_handle.decode_ops([_engine.OP_BYPASS])[0])
+
+    def encodeBinProb(self, binValue, probability):
+        """probability of the bin being 1 in percent (ref: encodeBinProb, CABAC_ArithmeticEncoder.cpp:180-243)"""
+        self.cabac_handle.encode_ops([int(binValue)], [_engine.op_prob(probability)])
+
+    def decodeBinProb(self, probability):
+        return int(self.cabac_handle.decode_ops([_engine.op_prob(probability)])[0])
 
     # ---- batch extension -------------------------------------------------------------------------------
     def encodeBatch(self, bins, ctx, nbins=None):

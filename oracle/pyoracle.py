@@ -25,6 +25,9 @@ u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)
 
 
+_METHOD = {"TU": 0, "EG": 1, "TR": 2, "FL32": 3}  # cabacBinarizer.m:10-27 (TR / FL32: encode side only)
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 
@@ -306,10 +309,10 @@ class Oracle:
     def iss_encode_column(self, sym, nq, method, k, types, nlbp, ctx_init):
         sym = np.ascontiguousarray(sym, np.uint32)
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
-        cap = self.stream_cap(sym.size * 96)
+        cap = self.stream_cap(sym.size * 320)
         out = np.zeros(cap, np.uint8)
         nb = C.c_uint32(0)
-        n = self.lib.orc_iss_encode_column(_p(sym, u32p), sym.size, nq, 0 if method == "TU" else 1, k, types, nlbp,
+        n = self.lib.orc_iss_encode_column(_p(sym, u32p), sym.size, nq, _METHOD[method], k, types, nlbp,
                                            _p(ctx_init, u8p), ctx_init.size, _p(out, u8p), cap, C.byref(nb))
         return out[:n].copy(), int(nb.value)
 
@@ -317,7 +320,7 @@ class Oracle:
         payload = np.ascontiguousarray(payload, np.uint8)
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
         sym = np.zeros(rows, np.uint32)
-        st = self.lib.orc_iss_decode_column(_p(payload, u8p), payload.size, rows, nq, 0 if method == "TU" else 1, k,
+        st = self.lib.orc_iss_decode_column(_p(payload, u8p), payload.size, rows, nq, _METHOD[method], k,
                                             types, nlbp, _p(ctx_init, u8p), ctx_init.size, _p(sym, u32p))
         return sym, int(st)
 
@@ -327,10 +330,10 @@ class Oracle:
         rows, cols = G.shape
         sym = np.ascontiguousarray(G.T, np.uint32).ravel()
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
-        cap = self.stream_cap(sym.size * 96)
+        cap = self.stream_cap(sym.size * 320)
         out = np.zeros(cap, np.uint8)
         nb = C.c_uint32(0)
-        n = self.lib.orc_iss_encode_matrix(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp,
+        n = self.lib.orc_iss_encode_matrix(_p(sym, u32p), rows, cols, nq, _METHOD[method], k, types, nlbp,
                                            _p(ctx_init, u8p), ctx_init.size, _p(out, u8p), cap, C.byref(nb))
         return out[:n].copy(), int(nb.value)
 
@@ -340,7 +343,7 @@ class Oracle:
         rows, cols = G.shape
         sym = np.ascontiguousarray(G.T, np.uint32).ravel()
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
-        cap = self.stream_cap(sym.size * 96)
+        cap = self.stream_cap(sym.size * 320)
         out = np.zeros(cap, np.uint8)
         n = 7 * nlbp + 2
         hist, cost, H = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(rows * cols, np.uint32)
@@ -348,7 +351,7 @@ class Oracle:
         f.restype = C.c_size_t
         f.argtypes = [u32p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint, C.c_int, u8p, C.c_int, u8p,
                       C.c_size_t, u32p, u32p, u32p]
-        m = f(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp, _p(ctx_init, u8p), ctx_init.size,
+        m = f(_p(sym, u32p), rows, cols, nq, _METHOD[method], k, types, nlbp, _p(ctx_init, u8p), ctx_init.size,
               _p(out, u8p), cap, _p(hist, u32p), _p(cost, u32p), _p(H, u32p))
         return out[:m].copy(), hist, cost, H.reshape(cols, rows).T.copy()
 
@@ -356,7 +359,7 @@ class Oracle:
         payload = np.ascontiguousarray(payload, np.uint8)
         ctx_init = np.ascontiguousarray(ctx_init, np.uint8)
         sym = np.zeros(rows * cols, np.uint32)
-        st = self.lib.orc_iss_decode_matrix(_p(payload, u8p), payload.size, rows, cols, nq, 0 if method == "TU" else 1,
+        st = self.lib.orc_iss_decode_matrix(_p(payload, u8p), payload.size, rows, cols, nq, _METHOD[method],
                                             k, types, nlbp, _p(ctx_init, u8p), ctx_init.size, _p(sym, u32p))
         return sym.reshape(cols, rows).T.copy(), int(st)
 
@@ -366,7 +369,7 @@ class Oracle:
         rows, cols = G.shape
         sym = np.ascontiguousarray(G.T, np.uint32).ravel()
         out = np.zeros(7 * nlbp + 2, np.float64)
-        self.lib.orc_iss_init_context_model(_p(sym, u32p), rows, cols, nq, 0 if method == "TU" else 1, k, types, nlbp,
+        self.lib.orc_iss_init_context_model(_p(sym, u32p), rows, cols, nq, _METHOD[method], k, types, nlbp,
                                             _p(out, f64p))
         return out, np.array([self.lib.orc_matlab_uint8_of_p(float(v)) for v in out], np.uint8)
 

@@ -17,6 +17,7 @@ namespace {
 
 const uint32_t kLpsRow[64] = {ISSCABAC_LPS_ROWS};
 const uint8_t kTransLps[64] = {ISSCABAC_TRANS_LPS};
+const uint32_t kProbRow[49] = {ISSCABAC_PROB_ROWS};
 struct NextTab {
   uint32_t e[64];
   NextTab() {
@@ -146,8 +147,7 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   enc_start(e);
   int mw = 0;
   for (uint32_t i = 0; i < n; i++) {
-    if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] != kBypass && ctx[i + 1] != kBypass && ctx[i + 2] != kBypass &&
-        ctx[i + 3] != kBypass) {
+    if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] < 128 && ctx[i + 1] < 128 && ctx[i + 2] < 128 && ctx[i + 3] < 128) {
       EncWordAcc acc;
       if (lat) {  // the kernel's order: read bin k + 1's state, then store bin k's successor, forward on equal addresses
         uint32_t at = st.addr(ctx[i]), at_prev = 0, nx_prev = 0, qld = st.load_at(at);
@@ -173,7 +173,11 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
       if (e.W > 62) return -2;
       continue;
     }
-    if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);
+    const bool prob = nctx <= 128 && is_prob_byte(ctx[i]);  // the batch kernels' rule
+    if (prob && ctx[i] != kProbBase + 50u) {
+      if (prob_valid(ctx[i] - kProbBase)) enc_bin_prob(e, bins[i], ctx[i] - kProbBase, kProbRow[prob_row_index(ctx[i] - kProbBase)]);
+    } else if (prob) enc_bin_ep(e, bins[i]);
+    else if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);
     else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
     else if (memtab) enc_bin_at_mem(e, HostBin{bins[i]}, st.addr(ctx[i]), st);
     else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
@@ -217,7 +221,10 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   if (noguard) group = 4;
   uint32_t pairs = 0;
   bool has_bypass = any;  // the kernel guards with 8 instead of 7 when a chunk holds bypass bins
-  for (uint32_t i = 0; i < n; i++) has_bypass |= ctx[i] == kBypass;
+  // the batch kernels' rule for fixed-probability bins: ctx byte kProbBase + p in batches of at most 128 contexts
+  auto prob_of = [&](uint32_t i) -> uint32_t { return nctx <= 128 && is_prob_byte(ctx[i]) ? ctx[i] - kProbBase : 0u; };
+  auto is_ep = [&](uint32_t i) { return ctx[i] == kBypass || prob_of(i) == 50u; };
+  for (uint32_t i = 0; i < n; i++) has_bypass |= is_ep(i);
   const int32_t min_sh = has_bypass ? 8 : 7;
   HostStates st;
   st.init(ctx_init, nctx);
@@ -245,24 +252,28 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
     }
     if (noguard && i % 4 == 3) dec_guard(d, src, min_sh);
     if (noguard) {
-      if (d.sh < (ctx[i] == kBypass ? 8 : 7)) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
+      if (d.sh < (is_ep(i) ? 8 : 7)) return 0xDEAD0000u | i;  // the no-guard argument would be wrong
     } else if (d.sh < 8) {
       dec_refill(d, src);
       slow_refills++;
     }
     if (memtab) {  // bypass bins join the pair format as (bin, 0), like the kernel's mixed chunks
-      if (lat && ctx[i] != kBypass) {
+      if (prob_of(i) && !is_ep(i)) {  // fixed-probability bin: no context model, joins the pair format like a bypass bin
+        lat_have_prev = lat_have_qld = false;
+        const uint32_t pp = prob_of(i);
+        pairs = collect_bin(pairs, prob_valid(pp) ? pair_of_bin(dec_bin_prob(d, pp, kProbRow[prob_row_index(pp)])) : pair_of_bin(0u));
+      } else if (lat && !is_ep(i)) {
         const uint32_t at = st.addr(ctx[i]);
         if (!lat_have_qld) lat_qld = st.load_at(at);  // first bin of a run: nothing was read ahead
         const uint32_t q = (lat_have_prev && at == lat_at_prev) ? lat_nx_prev : lat_qld;
-        lat_have_qld = i + 1 < n && ctx[i + 1] != kBypass && (i + 1) % 16 != 0;  // the kernel reads ahead inside a chunk only
+        lat_have_qld = i + 1 < n && ctx[i + 1] < 128 && (i + 1) % 16 != 0;  // the kernel reads ahead inside a chunk only
         if (lat_have_qld) lat_qld = st.load_at(st.addr(ctx[i + 1]));             // before this bin's store
         pairs = collect_bin(pairs, dec_bin_lat(d, at, q, st, lat_nx_prev));
         lat_at_prev = at;
         lat_have_prev = lat_have_qld;  // forwarding only ever pairs with a read-ahead value
       } else {
         lat_have_prev = lat_have_qld = false;
-        pairs = collect_bin(pairs, ctx[i] != kBypass ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
+        pairs = collect_bin(pairs, !is_ep(i) ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
       }
       if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
         const uint32_t done = i % 16 + 1;
@@ -276,8 +287,10 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       }
       continue;
     }
-    if (any) bins_out[i] = (uint8_t)dec_bin_any(d, ctx[i], st);
-    else bins_out[i] = (uint8_t)(ctx[i] == kBypass ? dec_bin_ep(d) : dec_bin(d, ctx[i], st));
+    if (prob_of(i) && !is_ep(i)) bins_out[i] = prob_valid(prob_of(i)) ? (uint8_t)dec_bin_prob(d, prob_of(i), kProbRow[prob_row_index(prob_of(i))]) : 0;
+    else if (is_ep(i)) bins_out[i] = (uint8_t)dec_bin_ep(d);
+    else if (any) bins_out[i] = (uint8_t)dec_bin_any(d, ctx[i], st);
+    else bins_out[i] = (uint8_t)dec_bin(d, ctx[i], st);
   }
   const uint8_t *p = buf + start;
   uint32_t status = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
@@ -299,7 +312,12 @@ uint32_t lane_decode_stream_ref(const uint8_t *payload, uint32_t len, const uint
   RefReader rd{payload, len, 0, 0};
   RefDec r;
   ref_dec_start(r, rd);
-  for (uint32_t i = 0; i < n; i++) bins_out[i] = (uint8_t)(ctx[i] == kBypass ? ref_dec_bin_ep(r, rd) : ref_dec_bin(r, ctx[i], st, rd));
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t pp = nctx <= 128 && is_prob_byte(ctx[i]) ? ctx[i] - kProbBase : 0u;
+    if (ctx[i] == kBypass || pp == 50u) bins_out[i] = (uint8_t)ref_dec_bin_ep(r, rd);
+    else if (pp) bins_out[i] = prob_valid(pp) ? (uint8_t)ref_dec_bin_prob(r, pp, kProbRow[prob_row_index(pp)], rd) : 0;
+    else bins_out[i] = (uint8_t)ref_dec_bin(r, ctx[i], st, rd);
+  }
   return ref_dec_finish(r, rd, len);
 }
 

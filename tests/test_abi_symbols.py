@@ -24,7 +24,7 @@ def test_all_declared_symbols_exported(lib):
     for n in names:
         assert hasattr(lib, n), n
     lib.isscabac_abi_version.restype = ctypes.c_int
-    assert lib.isscabac_abi_version() == 1
+    assert lib.isscabac_abi_version() == 2
 
 
 def test_init_maps_match_oracle(oracle):

@@ -280,8 +280,23 @@ def test_single_stream_handle_per_bin_commands(engine, oracle, golden, tmp_path)
     assert got == sym.tolist()
     with pytest.raises(ValueError):
         enc.encodeBin(2, 0)
-    with pytest.raises(RuntimeError):
-        enc.getEncoderStats(0)
+    # getEncoderStats / getDecoderStats (the reference's Windows build): 5 x N traces and 128 x 128 transition counts
+    ctx_seq, bin_seq, prev_first = [], [], None
+    for v in sym:
+        g = oracle.binarize(int(v), "TU", nq=4)
+        for n, b in enumerate(g, 1):
+            ctx_seq.append((1 if prev_first == 1 else 2) if (n == 1 and prev_first is not None) else 0)
+            bin_seq.append(int(b))
+        prev_first = int(g[0])
+    for c in range(3):
+        for side, w in ((False, enc), (True, dec)):
+            trace, stats = (w.getDecoderStats if side else w.getEncoderStats)(c)
+            want_t, want_x = oracle.trace_stats(bin_seq, ctx_seq, enc.ctx_init, c, decoder=side)
+            assert trace.shape == (5, want_t.shape[0]) and (trace.T == want_t).all() and (stats == want_x).all()
+    with pytest.raises(ValueError):
+        enc.encodeBin(1, 3)  # an index outside the initialised contexts is an error, not an alias
+    with pytest.raises(ValueError):
+        enc.encodeBin(1, -1)
 
 
 def _quantised_matrix(rng, rows, cols, nq):

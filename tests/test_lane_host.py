@@ -326,3 +326,19 @@ def test_symbol_code_tree_matches_the_general_walker(lane):
         params = (C.c_uint32 * 7)(1, 0, nq, 1, 15, 3, 0)
         sym = rng.integers(0, nq, 50).astype(np.uint8)
         assert lane.sym_trie_check(_p(sym), sym.size, params) == 0
+
+
+def test_fixed_probability_bins_match_the_reference(lane):
+    """the lane code's fixed-probability bins (enc_bin_prob / dec_bin_prob / ref_dec_bin_prob) in the batch kernels' byte
+    encoding, against golden vectors produced by the reference compiled with RWTH_CABAC_FIXED_PROBABILITY"""
+    import json
+    from conftest import unbits, unhex
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "cabac_golden_f4.json")))
+    for s in doc["streams"]:
+        bins, ctx, init = unbits(s["bins"], s["n"]), unhex(s["ctx"]), unhex(s["ctx_init"])
+        for mode in (1, 4, 16, 17, 18, 19):
+            got, fin, _ = lane_encode(lane, bins, ctx, init, mode)
+            assert got.tobytes().hex() == s["payload"] and fin.tobytes().hex() == s["ctx_final"], (s["name"], mode)
+        for group in (4, 2, 3, 5):
+            dec, st, dfin, _ = lane_decode(lane, unhex(s["payload"]), ctx, init, pad_front=2, pad_back=3, group=group)
+            assert st == 0 and (dec == bins).all() and dfin.tobytes().hex() == s["ctx_final"], (s["name"], group)
