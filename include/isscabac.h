@@ -65,7 +65,8 @@ enum {
   ISSCABAC_ERR_HIP = 2,      /* HIP runtime error (no GPU, launch failure, ...) */
   ISSCABAC_ERR_NOMEM = 3,    /* device allocation failed */
   ISSCABAC_ERR_CAPACITY = 4, /* caller's payload buffer too small; *total_bytes holds the need */
-  ISSCABAC_ERR_STATE = 5     /* call sequence error on a single-stream handle */
+  ISSCABAC_ERR_STATE = 5,    /* call sequence error on a single-stream handle */
+  ISSCABAC_ERR_IO = 6        /* a file could not be opened, read or written (container calls) */
 };
 
 /* decoder integrity flags (per stream), the two asserts of ref: CABAC_ArithmeticDecoder.cpp:78-81
@@ -320,6 +321,70 @@ int isscabac_stream_get_stats(isscabac_stream *s, int decoder, int ctx, uint8_t 
                               uint64_t *nsteps, uint32_t *transitions);
 int isscabac_trace_stats(const uint32_t *records, uint64_t nrecords, int ctx, int decoder, uint8_t *trace5,
                          uint64_t cap_steps, uint64_t *nsteps, uint32_t *transitions);
+
+/* ---- several GPUs behind one handle, one process (what a MEX / FFI caller can use) -------------------
+ * isscabac_multi owns one engine per listed device.  A batch is split like the multi-process path splits it
+ * (isscabac_amd/sharding.py): streams are independent, device g of n codes the contiguous block
+ * [S*g/n, S*(g+1)/n) (isscabac_multi_shard), nothing is exchanged while coding, and the only communication is the final
+ * bitstream gather.  One host thread per device drives its engine, so the devices work concurrently.  Results are
+ * identical to a single engine's.  A device may be listed more than once (two engines sharing it). */
+typedef struct isscabac_multi isscabac_multi;
+int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out);
+void isscabac_destroy_multi(isscabac_multi *m);
+int isscabac_multi_device_count(const isscabac_multi *m);
+isscabac_engine *isscabac_multi_engine(isscabac_multi *m, int g); /* engine g, e.g. for isscabac_dev_alloc / isscabac_set_tuning */
+const char *isscabac_multi_last_error(const isscabac_multi *m);
+void isscabac_multi_shard(const isscabac_multi *m, uint64_t S, int g, uint64_t *first, uint64_t *end);
+/* host buffers: as isscabac_encode_batch / isscabac_decode_batch */
+int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const uint8_t *ctx,
+                                const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                                uint64_t *offsets, uint64_t *total_bytes);
+int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                                const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status);
+/* device-resident shards: d_bins[g] / d_ctx[g] (/ d_nbins[g], the array or its entries may be NULL) live on device g and
+ * hold that device's block of streams; the payload and the S + 1 offsets are gathered on the FIRST listed device with
+ * hipMemcpyPeerAsync, every device pushing its piece straight to the root (no ring). */
+int isscabac_multi_encode_batch_dev(isscabac_multi *m, const uint8_t *const *d_bins, const uint8_t *const *d_ctx,
+                                    const uint32_t *const *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                    const uint8_t *ctx_init, int nctx, uint8_t *d_payload_root, uint64_t payload_cap,
+                                    uint64_t *d_offsets_root, uint64_t *total_bytes);
+
+/* ---- on-disk container (host side, no GPU work) --------------------------------------------------------------------
+ * The reference hands encoder output to the decoder through ONE FILE PER STREAM (ref: CABAC/SimpleCABACMex.cpp:195,288)
+ * and sizes results by `dir(fn).bytes * 8` (ref: CABAC/cabacDemo.m:190-191, ISS/+coder/cabacEncode.m:100-101).  These two
+ * calls convert between a batch (payload + offsets) and those files: stream s <-> paths[s], byte for byte what the
+ * reference would have written / can read.  isscabac_read_stream_files: ISSCABAC_ERR_CAPACITY (offsets and
+ * *total_bytes complete, nothing useful in payload) when cap is too small; payload may be NULL to ask for the sizes.
+ * Errors of the calls in this section are reported through isscabac_last_error(NULL). */
+int isscabac_write_stream_files(const uint8_t *payload, const uint64_t *offsets, uint64_t S, const char *const *paths);
+int isscabac_read_stream_files(const char *const *paths, uint64_t S, uint8_t *payload, uint64_t cap, uint64_t *offsets,
+                               uint64_t *total_bytes);
+/* the name scheme the MEX gateway's 'writeStreamFiles' / 'readStreamFiles' use: "<prefix>%06llu.bin" */
+int isscabac_stream_file_path(const char *prefix, uint64_t s, char *buf, uint64_t cap);
+
+/* What ISS.m transmits next to its two CABAC streams (ref: ISS/ISS.m:197-201): the quantiser centroids cW and cH, the
+ * matrix Q and -- unless equalProb -- the uint8 context initialisations xw, xh of the two streams (the p0_bytes_out of
+ * isscabac_iss_init_context_model).  The reference only measures this through MATLAB's `save`; here it is a concrete
+ * little-endian file holding the side information and the W and H bitstreams: everything a decoder needs. */
+typedef struct isscabac_iss_side_info {
+  const double *cW; /* ncW centroids */
+  const double *cH; /* ncH centroids */
+  const double *Q;  /* q_rows x q_cols, column-major */
+  const uint8_t *xw, *xh; /* nxw / nxh context initialisation bytes (0 entries with equalProb) */
+  uint32_t ncW, ncH, q_rows, q_cols, nxw, nxh;
+} isscabac_iss_side_info;
+typedef struct isscabac_iss_container_info {
+  uint32_t ncW, ncH, q_rows, q_cols, nxw, nxh;
+  uint64_t w_bytes, h_bytes;
+} isscabac_iss_container_info;
+int isscabac_iss_container_write(const char *path, const isscabac_iss_side_info *si, const uint8_t *w_stream,
+                                 uint64_t w_bytes, const uint8_t *h_stream, uint64_t h_bytes);
+int isscabac_iss_container_sizes(const char *path, isscabac_iss_container_info *out);
+/* buffers sized from isscabac_iss_container_sizes */
+int isscabac_iss_container_read(const char *path, double *cW, double *cH, double *Q, uint8_t *xw, uint8_t *xh,
+                                uint8_t *w_stream, uint8_t *h_stream);
 
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* when enabled, every batch call brackets each of its kernels with hipEvents on the engine's stream */

@@ -56,6 +56,18 @@ class SymbolStats(C.Structure):
 STAT_CTX = 64
 
 
+class IssSideInfo(C.Structure):
+    """isscabac_iss_side_info: what ISS.m transmits next to its two CABAC streams (ISS/ISS.m:197-201)."""
+    _fields_ = [("cW", C.POINTER(C.c_double)), ("cH", C.POINTER(C.c_double)), ("Q", C.POINTER(C.c_double)),
+                ("xw", C.POINTER(C.c_uint8)), ("xh", C.POINTER(C.c_uint8)), ("ncW", C.c_uint32), ("ncH", C.c_uint32),
+                ("q_rows", C.c_uint32), ("q_cols", C.c_uint32), ("nxw", C.c_uint32), ("nxh", C.c_uint32)]
+
+
+class IssContainerInfo(C.Structure):
+    _fields_ = [("ncW", C.c_uint32), ("ncH", C.c_uint32), ("q_rows", C.c_uint32), ("q_cols", C.c_uint32),
+                ("nxw", C.c_uint32), ("nxh", C.c_uint32), ("w_bytes", C.c_uint64), ("h_bytes", C.c_uint64)]
+
+
 class EngineError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("isscabac error %d: %s" % (code, msg))
@@ -140,6 +152,31 @@ def _load():
     _u16p = C.POINTER(C.c_uint16)
     L.isscabac_stream_encode_ops.argtypes = [_vp, _u8p, _u16p, C.c_uint32]
     L.isscabac_stream_decode_ops.argtypes = [_vp, _u16p, C.c_uint32, _u8p]
+    # several devices behind one handle
+    L.isscabac_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]
+    L.isscabac_destroy_multi.argtypes = [_vp]
+    L.isscabac_destroy_multi.restype = None
+    L.isscabac_multi_device_count.argtypes = [_vp]
+    L.isscabac_multi_engine.argtypes = [_vp, C.c_int]
+    L.isscabac_multi_engine.restype = _vp
+    L.isscabac_multi_last_error.argtypes = [_vp]
+    L.isscabac_multi_last_error.restype = C.c_char_p
+    L.isscabac_multi_shard.argtypes = [_vp, C.c_uint64, C.c_int, _u64p, _u64p]
+    L.isscabac_multi_shard.restype = None
+    L.isscabac_multi_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                              _u8p, C.c_uint64, _u64p, _u64p]
+    L.isscabac_multi_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
+                                              C.c_int, _u8p, _u32p]
+    L.isscabac_multi_encode_batch_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_uint64, C.c_uint32,
+                                                  C.c_uint32, _u8p, C.c_int, _vp, C.c_uint64, _vp, _u64p]
+    # on-disk container
+    _strs = C.POINTER(C.c_char_p)
+    L.isscabac_write_stream_files.argtypes = [_u8p, _u64p, C.c_uint64, _strs]
+    L.isscabac_read_stream_files.argtypes = [_strs, C.c_uint64, _u8p, C.c_uint64, _u64p, _u64p]
+    L.isscabac_stream_file_path.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    L.isscabac_iss_container_write.argtypes = [C.c_char_p, C.POINTER(IssSideInfo), _u8p, C.c_uint64, _u8p, C.c_uint64]
+    L.isscabac_iss_container_sizes.argtypes = [C.c_char_p, C.POINTER(IssContainerInfo)]
+    L.isscabac_iss_container_read.argtypes = [C.c_char_p, _f64p, _f64p, _f64p, _u8p, _u8p, _u8p, _u8p]
     L.isscabac_stream_set_trace.argtypes = [_vp, C.c_int]
     L.isscabac_stream_get_stats.argtypes = [_vp, C.c_int, C.c_int, _u8p, C.c_uint64, _u64p, _u32p]
     L.isscabac_trace_stats.argtypes = [_u32p, C.c_uint64, C.c_int, C.c_int, _u8p, C.c_uint64, _u64p, _u32p]
@@ -444,6 +481,152 @@ class Engine:
     def d2h(self, arr, d_src):
         assert arr.flags["C_CONTIGUOUS"]
         self._check(self._L.isscabac_copy_d2h(self._h, _vp(arr.ctypes.data), _vp(d_src), arr.nbytes))
+
+
+def _host_err(rc, what):
+    if rc:
+        raise EngineError(rc, "%s: %s" % (what, _load().isscabac_last_error(None).decode()))
+
+
+def write_stream_files(payload, offsets, paths):
+    """isscabac_write_stream_files: stream s of the batch -> paths[s], the file the reference would have written."""
+    p, o = _np(payload, np.uint8).ravel(), _np(offsets, np.uint64).ravel()
+    arr = (C.c_char_p * len(paths))(*[str(x).encode() for x in paths])
+    _host_err(_load().isscabac_write_stream_files(_ptr(p, _u8p) if p.size else None, _ptr(o, _u64p), o.size - 1, arr),
+              "write_stream_files")
+
+
+def read_stream_files(paths):
+    """isscabac_read_stream_files: one file per stream -> (payload, offsets)."""
+    L = _load()
+    arr = (C.c_char_p * len(paths))(*[str(x).encode() for x in paths])
+    offsets = np.zeros(len(paths) + 1, np.uint64)
+    total = C.c_uint64(0)
+    rc = L.isscabac_read_stream_files(arr, len(paths), None, 0, _ptr(offsets, _u64p), C.byref(total))
+    if rc not in (0, 4):
+        _host_err(rc, "read_stream_files")
+    payload = np.zeros(max(1, int(total.value)), np.uint8)
+    _host_err(L.isscabac_read_stream_files(arr, len(paths), _ptr(payload, _u8p), payload.size, _ptr(offsets, _u64p),
+                                           C.byref(total)), "read_stream_files")
+    return payload[:int(total.value)].copy(), offsets
+
+
+def stream_file_path(prefix, s):
+    buf = C.create_string_buffer(4096)
+    _host_err(_load().isscabac_stream_file_path(str(prefix).encode(), int(s), buf, 4096), "stream_file_path")
+    return buf.value.decode()
+
+
+def iss_container_write(path, cW, cH, Q, xw, xh, w_stream, h_stream):
+    """side information {cW, cH, Q, xw, xh} + the W and H bitstreams -> one file (isscabac_iss_container_write)."""
+    cW, cH = _np(cW, np.float64).ravel(), _np(cH, np.float64).ravel()
+    Q = np.asarray(Q, np.float64)
+    Q = Q.reshape(Q.shape[0], -1) if Q.ndim else Q.reshape(1, 1)
+    Qf = np.asfortranarray(Q)
+    xw, xh = _np(xw, np.uint8).ravel(), _np(xh, np.uint8).ravel()
+    w, h = _np(w_stream, np.uint8).ravel(), _np(h_stream, np.uint8).ravel()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a.size else None
+    bp = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a.size else None
+    si = IssSideInfo(dp(cW), dp(cH), Qf.ctypes.data_as(C.POINTER(C.c_double)) if Qf.size else None, bp(xw), bp(xh), cW.size,
+                     cH.size, Q.shape[0], Q.shape[1], xw.size, xh.size)
+    _host_err(_load().isscabac_iss_container_write(str(path).encode(), C.byref(si), bp(w), w.size, bp(h), h.size),
+              "iss_container_write")
+
+
+def iss_container_read(path):
+    """-> dict(cW, cH, Q, xw, xh, w_stream, h_stream)"""
+    L = _load()
+    n = IssContainerInfo()
+    _host_err(L.isscabac_iss_container_sizes(str(path).encode(), C.byref(n)), "iss_container_sizes")
+    cW, cH = np.zeros(n.ncW), np.zeros(n.ncH)
+    Q = np.zeros((n.q_rows, n.q_cols), order="F")
+    xw, xh = np.zeros(n.nxw, np.uint8), np.zeros(n.nxh, np.uint8)
+    w, h = np.zeros(n.w_bytes, np.uint8), np.zeros(n.h_bytes, np.uint8)
+    pp = lambda a, t: a.ctypes.data_as(t) if a.size else None
+    _host_err(L.isscabac_iss_container_read(str(path).encode(), pp(cW, _f64p), pp(cH, _f64p), pp(Q, _f64p), pp(xw, _u8p),
+                                            pp(xh, _u8p), pp(w, _u8p), pp(h, _u8p)), "iss_container_read")
+    return dict(cW=cW, cH=cH, Q=np.ascontiguousarray(Q), xw=xw, xh=xh, w_stream=w, h_stream=h)
+
+
+class MultiEngine:
+    """isscabac_multi: several GPUs behind one handle in one process.  Streams are split into contiguous blocks, one per
+    device; results equal a single engine's."""
+
+    def __init__(self, devices):
+        self._L = _load()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _vp()
+        rc = self._L.isscabac_create_multi(ids, len(devices), C.byref(h))
+        if rc:
+            raise EngineError(rc, self._L.isscabac_last_error(None).decode())
+        self._h = h
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.isscabac_destroy_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(rc, self._L.isscabac_multi_last_error(self._h).decode())
+
+    def shard(self, S, g):
+        lo, hi = C.c_uint64(0), C.c_uint64(0)
+        self._L.isscabac_multi_shard(self._h, int(S), int(g), C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    def engine_handle(self, g):
+        return self._L.isscabac_multi_engine(self._h, int(g))
+
+    def encode(self, bins, ctx, ctx_init, nbins=None):
+        bins, ctx = _np(bins, np.uint8), _np(ctx, np.uint8)
+        S, B = bins.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        bp, cp = Engine._pad_rows(bins, pitch), Engine._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        cap = S * stream_bound(B)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_multi_encode_batch(self._h, _ptr(bp, _u8p), _ptr(cp, _u8p), _ptr(nb, _u32p), S, B, pitch,
+                                                        _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap, _ptr(offsets, _u64p),
+                                                        C.byref(total)))
+        return payload[:int(total.value)].copy(), offsets
+
+    def decode(self, payload, offsets, ctx, ctx_init, nbins=None):
+        payload, offsets, ctx = _np(payload, np.uint8), _np(offsets, np.uint64), _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        cp = Engine._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        out = np.zeros((S, pitch), np.uint8)
+        status = np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_multi_decode_batch(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(cp, _u8p),
+                                                        _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size, _ptr(out, _u8p),
+                                                        _ptr(status, _u32p)))
+        return out[:, :B].copy(), status
+
+    def encode_dev(self, d_bins, d_ctx, S, nbins, pitch, ctx_init, d_payload_root, payload_cap, d_offsets_root, d_nbins=None):
+        """d_bins / d_ctx: one device address per device (that device's block of streams).  Payload + offsets are gathered
+        on the first device.  Returns the payload size."""
+        ci = _np(ctx_init, np.uint8)
+        pb = (_vp * self.n)(*[_vp(int(x)) for x in d_bins])
+        pc = (_vp * self.n)(*[_vp(int(x)) for x in d_ctx])
+        pn = (_vp * self.n)(*[_vp(int(x) or None) for x in d_nbins]) if d_nbins is not None else None
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_multi_encode_batch_dev(self._h, pb, pc, pn, int(S), int(nbins), int(pitch), _ptr(ci, _u8p),
+                                                            ci.size, _vp(d_payload_root), int(payload_cap), _vp(d_offsets_root),
+                                                            C.byref(total)))
+        return int(total.value)
 
 
 class Stream:

@@ -122,28 +122,6 @@ class cabacWrapper:
 
 
 # ---- on-disk container: the reference keeps ONE FILE PER STREAM (SimpleCABACMex.cpp:195,288) --------------------------
-def write_stream_files(payload, offsets, paths):
-    """Split a batch payload into the files the reference would have written, one per stream, so that callers that
-    read `dir(fn).bytes * 8` (cabacDemo.m:190-191, +coder/cabacEncode.m:100-101) or hand the file to a reference
-    decoder keep working.  Returns the list of file sizes in bytes."""
-    payload = np.asarray(payload, np.uint8)
-    offsets = np.asarray(offsets, np.uint64)
-    assert len(paths) == offsets.size - 1
-    sizes = []
-    for s, path in enumerate(paths):
-        a, b = int(offsets[s]), int(offsets[s + 1])
-        with open(path, "wb") as f:
-            f.write(payload[a:b].tobytes())
-        sizes.append(b - a)
-    return sizes
-
-
-def read_stream_files(paths):
-    """The inverse: per-stream files -> (payload, offsets) ready for decode_batch / decodeBatch."""
-    parts, offsets = [], [0]
-    for path in paths:
-        with open(path, "rb") as f:
-            parts.append(np.frombuffer(f.read(), np.uint8))
-        offsets.append(offsets[-1] + parts[-1].size)
-    payload = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
-    return payload, np.array(offsets, np.uint64)
+# isscabac_write_stream_files / isscabac_read_stream_files of the C ABI (csrc/cabac_container.cpp)
+write_stream_files = _engine.write_stream_files
+read_stream_files = _engine.read_stream_files

@@ -9,10 +9,18 @@ classdef cabacWrapper < handle
 %   encodeStart, encodeBin(bin, ctx), encodeFinish, getNumBits,
 %   decodeStart, bin = decodeBin(ctx), decodeFinish,
 %   [trace, stats] = getEncoderStats(ctx) / getDecoderStats(ctx)
+% Two more kinds of bin, per call (new; the engine of the original has them, its MEX file does not reach them):
+%   encodeBinEP(bin), bin = decodeBinEP()                  equiprobable bins
+%   encodeBinProb(bin, p), bin = decodeBinProb(p)          p = probability of a 1 in percent, 1..99 (not 46..49, 51..54)
 % Batch calls (new; one independent bitstream per matrix column, coded on the GPU in one go; ctx value 255 marks a
 % bypass bin; nbins optionally gives the number of bins actually coded in every column):
 %   [payload, offsets] = encodeBatch(bins, ctx [, nbins])
 %   [bins, status]     = decodeBatch(payload, offsets, ctx [, nbins])
+% Symbol calls (new; columns of integer symbols, binarisation and context selection done by the engine, see
+% coder.cabacSymbolParams for params):
+%   [payload, offsets, nbins] = encodeSymbols(sym, params [, nsym])
+%   [payload, offsets, nbins, ctxHist, ctxCost, symBits] = encodeSymbolsStats(sym, params [, nsym])
+%   [sym, status] = decodeSymbols(payload, offsets, symbolsPerStream, params [, nsym])
 %
 % Every method is a thin call into the MEX gateway SimpleCABACMex (matlab/SimpleCABACMex.cpp), which forwards to the C
 % ABI of include/isscabac.h; no coding logic lives here.
@@ -91,7 +99,29 @@ classdef cabacWrapper < handle
       obj.gateway('decodeFinish');
     end
 
-    % ---- state traces (the gateway answers "Invalid Command" like the reference's Linux build) -------------------
+    function status = decodeFinishStatus(obj)
+      % like decodeFinish, but hands back the decoder's integrity flags (0 = the stream ended where it should)
+      status = SimpleCABACMex('decodeFinish', obj.cabac_handle);
+    end
+
+    % ---- equiprobable and fixed-probability bins ----------------------------------------------------------------
+    function encodeBinEP(obj, binValue)
+      obj.gateway('encodeBinEP', binValue);
+    end
+
+    function bin = decodeBinEP(obj)
+      bin = SimpleCABACMex('decodeBinEP', obj.cabac_handle);
+    end
+
+    function encodeBinProb(obj, binValue, percent)
+      obj.gateway('encodeBinProb', binValue, percent);
+    end
+
+    function bin = decodeBinProb(obj, percent)
+      bin = SimpleCABACMex('decodeBinProb', obj.cabac_handle, percent);
+    end
+
+    % ---- state traces: trace is 5 x N (bin, state before, mps before, state after, mps after), stats 128 x 128 -----
     function [trace, stats] = getEncoderStats(obj, ctxID)
       [trace, stats] = SimpleCABACMex('getEncoderStats', obj.cabac_handle, ctxID);
     end
@@ -115,6 +145,33 @@ classdef cabacWrapper < handle
         args{end + 1} = uint32(nbins);
       end
       [bins, status] = SimpleCABACMex('decodeBatch', obj.cabac_handle, args{:});
+    end
+  end
+
+  methods
+    % ---- symbols: R x S uint8 matrices, column s = stream s -------------------------------------------------------
+    function [payload, offsets, nbins] = encodeSymbols(obj, sym, params, nsym)
+      args = {uint8(sym), double(params)};
+      if nargin >= 4
+        args{end + 1} = uint32(nsym);
+      end
+      [payload, offsets, nbins] = SimpleCABACMex('encodeSymbols', obj.cabac_handle, args{:});
+    end
+
+    function [payload, offsets, nbins, ctxHist, ctxCost, symBits] = encodeSymbolsStats(obj, sym, params, nsym)
+      args = {uint8(sym), double(params)};
+      if nargin >= 4
+        args{end + 1} = uint32(nsym);
+      end
+      [payload, offsets, nbins, ctxHist, ctxCost, symBits] = SimpleCABACMex('encodeSymbolsStats', obj.cabac_handle, args{:});
+    end
+
+    function [sym, status] = decodeSymbols(obj, payload, offsets, symbolsPerStream, params, nsym)
+      args = {uint8(payload), double(offsets), double(symbolsPerStream), double(params)};
+      if nargin >= 6
+        args{end + 1} = uint32(nsym);
+      end
+      [sym, status] = SimpleCABACMex('decodeSymbols', obj.cabac_handle, args{:});
     end
   end
 

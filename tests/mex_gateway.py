@@ -41,6 +41,20 @@ class Gateway:
         L.drv_data.argtypes = [C.c_void_p]
         L.drv_mex.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
         L.drv_printed.restype = C.c_char_p
+        L.drv_locks.restype = C.c_int
+
+    def printed(self, clear=True):
+        out = self.L.drv_printed().decode()
+        if clear:
+            self.L.drv_clear_printed()
+        return out
+
+    def locks(self):
+        return int(self.L.drv_locks())
+
+    def shutdown(self):
+        """what `clear mex` / MATLAB exit does: run the gateway's mexAtExit function"""
+        self.L.drv_shutdown()
 
     def _to_mx(self, a):
         if isinstance(a, str):

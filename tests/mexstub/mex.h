@@ -28,6 +28,14 @@ struct MexError : std::runtime_error {
 int mexPrintf(const char *fmt, ...);
 int mexAtExit(void (*fn)(void));
 inline void mexMakeMemoryPersistent(void *) {}
+void mexWarnMsgTxt(const char *msg);
+void mexLock(void);
+void mexUnlock(void);
+bool mexIsLocked(void);
+// memory MATLAB frees by itself when the MEX function returns or raises (the driver does the same after every call)
+void *mxCalloc(size_t n, size_t size);
+void *mxMalloc(size_t n);
+void mxFree(void *p);
 
 inline size_t mx_elsize(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : c == mxUINT32_CLASS ? 4 : 1; }
 inline bool mxIsClass(const mxArray *a, const char *name) {

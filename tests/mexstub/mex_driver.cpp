@@ -6,8 +6,35 @@
 
 #include "mex.h"
 
+#include <stdlib.h>
+
+#include <set>
+
 static std::string g_printed;
 static void (*g_atexit)(void) = nullptr;
+static int g_locks = 0;
+static std::set<void *> g_auto;  // mxCalloc'ed blocks of the running command
+static size_t g_auto_freed = 0;  // blocks the driver (standing in for MATLAB) had to free after a command
+
+void mexWarnMsgTxt(const char *msg) { g_printed += std::string("Warning: ") + msg + "\n"; }
+void mexLock(void) { g_locks++; }
+void mexUnlock(void) { g_locks--; }
+bool mexIsLocked(void) { return g_locks > 0; }
+void *mxCalloc(size_t n, size_t size) {
+  void *p = calloc(n ? n : 1, size ? size : 1);
+  g_auto.insert(p);
+  return p;
+}
+void *mxMalloc(size_t n) { return mxCalloc(n, 1); }
+void mxFree(void *p) {
+  g_auto.erase(p);
+  free(p);
+}
+static void free_auto() {
+  g_auto_freed += g_auto.size();
+  for (void *p : g_auto) free(p);
+  g_auto.clear();
+}
 
 int mexPrintf(const char *fmt, ...) {
   char buf[1024];
@@ -57,10 +84,14 @@ int drv_mex(int nlhs, void **plhs, int nrhs, void **prhs, char *err, int cap) {
     mexFunction(nlhs, (mxArray **)plhs, nrhs, (const mxArray **)prhs);
   } catch (const MexError &e) {
     snprintf(err, cap, "%s", e.what());
+    free_auto();
     return 1;
   }
+  free_auto();
   return 0;
 }
+int drv_locks() { return g_locks; }
+void drv_clear_printed() { g_printed.clear(); }
 const char *drv_printed() { return g_printed.c_str(); }
 void drv_shutdown() {
   if (g_atexit) g_atexit();

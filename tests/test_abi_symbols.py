@@ -50,14 +50,66 @@ def test_engine_fails_loudly_without_gpu():
 
 
 def test_stream_file_container_round_trip(oracle, tmp_path):
-    """one-file-per-stream <-> packed payload+offsets; the files are what the reference writes"""
-    from isscabac_amd.wrapper import read_stream_files, write_stream_files
+    """one-file-per-stream <-> packed payload+offsets through the C ABI; the files are what the reference
+    writes.  Host-only calls: they run without a GPU."""
+    import isscabac_amd.engine as eng
     bins, ctx = oracle.synth(0xCABAC002, 0, 5, 300, 3)
     payload, offsets = oracle.encode_batch(bins, ctx, np.zeros(3, np.uint8))
-    paths = [str(tmp_path / ("s%d.bin" % i)) for i in range(5)]
-    sizes = write_stream_files(payload, offsets, paths)
-    assert sizes == np.diff(offsets.astype(np.int64)).tolist()
+    paths = [eng.stream_file_path(str(tmp_path / "s"), i) for i in range(5)]
+    assert paths[3].endswith("s000003.bin")
+    eng.write_stream_files(payload, offsets, paths)
+    assert [os.path.getsize(p) for p in paths] == np.diff(offsets.astype(np.int64)).tolist()
     for i, p in enumerate(paths):
         assert open(p, "rb").read() == oracle.encode_stream(bins[i], ctx[i], np.zeros(3, np.uint8)).tobytes()
-    p2, o2 = read_stream_files(paths)
+    p2, o2 = eng.read_stream_files(paths)
     assert p2.tobytes() == payload.tobytes() and (o2 == offsets).all()
+    with pytest.raises(eng.EngineError, match="cannot read"):
+        eng.read_stream_files(paths + [str(tmp_path / "missing.bin")])
+    with pytest.raises(eng.EngineError, match="cannot write"):
+        eng.write_stream_files(payload, offsets, [str(tmp_path / "no_dir" / "x.bin")] * 5)
+    # an empty stream in the middle (zero-length file) survives the round trip
+    o3 = np.array([0, 4, 4, 9], np.uint64)
+    eng.write_stream_files(payload[:9], o3, paths[:3])
+    p4, o4 = eng.read_stream_files(paths[:3])
+    assert p4.tobytes() == payload[:9].tobytes() and (o4 == o3).all()
+
+
+def test_stream_files_interoperate_with_the_reference_decoder(oracle, reference, tmp_path):
+    """files written by isscabac_write_stream_files are decoded by the REAL reference classes (oracle/_ref), and files the
+    reference's encoder wrote come back through isscabac_read_stream_files as the batch the oracle produces"""
+    import isscabac_amd.engine as eng
+    S, B, C = 6, 700, 5
+    bins, ctx = oracle.synth(0xCABAC003, 3, S, B, C)
+    init = np.arange(C, dtype=np.uint8) * 9
+    payload, offsets = oracle.encode_batch(bins, ctx, init)
+    paths = [eng.stream_file_path(str(tmp_path / "w"), i) for i in range(S)]
+    eng.write_stream_files(payload, offsets, paths)
+    for s in range(S):  # the reference reads our files
+        got, status, _ = reference.decode_stream(np.fromfile(paths[s], np.uint8), ctx[s], init)
+        assert status == 0 and (got == bins[s]).all()
+    for s in range(S):  # ... and we read the reference's
+        p_ref, _ = reference.encode_stream(bins[s], ctx[s], init)
+        p_ref.tofile(paths[s])
+    p2, o2 = eng.read_stream_files(paths)
+    assert p2.tobytes() == payload.tobytes() and (o2 == offsets).all()
+
+
+def test_iss_side_info_container_round_trip(tmp_path):
+    import isscabac_amd.engine as eng
+    rng = np.random.default_rng(8)
+    cW, cH, Q = rng.random(8), rng.random(6), rng.normal(size=(2, 3))
+    xw, xh = rng.integers(0, 256, 23).astype(np.uint8), rng.integers(0, 256, 23).astype(np.uint8)
+    w, h = rng.integers(0, 256, 901).astype(np.uint8), rng.integers(0, 256, 77).astype(np.uint8)
+    fn = str(tmp_path / "iss.bin")
+    eng.iss_container_write(fn, cW, cH, Q, xw, xh, w, h)
+    assert os.path.getsize(fn) == 8 + 32 + 16 + 8 * (8 + 6 + 6) + 46 + 901 + 77
+    d = eng.iss_container_read(fn)
+    assert (d["cW"] == cW).all() and (d["cH"] == cH).all() and (d["Q"] == Q).all()
+    assert (d["xw"] == xw).all() and (d["xh"] == xh).all() and (d["w_stream"] == w).all() and (d["h_stream"] == h).all()
+    # equalProb: no context initialisations are transmitted (ISS.m:198-200)
+    eng.iss_container_write(fn, cW, cH, Q, [], [], w, [])
+    d = eng.iss_container_read(fn)
+    assert d["xw"].size == 0 and d["xh"].size == 0 and d["h_stream"].size == 0 and (d["w_stream"] == w).all()
+    open(fn, "wb").write(b"not a container at all, really not" * 3)
+    with pytest.raises(eng.EngineError, match="not an ISS container"):
+        eng.iss_container_read(fn)

@@ -18,8 +18,10 @@ def test_compiles_and_rejects_like_the_reference(gw):
         gw.call(np.array([1.0]))
     with pytest.raises(MexError, match="Invalid Command"):
         gw.call("noSuchCommand")
-    with pytest.raises(MexError, match="Invalid Command"):
-        gw.call("getEncoderStats", np.array([1.0]), 0.0)  # Windows-only in the reference; Linux falls through
+    with pytest.raises(MexError, match="provide two variables to store the trace"):
+        gw.call("getEncoderStats", np.array([1.0]), 0.0)  # ref: SimpleCABACMex.cpp:362-365
+    with pytest.raises(MexError, match="No initialized CABAC instance"):
+        gw.call("getEncoderStats", np.array([12345.0]), 0.0, nlhs=2)  # not a handle this gateway gave out
     with pytest.raises(MexError, match="please provide the filename"):
         gw.call("initByProb")
     with pytest.raises(MexError, match="too many parameters"):
@@ -93,3 +95,212 @@ def test_batch_commands(gw, oracle, tmp_path):
     assert payload.ravel().tobytes() == want_payload.tobytes() and offsets.ravel().tolist() == want_off.tolist()
     with pytest.raises(MexError, match="same size"):
         gw.call("encodeBatch", h, bins.T.copy(), ctx.T[:10].copy(), nlhs=2)
+
+
+@pytest.mark.gpu
+def test_context_index_is_range_checked_before_narrowing(gw, tmp_path):
+    """256 must not become context 0, and -1 / 255 / 511 must not become a bypass bin (round-1 finding)"""
+    (h,) = gw.call("initByProb", str(tmp_path / "r.bin"), np.array([0.5, 0.5, 0.5]), nlhs=1)
+    gw.call("encodeStart", h)
+    for bad in (3.0, 255.0, 256.0, 511.0, -1.0, 0.5, 1e9, float("nan")):
+        with pytest.raises(MexError, match="invalid context index"):
+            gw.call("encodeBin", h, 1.0, bad)
+    gw.call("encodeBin", h, 1.0, 2.0)
+    gw.call("encodeFinish", h)
+    gw.call("decodeStart", h)
+    for bad in (3.0, 255.0, 256.0, -1.0):
+        with pytest.raises(MexError, match="invalid context index"):
+            gw.call("decodeBin", h, bad, nlhs=1)
+    assert gw.call("decodeBin", h, 2.0, nlhs=1)[0][0, 0] == 1
+    (st,) = gw.call("decodeFinish", h, nlhs=1)
+    assert st[0, 0] == 0
+    gw.call("delete", h)
+    with pytest.raises(MexError, match="No initialized CABAC instance"):
+        gw.call("encodeStart", h)  # a deleted handle is refused, not dereferenced
+
+
+@pytest.mark.gpu
+def test_handles_hold_the_mex_file_and_are_closed_at_exit(gw, tmp_path):
+    gw.shutdown()  # whatever earlier tests left open
+    assert gw.locks() == 0
+    hs = [gw.call("initByProb", str(tmp_path / ("l%d.bin" % i)), np.array([0.5]), nlhs=1)[0] for i in range(3)]
+    assert gw.locks() == 1  # locked while handles live: `clear mex` cannot unload the engine under them
+    gw.call("delete", hs[0])
+    assert gw.locks() == 1
+    gw.call("delete", hs[1])
+    gw.call("delete", hs[2])
+    assert gw.locks() == 0
+    (h,) = gw.call("initByProb", str(tmp_path / "l.bin"), np.array([0.5]), nlhs=1)
+    gw.shutdown()  # MATLAB exit: the gateway closes the stream before destroying the engine
+    assert gw.locks() == 0
+    with pytest.raises(MexError, match="No initialized CABAC instance"):
+        gw.call("encodeStart", h)
+    (h,) = gw.call("initByProb", str(tmp_path / "l.bin"), np.array([0.5]), nlhs=1)  # and comes up again
+    gw.call("delete", h)
+
+
+@pytest.mark.gpu
+def test_more_than_255_contexts_per_bin_commands_only(gw, oracle, tmp_path):
+    """the reference holds up to 999 context models per handle (CommonDef.h:56): the per-bin commands reach all of them"""
+    C = 999
+    p0 = (np.arange(C) % 200 + 20) / 255.0
+    fn = str(tmp_path / "big.bin")
+    (h,) = gw.call("initByProb", fn, p0, nlhs=1)
+    rng = np.random.default_rng(3)
+    ctx = np.concatenate([[0, 255, 256, 511, 998], rng.integers(0, C, 300)])
+    bins = rng.integers(0, 2, ctx.size)
+    gw.call("encodeStart", h)
+    for b, c in zip(bins, ctx):
+        gw.call("encodeBin", h, float(b), float(c))
+    gw.call("encodeFinish", h)
+    want, _ = oracle.encode_ops([0] * ctx.size, bins.tolist(), ctx.tolist(), oracle.init_by_prob(p0))
+    assert open(fn, "rb").read() == want.tobytes()
+    with pytest.raises(MexError, match="invalid context index"):
+        gw.call("encodeBin", h, 1.0, 999.0)
+    with pytest.raises(MexError, match="at most 255 contexts"):
+        gw.call("encodeBatch", h, np.zeros((16, 1), np.uint8), np.zeros((16, 1), np.uint8), nlhs=2)
+    with pytest.raises(MexError, match="invalid context initialization"):
+        gw.call("initByProb", fn, np.full(1000, 0.5), nlhs=1)
+    gw.call("delete", h)
+
+
+@pytest.mark.gpu
+def test_stats_ep_and_probability_commands(gw, oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    fn = str(tmp_path / "s.bin")
+    p0 = np.array([0.2, 0.5, 0.8])
+    init = oracle.init_by_prob(p0)
+    (h,) = gw.call("initByProb", fn, p0, nlhs=1)
+    gw.call("encodeStart", h)
+    kind, val, arg, bins, ctx = [], [], [], [], []
+    for _ in range(400):
+        r = rng.integers(0, 4)
+        b = int(rng.integers(0, 2))
+        if r < 2:
+            c = int(rng.integers(0, 3))
+            gw.call("encodeBin", h, float(b), float(c))
+            kind.append(0); arg.append(c); bins.append(b); ctx.append(c)
+        elif r == 2:
+            gw.call("encodeBinEP", h, float(b))
+            kind.append(1); arg.append(0)
+        else:
+            p = int(rng.choice([1, 10, 30, 45, 50, 55, 90, 99]))
+            gw.call("encodeBinProb", h, float(b), float(p))
+            kind.append(3); arg.append(p)
+        val.append(b)
+    gw.call("encodeFinish", h)
+    want, _ = oracle.encode_ops(kind, val, arg, init)
+    assert open(fn, "rb").read() == want.tobytes()
+    for bad in (46.0, 54.0, 0.0, 100.0, 12.5):
+        with pytest.raises(MexError):
+            gw.call("encodeBinProb", h, 1.0, bad)
+    gw.call("decodeStart", h)
+    got = []
+    for k, a in zip(kind, arg):
+        if k == 0:
+            got.append(gw.call("decodeBin", h, float(a), nlhs=1)[0][0, 0])
+        elif k == 1:
+            got.append(gw.call("decodeBinEP", h, nlhs=1)[0][0, 0])
+        else:
+            got.append(gw.call("decodeBinProb", h, float(a), nlhs=1)[0][0, 0])
+    assert got == val
+    gw.call("decodeFinish", h)
+    for c in range(3):
+        for cmdname, side in (("getEncoderStats", False), ("getDecoderStats", True)):
+            trace, stats = gw.call(cmdname, h, float(c), nlhs=2)
+            want_t, want_x = oracle.trace_stats(bins, ctx, init, c, decoder=side)
+            assert trace.shape == (5, want_t.shape[0]) and (trace.T == want_t).all()
+            # the reference fills its 128 x 128 output row-major ([state before][state after], SimpleCABACMex.cpp:393-399):
+            # MATLAB therefore sees the transpose
+            assert stats.shape == (128, 128) and stats.dtype == np.uint32 and (stats.T == want_x).all()
+    with pytest.raises(MexError, match="invalid context index"):
+        gw.call("getEncoderStats", h, 3.0, nlhs=2)
+    # a damaged stream: the reference asserts in decodeFinish (compiled out in a release MEX); here a warning + the flags
+    data = bytearray(open(fn, "rb").read())
+    data[-1] ^= 0xFF
+    open(fn, "wb").write(bytes(data))
+    (h2,) = gw.call("initByProb", fn, p0, nlhs=1)
+    gw.call("decodeStart", h2)
+    gw.printed()
+    (st,) = gw.call("decodeFinish", h2, nlhs=1)
+    assert st[0, 0] != 0 and "not terminated properly" in gw.printed()
+    gw.call("delete", h)
+    gw.call("delete", h2)
+
+
+def _iss_params(nq, rows, method=1, k=0, types=15, nlbp=3):
+    return np.array([method, k, nq, 1, types, nlbp, rows], np.float64)
+
+
+@pytest.mark.gpu
+def test_symbol_commands_run_the_iss_coder_in_one_call_per_matrix(gw, oracle, tmp_path):
+    """the gateway calls matlab/+coder/cabacEncode.m / cabacDecode.m make, against the oracle's walk of the reference's
+    loops (ISS/+coder/cabacEncode.m:45-70, cabacDecode.m:29-55) on ISS.m's two matrix shapes"""
+    rng = np.random.default_rng(6)
+    for rows, cols, nq in ((400, 20, 8), (109, 20, 8), (33, 7, 16)):
+        x = np.abs(rng.normal(size=(rows, cols)))
+        for r in range(1, rows):
+            x[r] = 0.7 * x[r - 1] + 0.3 * x[r]
+        G = np.minimum((x / np.quantile(x, 0.99) * nq).astype(np.int64), nq - 1).astype(np.uint8)
+        # 1. empirical context initialisation + its uint8 form (cabacEncode.m:23-31)
+        p0, p0b = gw.call("issInitContextModel", G, _iss_params(nq, 0), nlhs=2)
+        want_p0, want_b = oracle.iss_init_context_model(G, nq, "EG", 0, 15, 3)
+        assert p0.shape == (1, 23) and np.array_equal(p0.ravel(), want_p0)
+        assert p0b.dtype == np.uint8 and (p0b.ravel() == want_b).all()
+        # 2. the whole matrix as one stream (what +coder/cabacEncode.m hands over: G(:) and colRows = rows)
+        ctx_init = p0b.ravel().astype(np.float64) / 255.0
+        fn = str(tmp_path / "iss.bin")
+        (h,) = gw.call("initByProb", fn, ctx_init, nlhs=1)
+        params = _iss_params(nq, rows)
+        one = G.T.reshape(-1, 1).copy()  # MATLAB's G(:)
+        payload, offsets, nbins, hist, cost, hbits = gw.call("encodeSymbolsStats", h, one, params, nlhs=6)
+        states = oracle.init_by_prob(ctx_init)
+        want, want_hist, want_cost, want_H = oracle.iss_encode_matrix_stats(G, nq, "EG", 0, 15, 3, states)
+        assert payload.ravel().tobytes() == want.tobytes() and offsets.ravel().tolist() == [0, want.size]
+        assert int(nbins[0, 0]) == int(want_hist.sum())
+        assert (hist[:23, 0] == want_hist[:23]).all() and (cost[:23, 0] == want_cost[:23]).all()
+        assert (hbits.ravel().reshape(cols, rows).T == want_H).all()
+        (p2, o2, nb2) = gw.call("encodeSymbols", h, one, params, nlhs=3)
+        assert p2.ravel().tobytes() == want.tobytes() and nb2[0, 0] == nbins[0, 0]
+        # 3. decode: one call per matrix
+        sym, status = gw.call("decodeSymbols", h, payload, offsets, float(rows * cols), params, nlhs=2)
+        assert status[0, 0] == 0 and (sym.ravel().reshape(cols, rows).T == G).all()
+        gw.call("delete", h)
+    with pytest.raises(MexError, match="params must be"):
+        gw.call("issInitContextModel", G, np.array([1.0, 0.0]), nlhs=2)
+
+
+@pytest.mark.gpu
+def test_stream_file_commands_and_multi_device_batches(gw, oracle, reference, tmp_path):
+    S, B, C = 40, 304, 9
+    bins, ctx = oracle.synth(0xCABAC005, 11, S, B, C, True)
+    p0 = (np.arange(C) + 1) / (C + 1.0)
+    init = oracle.init_by_prob(p0)
+    (h,) = gw.call("initByProb", str(tmp_path / "b.bin"), p0, nlhs=1)
+    payload, offsets = gw.call("encodeBatch", h, bins.T.copy(), ctx.T.copy(), nlhs=2)
+    want_p, want_o = oracle.encode_batch(bins, ctx, init)
+    assert payload.ravel().tobytes() == want_p.tobytes()
+    # one file per stream, decodable by the REAL reference classes (oracle/_ref)
+    prefix = str(tmp_path / "str_")
+    gw.call("writeStreamFiles", payload, offsets, prefix)
+    for s in (0, 7, S - 1):
+        data = np.fromfile(prefix + "%06d.bin" % s, np.uint8)
+        got, st, _ = reference.decode_stream(data, ctx[s], init)
+        assert st == 0 and (got == bins[s]).all()
+    # ... and files the reference's encoder wrote come back as the same batch
+    for s in range(S):
+        reference.encode_stream(bins[s], ctx[s], init)[0].tofile(prefix + "%06d.bin" % s)
+    p2, o2 = gw.call("readStreamFiles", prefix, float(S), nlhs=2)
+    assert p2.ravel().tobytes() == want_p.tobytes() and o2.ravel().tolist() == want_o.tolist()
+    with pytest.raises(MexError, match="bitstreamfile access error"):
+        gw.call("readStreamFiles", str(tmp_path / "nothing_"), 3.0, nlhs=2)
+    # two engines behind the gateway (the box has one GPU: both on device 0 -- the sharding and gather code is the same)
+    gw.call("setDevices", np.array([0.0, 0.0]))
+    p3, o3 = gw.call("encodeBatch", h, bins.T.copy(), ctx.T.copy(), nlhs=2)
+    assert p3.ravel().tobytes() == want_p.tobytes() and o3.ravel().tolist() == want_o.tolist()
+    dec, status = gw.call("decodeBatch", h, p3, o3, ctx.T.copy(), nlhs=2)
+    assert (dec.T == bins).all() and (status == 0).all()
+    gw.call("setDevices", np.zeros((0, 0)))
+    p4, _ = gw.call("encodeBatch", h, bins.T.copy(), ctx.T.copy(), nlhs=2)
+    assert p4.ravel().tobytes() == want_p.tobytes()
+    gw.call("delete", h)
