@@ -80,9 +80,9 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 // waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
 // let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
 constexpr int waves_per_block(int cm) { return cm == 1 ? 4 : 1; }
-constexpr int kTabBytes = 1280;  // [0,256) rangeTabLps rows, [256,512) next-state entries, [512,768) 16-bit next-state
-                                 // entries, [768,1024) successor bytes by (packed state, bin), [1024,1280) by (.., path)
-constexpr int kTab16Off = 512, kTabBinOff = 768, kTabPathOff = 1024;
+constexpr int kTabBytes = 768;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
+                                // encoder's --, [512,768) by (packed state, path) -- the decoder's
+constexpr int kTabBinOff = 256, kTabPathOff = 512;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -203,13 +203,9 @@ __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1
 // context-state policies (see cabac_lane.h: States)
 // ------------------------------------------------------------------------------------------------
 // One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
-// pick, lane l only ever touches bank l % 32.  TABLES: true = ds_bpermute from a VGPR that holds entry `lane`
-// (legal only while all 64 lanes are active), false = LDS copy of the tables (any exec mask).
-template <bool XBAR, bool NEXT16 = false>
+// pick, lane l only ever touches bank l % 32.  The tables are byte tables in LDS, read by absolute LDS address.
 struct LdsStates {
-  uint8_t *base;        // wave's state region + lane * 4
-  const uint32_t *tab;  // LDS: [0..63] rangeTabLps rows, [64..127] next-state entries, then the 16-bit entries
-  uint32_t row_tab, next_tab;
+  uint8_t *base;  // wave's state region + lane * 4
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
   __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
@@ -228,20 +224,9 @@ struct LdsStates {
   __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
-  // q = (state << 2) | (mps << 1): ds_bpermute reads lane (addr >> 2) & 63 = state, the low address bits are ignored
-  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const {
-    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)row_tab) : tab[q >> 2];
-  }
-  // NEXT16 (encode kernel): the 16-bit table entry of packed state q >> 1 lives at byte q of its table -- an LDS read
-  // with no address arithmetic, conflict-free (the 256-byte table covers each bank once), and one VALU less per bin
-  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const {
-    // (LDS address as an integer: the kernels' dynamic LDS starts at 0 -- they have no static __shared__, which the
-    // engine checks at start-up -- so the table offset folds into the instruction and q itself is the address)
-    if (NEXT16) return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(kTab16Off + q));
-    return XBAR ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)q, (int)next_tab) : tab[64 + (q >> 2)];
-  }
-  // byte-table lookups by absolute LDS address (see next_entry): the rangeTabLps rows at LDS 0 are a [state][column]
-  // byte table, and the 16-bit next-state table is a [packed state][lps] byte table
+  // (LDS addresses as integers: the kernels' dynamic LDS starts at 0 -- they have no static __shared__, which the engine
+  // checks at start-up -- so a table's offset folds into the instruction and q itself is the address)
+  // the rangeTabLps rows at LDS 0 are a [state][column] byte table
   __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
   }
@@ -252,9 +237,6 @@ struct LdsStates {
   }
   __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
-  }
-  __device__ __forceinline__ uint32_t next_q(uint32_t q, uint32_t lps_mask, uint32_t entry) const {
-    return NEXT16 ? next_state_q16(lps_mask, entry) : next_state_q(q, lps_mask, entry);
   }
   // lookups of the latency-oriented steps (cabac_lane.h: enc_bin_lat_acc / dec_bin_lat): everything by q alone
   __device__ __forceinline__ uint32_t lps_row_mem(uint32_t q) const {  // the state's 4-byte rangeTabLps row
@@ -282,11 +264,7 @@ struct SlotSink {
     pos++;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-#ifndef ISSCABAC_ABL_NO_SLOT_STORE
       if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
-#else
-      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#endif
     }
   }
   // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
@@ -295,11 +273,7 @@ struct SlotSink {
     pos += 2;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-#ifndef ISSCABAC_ABL_NO_SLOT_STORE
       if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
-#else
-      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#endif
     }
   }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
@@ -337,9 +311,6 @@ struct WaveLds {
 #define ISSCABAC_FLUSH_FN enc_flush16_wave  // or enc_flush16: the general loop only
 #endif
 
-template <bool XBAR>
-using StatesFor = LdsStates<XBAR>;
-using EncStatesFor = LdsStates<true, true>;
 
 // LAT: the latency-oriented instance for launches that leave fewer than four waves on a SIMD (see enc_bin_lat_acc):
 // the same bytes, three more VALU instructions per bin, one LDS round trip per bin instead of three behind each other
@@ -351,9 +322,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
-    tab[64 + tid] = c_next.e[tid];
-    tab[128 + tid] = c_next.e16[tid];
-    tab[192 + tid] = c_next.eb[tid];
+    tab[kTabBinOff / 4 + tid] = c_next.eb[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
@@ -380,7 +349,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     constexpr uint32_t ngrp = WL::SB / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  EncStatesFor stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
+  LdsStates stx{wbase + lane * 4};
 
   EncCore e;
   enc_start(e);
@@ -444,13 +413,12 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             }
           }
         } else if (full && !hi) {
-          // every lane codes 16 context bins: convergent, tables through the crossbar
+          // every lane codes 16 context bins: convergent
           EncWordAcc acc;
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-#if !defined(ISSCABAC_ENC_XBAR) && !defined(ISSCABAC_ENC_LOW_PER_BIN)
             // `low` takes the word's four additions at once (EncWordAcc): one 64-bit shift + add per word, not per bin
             if ((k & 3) == 0) enc_bin_at_mem_acc(e, acc, true, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
             else if ((k & 3) == 1) enc_bin_at_mem_acc(e, acc, false, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
@@ -459,25 +427,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
               enc_bin_at_mem_acc(e, acc, false, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
               enc_word_close(e, acc);
             }
-#elif !defined(ISSCABAC_ENC_XBAR)
-            if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-            else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-            else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-            else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-#else  // tables through ds_bpermute instead: 2 more VALU per bin, measured 1.8% slower
-            if ((k & 3) == 0) enc_bin_at(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-            else if ((k & 3) == 1) enc_bin_at(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-            else if ((k & 3) == 2) enc_bin_at(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-            else enc_bin_at(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
-#endif
-#ifndef ISSCABAC_ABL_NO_FLUSH
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)
             if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
-#else
-            if ((k & 3) == 3) { e.W &= 15; }
-#endif
           }
         } else {
           // bypass bins (or contexts >= 128) somewhere in the wave, or streams that end inside this chunk.  The byte-table
@@ -536,9 +489,6 @@ struct DevMem {
     return r;
   }
   __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
-#ifdef ISSCABAC_ABL_HOT_PAYLOAD
-    off &= 60u;  // timing only: every fetch hits the same hot line
-#endif
     const uint64_t at = abase + off;
     if ((int32_t)off <= lim) {  // off is far below 2^31 (a stream's payload is bounded by 6/8 of its <= 2^25 bins)
       const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
@@ -564,19 +514,10 @@ struct DecArgs {
   uint32_t ctx_init[64];
 };
 
-// experiment knobs (tools/ab_bench.py builds variants with -D...).  ISSCABAC_ABL_* builds are TIMING-ONLY: they drop
-// one piece of work to price it, their results are wrong.
 #ifndef ISSCABAC_DEC_OCC
 #define ISSCABAC_DEC_OCC 4  // waves per SIMD the decode kernel is register-limited to (4 measured 6% faster than 3)
 #endif
-#ifdef ISSCABAC_DEC_NO_NT
-constexpr bool kDecNT = false;
-#else
 constexpr bool kDecNT = true;  // decode kernel: ctx loads and bin stores are streaming
-#endif
-#ifndef ISSCABAC_DEC_ROLLED
-#define ISSCABAC_DEC_ROLLED 0  // 1: loop over the chunk's four words, 0: all 16 bins unrolled (1% faster, 113 VGPRs)
-#endif
 
 template <int CM, bool LAT>
 __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
@@ -586,9 +527,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
-    tab[64 + tid] = c_next.e[tid];
-    tab[128 + tid] = c_next.e16[tid];
-    tab[256 + tid] = c_next.ep[tid];
+    tab[kTabPathOff / 4 + tid] = c_next.ep[tid];
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
@@ -614,10 +553,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     constexpr uint32_t ngrp = WL::SB / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
-  StatesFor<true> stx{wbase + lane * 4, tab, c_lps_rows[lane], c_next.e[lane]};
-#ifdef ISSCABAC_DEC_XBAR
-  StatesFor<false> stm{wbase + lane * 4, tab, 0, 0};  // LDS copy of the dword tables for the ragged loop
-#endif
+  LdsStates stx{wbase + lane * 4};
 
   // payload window
   uint64_t start = a.offsets[s];
@@ -657,12 +593,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       v.w = collected_bytes(bits, 3);
       const uint32_t boff = off + c * 16;
       const uint32_t voff = row * a.pitch + boff;  // 32-bit: see Tile::load
-#ifndef ISSCABAC_ABL_NO_STORE
       if (row < nrows && boff < a.pitch) {
         if (kDecNT) nt_store16(out_w + voff, v);
         else *reinterpret_cast<uint4 *>(out_w + voff) = v;
       }
-#endif
     }
   };
 
@@ -682,11 +616,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output tile
         uint32_t ob = 0;
         const bool live = i0 < nmax;  // past the longest stream of the wave: zeros
-#ifndef ISSCABAC_ABL_NO_PAYLOAD
         if (live) src.boundary();
-#else
-        src.cend = src.bpos + 64u;
-#endif
         if (j == 0) {
           // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
           // anything issued just before the boundary's wait for the payload piece would be waited for as well
@@ -702,7 +632,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
           const bool full = i0 + 16 <= nmin;
           const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
-#ifndef ISSCABAC_DEC_XBAR
           {
             // One bit-granular top-up per four bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs
             // sh >= 7, a bypass bin takes 1 and needs sh >= 8, so three bins never run short and only the fourth is
@@ -720,26 +649,12 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               at = stx.addr32_of(zl, 0);
               qld = stx.load_at(at);
             }
-#if ISSCABAC_DEC_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
             for (int g = 0; g < 4; g++) {
-#ifndef ISSCABAC_ABL_NO_PAYLOAD
               // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check
               // then covers words 2 and 3
               if (g == 2) src.ensure(47);
-#else
-              src.cend = src.bpos + 64u;
-#endif
-#if ISSCABAC_DEC_ROLLED
-              // the word comes from LDS again rather than out of wc: picking one of four registers by the loop counter
-              // costs the rolled loop a chain of scalar branches (1% of the kernel)
-              const uint32_t cw = *reinterpret_cast<const uint32_t *>(tile_c + Tile::lds_off(lane, j) + 4 * g);
-#else
               const uint32_t cw = word_of(wc, g);
-#endif
               dec_topup_nocheck(d, src);
               const CtxQuad z = stx.prep4(cw);
               if (LAT && plain) {
@@ -781,41 +696,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             }
             ob = pairs_to_bins(ob);
           }
-#else  // tables through ds_bpermute (3 more VALU per bin), one combined step for chunks with bypass bins, and a per-bin
-       // guarded loop with LDS tables for ragged ends (bpermute cannot read inactive lanes)
-          if (full) {
-            for (int g = 0; g < 4; g++) {
-              if (g == 2) src.ensure(47);
-              const uint32_t cw = word_of(wc, g);
-              dec_topup_nocheck(d, src);
-              const CtxQuad z = stx.prep4(cw);
-              if (!hi) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  if (k == 3) dec_guard(d, src, 7);
-                  ob = collect_bin(ob, dec_bin_at_b1(d, stx.addr_of(z, k), stx));
-                }
-              } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  if (k == 3) dec_guard(d, src, 8);
-                  ob = collect_bin(ob, dec_bin_any_b1(d, (cw >> (8 * k)) & 0xFFu, stx));
-                }
-              }
-            }
-          } else {
-#pragma unroll 1
-            for (int k = 0; k < 16; k++) {
-              uint32_t w = 0;
-              if (i0 + k < n) {
-                if (d.sh < 8) dec_refill(d, src);
-                const uint32_t cx = (word_of(wc, k >> 2) >> (8 * (k & 3))) & 0xFFu;
-                w = dec_bin_any_b1(d, cx, stm);
-              }
-              ob = collect_bin(ob, w);
-            }
-          }
-#endif
         }
         obits[cidx * 64 + lane] = ob;
       }

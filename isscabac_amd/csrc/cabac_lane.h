@@ -97,7 +97,7 @@ CABAC_HD uint32_t packed_from_q(uint32_t q) { return q >> 1; }
 
 // rangeTabLps[state][(range >> 6) & 3] out of the state's table row (range is 256..510)
 CABAC_HD uint32_t lps_of(uint32_t row, uint32_t range) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ISSCABAC_NO_ALIGNBYTE)
+#if defined(__HIP_DEVICE_COMPILE__)
   // v_alignbyte_b32 shifts {row, row} right by (range >> 6) bytes; whether the hardware takes 2 or more bits of the
   // byte count (range >> 6 is 4..7), the low byte of the result is byte (range >> 6) & 3 of row
   return __builtin_amdgcn_alignbyte(row, row, range >> 6) & 0xFFu;
