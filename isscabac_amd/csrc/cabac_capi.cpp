@@ -5,11 +5,14 @@
 // call fails with ISSCABAC_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/isscabac.h"
 #include "cabac_internal.h"
@@ -84,6 +87,14 @@ void isscabac_destroy(isscabac_engine *e) {
       for (hipEvent_t ev : e->prof[i].ev) (void)hipEventDestroy(ev);
     delete[] e->prof;
   }
+  for (int i = 0; i < isscabac_engine::kPinSlots; i++) {
+    if (e->pin[i]) (void)hipHostFree(e->pin[i]);
+    if (e->pin_ev[i]) (void)hipEventDestroy(e->pin_ev[i]);
+  }
+  for (hipEvent_t ev : e->pipe_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
+  if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
   if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -321,6 +332,113 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
 }
 
 // ---- batch coding, host buffers -----------------------------------------------------------------------
+// What a MEX / FFI caller holding host arrays pays for is PCIe, not coding (4 B/bin cross the link against ~4 ms of
+// kernels per GiB), so these entry points are built around the copies:
+//   * caller memory is pageable: a hipMemcpy from it is staged by the runtime through one thread.  Here the bytes go through
+//     the engine's own pinned ring (kPinSlots x 16 MiB): a few host threads copy a block into a pinned slot while the DMA
+//     engine drains the previous slots, H2D and D2H on streams of their own, so that both directions and the kernels overlap;
+//   * the batch is cut into groups of streams: group g is decoded while group g + 1's contexts are still arriving and
+//     group g - 1's bins are already leaving;
+//   * every device buffer is grow-only scratch of the engine: no allocation after the first call of a size.
+namespace {
+
+// copy n bytes with a few threads (one memcpy stream tops out near 10 GB/s; the PCIe link takes 50+)
+void parallel_copy(void *dst, const void *src, size_t n) {
+  const size_t kMin = 1u << 20;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, hw), n / kMin + 1);
+  if (nt <= 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t per = (n / nt + 63) & ~(size_t)63;
+  for (unsigned t = 1; t < nt; t++) {
+    const size_t off = (size_t)t * per;
+    if (off >= n) break;
+    th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, std::min(per, n - off)); });
+  }
+  memcpy(dst, src, std::min(per, n));
+  for (auto &t : th) t.join();
+}
+
+int pipe_init(isscabac_engine *e) {
+  if (e->h2d_stream) return ISSCABAC_OK;
+  HIP_TRY(e, hipStreamCreateWithFlags(&e->h2d_stream, hipStreamNonBlocking));
+  HIP_TRY(e, hipStreamCreateWithFlags(&e->d2h_stream, hipStreamNonBlocking));
+  for (hipEvent_t &ev : e->pipe_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  for (int i = 0; i < isscabac_engine::kPinSlots; i++) {
+    HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->pin[i]), isscabac_engine::kPinBytes, hipHostMallocDefault));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->pin_ev[i], hipEventDisableTiming));
+  }
+  return ISSCABAC_OK;
+}
+
+// The pinned ring, used by one direction at a time per call site.  H2D: the host fills a slot, the copy is enqueued, the
+// slot's event marks it free again.  D2H: the copy into a slot is enqueued, and when its event has fired the host moves
+// the block to the caller's memory.  Slots [first, first + count) of the engine's ring.
+struct HostPipe {
+  isscabac_engine *e;
+  int first, count, next = 0;
+  // pending D2H blocks (slot -> where its bytes go)
+  struct Out {
+    void *dst;
+    size_t n;
+    bool live;
+  } out[isscabac_engine::kPinSlots] = {};
+
+  int upload(void *d_dst, const void *h_src, uint64_t bytes) {
+    const uint64_t B = isscabac_engine::kPinBytes;
+    for (uint64_t off = 0; off < bytes; off += B) {
+      const uint64_t n = std::min(B, bytes - off);
+      const int slot = first + next;
+      next = (next + 1) % count;
+      HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));  // the DMA that last read this slot is done
+      parallel_copy(e->pin[slot], (const char *)h_src + off, n);
+      HIP_TRY(e, hipMemcpyAsync((char *)d_dst + off, e->pin[slot], n, hipMemcpyHostToDevice, e->h2d_stream));
+      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->h2d_stream));
+    }
+    return ISSCABAC_OK;
+  }
+  int drain_slot(int slot) {
+    if (!out[slot].live) return ISSCABAC_OK;
+    HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));
+    parallel_copy(out[slot].dst, e->pin[slot], out[slot].n);
+    out[slot].live = false;
+    return ISSCABAC_OK;
+  }
+  // enqueue d_src -> h_dst on the D2H stream (which the caller has made wait for the producing kernel)
+  int download(void *h_dst, const void *d_src, uint64_t bytes) {
+    const uint64_t B = isscabac_engine::kPinBytes;
+    for (uint64_t off = 0; off < bytes; off += B) {
+      const uint64_t n = std::min(B, bytes - off);
+      const int slot = first + next;
+      next = (next + 1) % count;
+      const int rc = drain_slot(slot);
+      if (rc) return rc;
+      HIP_TRY(e, hipMemcpyAsync(e->pin[slot], (const char *)d_src + off, n, hipMemcpyDeviceToHost, e->d2h_stream));
+      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->d2h_stream));
+      out[slot] = Out{(char *)h_dst + off, (size_t)n, true};
+    }
+    return ISSCABAC_OK;
+  }
+  int drain() {
+    for (int k = 0; k < count; k++) {  // oldest first
+      const int rc = drain_slot(first + (next + k) % count);
+      if (rc) return rc;
+    }
+    return ISSCABAC_OK;
+  }
+};
+
+// streams per group: about 64 MiB of bins (and as much ctx) per group, at least 4 groups for a big batch
+uint64_t group_streams(uint64_t S, uint32_t pitch) {
+  const uint64_t by_bytes = std::max<uint64_t>(1, (64ull << 20) / pitch);
+  return std::max<uint64_t>(64, std::min(by_bytes, (S + 3) / 4)) / 64 * 64 + (S < 64 ? S : 0);
+}
+
+}  // namespace
+
 int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
                           uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
                           uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
@@ -329,32 +447,53 @@ int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t
   if (rc) return rc;
   if (!bins || !ctx || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch: null buffer");
   HIP_TRY(e, hipSetDevice(e->device));
+  if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch;
   // worst-case payload on device so that the gather can never overflow; copy back only what is used
-  const uint64_t dev_cap = S * isscabac_stream_bound(nbins);
+  const uint64_t dev_cap = S * isscabac_stream_bound(nbins), stride = slot_stride_for(nbins);
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;
   if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], in_bytes))) return rc;
   if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
   if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
-  HIP_TRY(e, hipMemcpyAsync(e->stage[0], bins, in_bytes, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx, in_bytes, hipMemcpyHostToDevice, e->stream));
-  if (nbins_per_stream)
-    HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-  uint64_t total = 0;
-  rc = isscabac_encode_batch_dev(e, static_cast<uint8_t *>(e->stage[0]), static_cast<uint8_t *>(e->stage[1]),
-                                 nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nbins, pitch, ctx_init,
-                                 nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap, static_cast<uint64_t *>(e->stage[4]),
-                                 &total);
-  if (rc) return rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
+  uint8_t *d_bins = static_cast<uint8_t *>(e->stage[0]), *d_ctx = static_cast<uint8_t *>(e->stage[1]);
+  uint32_t *d_nb = nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr;
+  uint8_t *d_payload = static_cast<uint8_t *>(e->stage[3]);
+  uint64_t *d_offsets = static_cast<uint64_t *>(e->stage[4]);
+  // everything enqueued earlier on the engine's stream may still read the staging buffers
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HostPipe up{e, 0, isscabac_engine::kPinSlots};
+  if (d_nb && (rc = up.upload(d_nb, nbins_per_stream, S * sizeof(uint32_t)))) return rc;
+  // groups of streams: group g is coded while group g + 1 is still crossing the link
+  const uint64_t G = group_streams(S, pitch);
+  for (uint64_t s0 = 0; s0 < S; s0 += G) {
+    const uint64_t n = std::min(G, S - s0);
+    if ((rc = up.upload(d_bins + s0 * pitch, bins + s0 * pitch, n * pitch))) return rc;
+    if ((rc = up.upload(d_ctx + s0 * pitch, ctx + s0 * pitch, n * pitch))) return rc;
+    HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
+    BatchShape g = sh;
+    g.S = n;
+    HIP_TRY(e, launch_encode(g, d_bins + s0 * pitch, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, e->slots + s0 * stride, stride,
+                             e->lens + s0, e->stream));
+  }
+  HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
+  HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, dev_cap, e->stream));
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const uint64_t total = *e->h_total;
   if (total_bytes) *total_bytes = total;
   if (total > payload_cap)
     return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch: payload needs %llu bytes, capacity is %llu",
                 (unsigned long long)total, (unsigned long long)payload_cap);
-  HIP_TRY(e, hipMemcpyAsync(payload, e->stage[3], total, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(offsets, e->stage[4], (S + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  return ISSCABAC_OK;
+  HostPipe down{e, 0, isscabac_engine::kPinSlots};  // (the uploads are done: the whole ring is free)
+  if ((rc = down.download(payload, d_payload, total))) return rc;
+  if ((rc = down.download(offsets, d_offsets, (S + 1) * sizeof(uint64_t)))) return rc;
+  return down.drain();
 }
 
 int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
@@ -368,6 +507,7 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
       return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch: offsets not monotone at stream %llu", (unsigned long long)s);
   HIP_TRY(e, hipSetDevice(e->device));
+  if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch, total = offsets[S];
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;  // decoded bins
   if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], in_bytes))) return rc;  // ctx
@@ -375,18 +515,40 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
   if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
   if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
-  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx, in_bytes, hipMemcpyHostToDevice, e->stream));
-  if (nbins_per_stream)
-    HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->stage[3], payload, total, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->stage[4], offsets, (S + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-  rc = isscabac_decode_batch_dev(e, static_cast<uint8_t *>(e->stage[3]), total, static_cast<uint64_t *>(e->stage[4]),
-                                 static_cast<uint8_t *>(e->stage[1]),
-                                 nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nbins, pitch, ctx_init,
-                                 nctx, static_cast<uint8_t *>(e->stage[0]), static_cast<uint32_t *>(e->stage[5]));
-  if (rc) return rc;
-  HIP_TRY(e, hipMemcpyAsync(bins_out, e->stage[0], in_bytes, hipMemcpyDeviceToHost, e->stream));
-  if (status) HIP_TRY(e, hipMemcpyAsync(status, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+  uint8_t *d_out = static_cast<uint8_t *>(e->stage[0]), *d_ctx = static_cast<uint8_t *>(e->stage[1]);
+  uint32_t *d_nb = nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr;
+  uint8_t *d_payload = static_cast<uint8_t *>(e->stage[3]);
+  uint64_t *d_offsets = static_cast<uint64_t *>(e->stage[4]);
+  uint32_t *d_status = static_cast<uint32_t *>(e->stage[5]);
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // half of the ring feeds the device, the other half brings the bins back: both directions run at once
+  const int half = isscabac_engine::kPinSlots / 2;
+  HostPipe up{e, 0, half}, down{e, half, isscabac_engine::kPinSlots - half};
+  if ((rc = up.upload(d_payload, payload, total))) return rc;
+  if ((rc = up.upload(d_offsets, offsets, (S + 1) * sizeof(uint64_t)))) return rc;
+  if (d_nb && (rc = up.upload(d_nb, nbins_per_stream, S * sizeof(uint32_t)))) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+  const uint64_t G = group_streams(S, pitch);
+  for (uint64_t s0 = 0; s0 < S; s0 += G) {
+    const uint64_t n = std::min(G, S - s0);
+    if ((rc = up.upload(d_ctx + s0 * pitch, ctx + s0 * pitch, n * pitch))) return rc;
+    HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
+    BatchShape g = sh;
+    g.S = n;
+    // (offsets are positions in the whole payload: the group's kernels get the array from its first stream on)
+    HIP_TRY(e, launch_decode(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, d_out + s0 * pitch,
+                             d_status + s0, e->flag, e->stream));
+    // streams that start with 0xFF (corrupt input): redone in the reference's own formulation, see isscabac_decode_batch_dev
+    HIP_TRY(e, launch_decode_exact(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr,
+                                   d_out + s0 * pitch, d_status + s0, e->flag, e->stream));
+    HIP_TRY(e, hipEventRecord(e->pipe_ev[1], e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->d2h_stream, e->pipe_ev[1], 0));
+    if ((rc = down.download(bins_out + s0 * pitch, d_out + s0 * pitch, n * pitch))) return rc;
+  }
+  if (status && (rc = down.download(status, d_status, S * sizeof(uint32_t)))) return rc;
+  if ((rc = down.drain())) return rc;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
 }

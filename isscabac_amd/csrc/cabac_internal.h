@@ -29,6 +29,14 @@ struct isscabac_engine {
   // staging for the host-buffer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // pinned staging ring of the host-buffer entry points (see HostPipe in cabac_capi.cpp): kPinSlots blocks of kPinBytes,
+  // one event each, and two copy streams (H2D and D2H run full duplex beside the compute stream)
+  static constexpr int kPinSlots = 6;
+  static constexpr uint64_t kPinBytes = 16ull << 20;
+  uint8_t *pin[kPinSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pin_ev[kPinSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // hand-over points between the copy streams and the compute stream
   // what isscabac_sync has to report about the most recent (async) encode
   uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]
   uint64_t pending_cap = 0;

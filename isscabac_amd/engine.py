@@ -345,8 +345,10 @@ class Engine:
         out[:, :a.shape[1]] = a
         return out
 
-    def encode(self, bins, ctx, ctx_init, nbins=None):
-        """bins, ctx: [S, B] uint8 (stream-major).  Returns (payload uint8[total], offsets uint64[S+1])."""
+    def encode(self, bins, ctx, ctx_init, nbins=None, out=None):
+        """bins, ctx: [S, B] uint8 (stream-major).  Returns (payload uint8[total], offsets uint64[S+1]).
+        out: optional (payload buffer uint8[>= S * stream_bound(B)], offsets buffer uint64[S + 1]) to reuse between calls
+        -- the results are then views into them (fresh arrays cost a page fault per 4 KiB they receive)."""
         bins = _np(bins, np.uint8)
         ctx = _np(ctx, np.uint8)
         assert bins.ndim == 2 and bins.shape == ctx.shape
@@ -355,17 +357,25 @@ class Engine:
         bins, ctx = self._pad_rows(bins, pitch), self._pad_rows(ctx, pitch)
         ci = _np(ctx_init, np.uint8)
         nb = None if nbins is None else _np(nbins, np.uint32)
-        cap = S * stream_bound(B)
-        payload = np.empty(cap, np.uint8)
-        offsets = np.zeros(S + 1, np.uint64)
+        if out is not None:
+            payload, offsets = out
+            assert payload.dtype == np.uint8 and offsets.dtype == np.uint64 and offsets.size >= S + 1
+            cap = payload.size
+        else:
+            cap = S * stream_bound(B)
+            payload = np.empty(cap, np.uint8)
+            offsets = np.zeros(S + 1, np.uint64)
         total = C.c_uint64(0)
         self._check(self._L.isscabac_encode_batch(self._h, _ptr(bins, _u8p), _ptr(ctx, _u8p), _ptr(nb, _u32p), S, B,
                                                   pitch, _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
                                                   _ptr(offsets, _u64p), C.byref(total)))
+        if out is not None:
+            return payload[:int(total.value)], offsets[:S + 1]
         return payload[:int(total.value)].copy(), offsets
 
-    def decode(self, payload, offsets, ctx, ctx_init, nbins=None):
-        """Returns (bins uint8[S, B], status uint32[S])."""
+    def decode(self, payload, offsets, ctx, ctx_init, nbins=None, out=None):
+        """Returns (bins uint8[S, B], status uint32[S]).  out: optional (bins buffer uint8[S, pitch], status buffer
+        uint32[S]) to reuse between calls (pitch = B rounded up to 16)."""
         payload = _np(payload, np.uint8)
         offsets = _np(offsets, np.uint64)
         ctx = _np(ctx, np.uint8)
@@ -374,8 +384,12 @@ class Engine:
         ctxp = self._pad_rows(ctx, pitch)
         ci = _np(ctx_init, np.uint8)
         nb = None if nbins is None else _np(nbins, np.uint32)
-        bins = np.empty((S, pitch), np.uint8)
-        status = np.zeros(S, np.uint32)
+        if out is not None:
+            bins, status = out
+            assert bins.shape == (S, pitch) and bins.dtype == np.uint8 and bins.flags["C_CONTIGUOUS"] and status.size >= S
+        else:
+            bins = np.empty((S, pitch), np.uint8)
+            status = np.zeros(S, np.uint32)
         self._check(self._L.isscabac_decode_batch(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ctxp, _u8p),
                                                   _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
                                                   _ptr(bins, _u8p), _ptr(status, _u32p)))

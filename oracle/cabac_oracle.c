@@ -149,7 +149,7 @@ void orc_enc_start(orc_encoder *e, uint8_t *buf, size_t cap) {
   orc_sink_init(&e->sink, buf, cap);
 }
 
-static orc_counters g_cnt;
+static _Thread_local orc_counters g_cnt; /* per thread: the all-core baseline must not share a cache line */
 void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof g_cnt); }
 const orc_counters *orc_counters_get(void) { return &g_cnt; }
 
@@ -1038,4 +1038,66 @@ uint64_t orc_trace_stats(const uint8_t *bins, const uint8_t *ctx, uint64_t nbins
     steps++;
   }
   return steps;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * All-core CPU ceiling for bench.py's cpu_baseline: the restatement above with its in-memory sink on
+ * native threads, streams split evenly, no files and nothing interpreted between streams.  Every thread generates its
+ * streams with the counter-based generator, encodes, decodes and compares.  *wall_s = time from the first thread's
+ * start to the last one's end.  Returns 1 when every round trip reproduced its bins, else 0.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef struct {
+  uint32_t seed, B, C;
+  int ep;
+  uint64_t s0, n;
+  int ok;
+} orc_rt_job;
+
+static void *orc_rt_worker(void *arg) {
+  orc_rt_job *j = (orc_rt_job *)arg;
+  const size_t cap = (6 * (size_t)j->B + 9 + 7) / 8 + 16;
+  uint8_t *bins = (uint8_t *)malloc(j->B), *ctx = (uint8_t *)malloc(j->B), *dec = (uint8_t *)malloc(j->B);
+  uint8_t *out = (uint8_t *)malloc(cap);
+  uint8_t init[256];
+  memset(init, 0, sizeof init); /* (mps 0, state 0): the workload's initialisation */
+  j->ok = bins && ctx && dec && out;
+  for (uint64_t s = 0; j->ok && s < j->n; s++) {
+    orc_synth_fill(j->seed, j->s0 + s, 1, j->B, j->C, j->ep, bins, ctx);
+    const size_t len = orc_encode_stream(bins, ctx, j->B, init, (int)j->C, out, cap, NULL, NULL);
+    const uint32_t st = orc_decode_stream(out, len, ctx, j->B, init, (int)j->C, dec, NULL);
+    if (len == 0 || st != 0 || memcmp(dec, bins, j->B) != 0) j->ok = 0;
+  }
+  free(bins);
+  free(ctx);
+  free(dec);
+  free(out);
+  return NULL;
+}
+
+int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint64_t nstreams, uint32_t B, uint32_t C, int ep_half, int nthreads,
+                          double *wall_s) {
+  if (nthreads < 1 || nthreads > 1024 || C > 255) return 0;
+  pthread_t th[1024];
+  orc_rt_job job[1024];
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  uint64_t at = s0;
+  for (int t = 0; t < nthreads; t++) {
+    const uint64_t n = nstreams / (uint64_t)nthreads + ((uint64_t)t < nstreams % (uint64_t)nthreads ? 1 : 0);
+    job[t] = (orc_rt_job){seed, B, C, ep_half, at, n, 0};
+    at += n;
+    if (pthread_create(&th[t], NULL, orc_rt_worker, &job[t]) != 0) return 0;
+  }
+  int ok = 1;
+  for (int t = 0; t < nthreads; t++) {
+    pthread_join(th[t], NULL);
+    ok &= job[t].ok;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (wall_s) *wall_s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return ok;
 }

@@ -192,6 +192,10 @@ uint64_t orc_trace_stats(const uint8_t *bins, const uint8_t *ctx, uint64_t nbins
 void orc_synth_fill(uint32_t seed, uint64_t s0, uint64_t nS, uint32_t B, uint32_t C,
                     int ep_half, uint8_t *bins, uint8_t *ctx);
 
+/* all-core CPU ceiling: the restatement, in-memory sink, native threads (bench.py cpu_baseline) */
+int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint64_t nstreams, uint32_t B, uint32_t C, int ep_half, int nthreads,
+                          double *wall_s);
+
 #ifdef __cplusplus
 }
 #endif

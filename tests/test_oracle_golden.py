@@ -137,3 +137,23 @@ def test_multi_ep_equals_single_ep(oracle, golden):
         assert payload.tobytes().hex() == o["payload"], o["name"]
         dec, status = oracle.decode_stream(payload, ctx, unhex(o["ctx_init"]))
         assert status == 0 and dec.tolist() == bins
+
+
+def test_p0_map_engine_oracle_and_independent_fixture_agree(oracle):
+    """row a9: the engine's host-side isscabac_init_by_prob, the oracle's restatement and a 256-entry table derived
+    independently (numpy, double: tests/golden/make_p0_fixture.py) give the same (mps, state) for every p0 = k / 255"""
+    import ctypes
+    import json
+    import os
+    from isscabac_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = np.array(json.load(open(os.path.join(root, "tests", "golden", "p0_state_lut.json")))["packed"], np.uint8)
+    p0 = np.arange(256, dtype=np.float64) / 255.0
+    assert (oracle.init_by_prob(p0) == want).all()
+    lib = ctypes.CDLL(build.build_lib())  # a pure host function: no GPU involved
+    got = np.zeros(256, np.uint8)
+    rc = lib.isscabac_init_by_prob(p0.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 256,
+                                   got.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    assert rc == 0 and (got == want).all()
+    # the shape SURVEY 8(a)-9 quotes from its probe of the real code
+    assert want[0] == (62 << 1 | 1) and want[127] == (0 << 1 | 1) and want[128] == 0 and want[255] == 62 << 1
