@@ -432,8 +432,27 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)
             if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
           }
+        } else if (CM != 2 && full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
+          // context-coded and bypass bins only (config 5's chunks): one select-based step per bin for every lane, no lane
+          // branches, `low` touched once per word (enc_bin_mixed_acc).  Bit 7 of a ctx byte says "bypass" here -- batches
+          // of more than 128 contexts never come this way --, and the state address of a bypass lane is made valid by
+          // masking the byte down to a context of the image (its state is written back unchanged).
+          constexpr uint32_t kIn = CM == 1 ? 0x3F3F3F3Fu : 0x7F7F7F7Fu;
+          EncWordAcc acc;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const uint32_t cw = word_of(wc, k >> 2);
+            const CtxQuad z = stx.prep4(cw & kIn);
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+            const uint32_t mb = byte_bit_mask(cw, k & 3, 7), bm = byte_bit_mask(w1, k & 3, 0);
+            with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed_acc(e, acc, (k & 3) == 0, bin, mb, bm, stx.addr_of(z, k & 3), stx); return 0; });
+            if ((k & 3) == 3) {
+              enc_word_close(e, acc);
+              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+            }
+          }
         } else {
-          // bypass bins (or contexts >= 128) somewhere in the wave, or streams that end inside this chunk.  The byte-table
+          // fixed-probability bins, contexts >= 128 or streams that end inside this chunk.  The byte-table
           // bin step works under any exec mask, so every lane simply takes its own branch: context-coded bin, bypass bin,
           // or nothing once its stream is over (all sides run when a wave mixes them: ~29 VALU per bin against ~37 for
           // one combined, select-based step).
@@ -641,6 +660,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             // Otherwise -- bypass bins in the chunk, or streams that end inside it -- every lane takes its own branch
             // under the exec mask: context bin, bypass bin, or nothing (its output reads 0) once its stream is over.
             const bool plain = full && !hi;
+            // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed), see k_encode
+            const bool mixed = CM != 2 && full && hi &&
+                               !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0);
+            constexpr uint32_t kIn = CM == 1 ? 0x3F3F3F3Fu : 0x7F7F7F7Fu;
             // latency-oriented instance (see dec_bin_lat): the state of the next bin is loaded one bin ahead, the
             // successor forwarded in a register for a repeated context
             uint32_t at = 0, at_prev = 0, nx_prev = 0, qld = 0;
@@ -677,6 +700,13 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                 for (int k = 0; k < 4; k++) {
                   if (k == 3) dec_guard(d, src, 7);
                   ob = collect_bin(ob, dec_bin_at_mem(d, stx.addr_of(z, k), stx));
+                }
+              } else if (mixed) {
+                const CtxQuad zs = stx.prep4(cw & kIn);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  if (k == 3) dec_guard(d, src, 8);
+                  ob = collect_bin(ob, dec_bin_mixed(d, byte_bit_mask(cw, k, 7), stx.addr_of(zs, k), stx));
                 }
               } else {
 #pragma unroll

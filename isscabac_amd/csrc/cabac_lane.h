@@ -179,6 +179,12 @@ CABAC_HD uint32_t collected_bytes(uint32_t acc, int w) {
 // context c lives at (c / 4) * 256 + lane * 4 + c % 4 (see LdsStates), i.e. offset X(c) = ((c >> 2) << 8) | (c & 3)
 // before the lane term.  z01 = X(c0) | X(c1) << 16, z23 = X(c2) | X(c3) << 16: 3 + 2 instructions per four bins
 // instead of 4 per bin, and the per-bin address is one add with a 16-bit operand select.
+// 0x80 in every byte of a ctx word that has bit 7 set without being the bypass marker 0xFF (fixed-probability bins,
+// invalid bytes): such chunks take the general path.  (b & 0x7F) + 1 reaches bit 7 exactly for b & 0x7F == 0x7F.
+CABAC_HD uint32_t odd_high_bytes(uint32_t cw) { return cw & ~((cw & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u; }
+// ~0 if bit (8 k + bit) of w is set
+CABAC_HD uint32_t byte_bit_mask(uint32_t w, int k, int bit) { return (uint32_t)((int32_t)(w << (31 - 8 * k - bit)) >> 31); }
+
 struct CtxQuad {
   uint32_t z01, z23;
 };
@@ -293,6 +299,29 @@ CABAC_HD void enc_bin_at_mem_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin,
 CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
   e.low = (e.low << g.S) + g.T;
   e.W += (int32_t)g.S;
+}
+
+// One select-based step for chunks that mix context-coded and bypass bins (BASELINE config 5: every other bin is a
+// bypass bin), again accumulated per input word: with  T' = ((T + a) << n) + b  a context bin has (a, n, b) =
+// (rmps & m, shift, 0) and a bypass bin (0, 1, bin ? range : 0) -- low = 2 low + bin * range, ref:
+// CABAC_ArithmeticEncoder.cpp:250-270.  mb = ~0 for a bypass bin, 0 for a context bin; bmask = ~0 if the bin is 1.
+// A bypass lane still reads some state (its address is made valid by the caller) and writes it back unchanged, and its
+// range passes through the renormalisation untouched (it is normalised: shift 0).  No lane branches.
+// The bounds of EncWordAcc hold: a bypass bin adds one bit and a term below 2^9 like a context bin with shift 1.
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t mb, uint32_t bmask, Addr at,
+                                States &st) {
+  const uint32_t q = st.load_at(at);
+  st.store_at(at, select_mask(mb, q, st.next_mem(bin.or_q(q))));
+  const uint32_t m = mask_from_bit1(bin.xor_q(q)) & ~mb;  // ~0: a context bin that is not its mps
+  const uint32_t lps = st.lps_mem(q, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(mb, e.range, select_mask(m, lps, rmps));
+  const uint32_t n = clz32(r) - 23u;  // 0 for a bypass bin
+  const uint32_t nt = n - mb;         // ... which moves low by one bit all the same
+  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & mb & bmask);
+  g.S = (first ? 0u : g.S) + nt;
+  e.range = r << n;
 }
 
 // Latency-oriented form of enc_bin_at_mem_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides
@@ -636,6 +665,29 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   d.sh -= (int32_t)n;
   return idx;
 }
+// The decoder's select-based step for chunks that mix context-coded and bypass bins (see enc_bin_mixed_acc): a bypass
+// bin compares the value with the whole range one bit further down (ref: CABAC_ArithmeticDecoder.cpp:288-331) and leaves
+// range and state alone.  Returns the (mps, path) pair of dec_bin_at_mem; a bypass bin reports mps 0, which makes
+// pairs_to_bins() turn its path bit into the bin.  Needs sh >= 8 (a bypass bin) / 7 (a context bin).
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_mixed(DecCore &d, uint32_t mb, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  const uint32_t lps = st.lps_mem(q, d.range);
+  const uint32_t rmps = d.range - lps;
+  const int32_t sh = d.sh + (int32_t)mb;  // mb = -1: the bypass bin's bit
+  const uint32_t scaled = select_mask(mb, d.range, rmps) << sh;
+  uint32_t diff;
+  const bool below = __builtin_sub_overflow(d.v, scaled, &diff);  // the MPS path / a bypass bin of 0
+  const uint32_t idx = st.path_index(q) + (uint32_t)below;
+  st.store_at(at, select_mask(mb, q, st.next_path_mem(idx)));
+  const uint32_t r = select_mask(mb, d.range, below ? rmps : lps);
+  const uint32_t n = clz32(r) - 23u;
+  d.v = below ? d.v : diff;
+  d.range = r << n;
+  d.sh = sh - (int32_t)n;
+  return idx & ~(mb & 2u);
+}
+
 // Latency-oriented form of dec_bin_at_mem (see enc_bin_lat_acc): q comes from the caller (loaded one bin ahead, the
 // previous successor forwarded for a repeated context); the row and BOTH successors are fetched as soon as q is known,
 // so the decision needs no lookup behind it and the next bin's state is one select away.  nx receives the successor.

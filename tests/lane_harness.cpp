@@ -130,6 +130,9 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
                         int flush_every, uint8_t *out, size_t cap, uint8_t *ctx_final, int *max_w) {
   const bool any = flush_every < 0;
   if (any) flush_every = -flush_every;
+  // 20: the select-based step for words that mix context-coded and bypass bins (enc_bin_mixed_acc), every word it can take
+  const bool mixedw = flush_every == 20;
+  if (mixedw) flush_every = 18;
   // 19: the latency-oriented instance of that path: state read one bin ahead, successor forwarded for a repeated context
   const bool lat = flush_every == 19;
   if (lat) flush_every = 18;
@@ -147,6 +150,21 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   enc_start(e);
   int mw = 0;
   for (uint32_t i = 0; i < n; i++) {
+    auto ctx_or_ep = [&](uint32_t j) { return ctx[j] < 128 || ctx[j] == kBypass; };
+    if (mixedw && nctx <= 128 && i % 4 == 0 && i + 4 <= n && ctx_or_ep(i) && ctx_or_ep(i + 1) && ctx_or_ep(i + 2) && ctx_or_ep(i + 3)) {
+      EncWordAcc acc;
+      for (int k = 0; k < 4; k++) {  // the kernel's view: bit 7 = bypass, the state address masked into the image
+        const uint32_t c = ctx[i + k], mb = (c & 0x80u) ? ~0u : 0u, bm = bins[i + k] ? ~0u : 0u;
+        enc_bin_mixed_acc(e, acc, k == 0, HostBin{bins[i + k]}, mb, bm, st.addr(c & (nctx <= 64 ? 0x3Fu : 0x7Fu)), st);
+      }
+      if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
+      enc_word_close(e, acc);
+      if (e.W > mw) mw = e.W;
+      i += 3;
+      if (e.W >= 39) enc_flush16_wave(e, sink);
+      if (e.W > 62) return -2;
+      continue;
+    }
     if (wordacc && i % 4 == 0 && i + 4 <= n && ctx[i] < 128 && ctx[i + 1] < 128 && ctx[i + 2] < 128 && ctx[i + 3] < 128) {
       EncWordAcc acc;
       if (lat) {  // the kernel's order: read bin k + 1's state, then store bin k's successor, forward on equal addresses
@@ -211,6 +229,8 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   const bool any = group < 0;
   if (any) group = -group;
   // kernel fast path: one bit-granular top-up per 4 bins (no availability check), only the 4th bin guarded
+  const bool mixedw = group == 6;  // ... with the select-based step for context-coded and bypass bins alike (dec_bin_mixed)
+  if (mixedw) group = 3;
   const bool lat = group == 5;  // ... in the latency-oriented instance's order (state one bin ahead, forwarding)
   if (lat) group = 3;
   bool memtab = group == 3;  // ... with the byte-table bin step and (mps, lps) pair collection of the kernel
@@ -258,7 +278,11 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
       slow_refills++;
     }
     if (memtab) {  // bypass bins join the pair format as (bin, 0), like the kernel's mixed chunks
-      if (prob_of(i) && !is_ep(i)) {  // fixed-probability bin: no context model, joins the pair format like a bypass bin
+      if (mixedw && nctx <= 128 && (ctx[i] < 128 || ctx[i] == kBypass)) {
+        lat_have_prev = lat_have_qld = false;
+        const uint32_t c = ctx[i], mb = (c & 0x80u) ? ~0u : 0u;
+        pairs = collect_bin(pairs, dec_bin_mixed(d, mb, st.addr(c & (nctx <= 64 ? 0x3Fu : 0x7Fu)), st));
+      } else if (prob_of(i) && !is_ep(i)) {  // fixed-probability bin: no context model, joins the pair format like a bypass bin
         lat_have_prev = lat_have_qld = false;
         const uint32_t pp = prob_of(i);
         pairs = collect_bin(pairs, prob_valid(pp) ? pair_of_bin(dec_bin_prob(d, pp, kProbRow[prob_row_index(pp)])) : pair_of_bin(0u));

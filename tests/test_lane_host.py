@@ -72,16 +72,16 @@ def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
-@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 16, 17, 18, 19])
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 16, 17, 18, 19, 20])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
         out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
         assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
-        assert mw <= (62 if flush_every in (16, 17, 18, 19) else 20 + 6 * min(abs(flush_every), 4) + 1)
+        assert mw <= (62 if flush_every in (16, 17, 18, 19, 20) else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
-@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (6, 2, 2), (1, 7, -2), (2, 6, 3), (3, 2, 5)])
+@pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (6, 2, 2), (1, 7, -2), (2, 6, 3), (3, 2, 5), (1, 4, 6)])
 def test_decode_golden(lane, golden, pads):
     for s in golden["streams"]:
         bins, st, fin, _ = lane_decode(lane, s["payload_a"], s["ctx_a"], s["ctx_init_a"], pad_front=pads[0],
@@ -99,16 +99,16 @@ def test_fuzz_vs_oracle(lane, oracle):
         Cn = int(rng.choice([1, 3, 4, 5, 23, 64, 255]))
         init = rng.integers(0, 126, Cn).astype(np.uint8)
         ctx = rng.integers(0, Cn, n).astype(np.uint8)
-        if it % 3 == 1:
+        if it % 4 == 1:  # (4 against the 6 modes below: every mode sees bypass bins)
             ctx[rng.random(n) < 0.5] = 0xFF
         skew = rng.random(Cn + 1) ** (1 + it % 4)
         bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        got, fin, _ = lane_encode(lane, bins, ctx, init, (4, 16, 17, 18, 19)[it % 5])
+        got, fin, _ = lane_encode(lane, bins, ctx, init, (4, 16, 17, 18, 19, 20)[it % 6])
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
-                                         pad_back=int(rng.integers(0, 20)), group=(4, 16, 2, 3, 5)[it % 5])
+                                         pad_back=int(rng.integers(0, 20)), group=(4, 16, 2, 3, 5, 6)[it % 6])
         assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes()
         slow += cnt[2]
     assert slow > 0  # the in-chunk refill path was exercised
@@ -176,7 +176,7 @@ def test_corrupt_streams_same_bins_and_status_as_oracle(lane, oracle):
             bad = np.concatenate([bad, rng.integers(0, 256, 3).astype(np.uint8)])
         want, st_want = oracle.decode_stream(bad, ctx, init)
         got, st, _, _ = lane_decode(lane, bad, ctx, init, pad_front=2, pad_back=int(rng.integers(0, 30)),
-                                    group=int(rng.choice([2, 3, 4, -2, 5])))
+                                    group=int(rng.choice([2, 3, 4, -2, 5, 6])))
         assert (got == want).all()
         assert st == st_want
         flagged += st != 0
@@ -336,9 +336,9 @@ def test_fixed_probability_bins_match_the_reference(lane):
     doc = json.load(open(os.path.join(ROOT, "tests", "golden", "cabac_golden_f4.json")))
     for s in doc["streams"]:
         bins, ctx, init = unbits(s["bins"], s["n"]), unhex(s["ctx"]), unhex(s["ctx_init"])
-        for mode in (1, 4, 16, 17, 18, 19):
+        for mode in (1, 4, 16, 17, 18, 19, 20):
             got, fin, _ = lane_encode(lane, bins, ctx, init, mode)
             assert got.tobytes().hex() == s["payload"] and fin.tobytes().hex() == s["ctx_final"], (s["name"], mode)
-        for group in (4, 2, 3, 5):
+        for group in (4, 2, 3, 5, 6):
             dec, st, dfin, _ = lane_decode(lane, unhex(s["payload"]), ctx, init, pad_front=2, pad_back=3, group=group)
             assert st == 0 and (dec == bins).all() and dfin.tobytes().hex() == s["ctx_final"], (s["name"], group)
