@@ -85,8 +85,8 @@ void isscabac_destroy(isscabac_engine *e);
 const char *isscabac_last_error(const isscabac_engine *e);
 int isscabac_abi_version(void);
 /* Which instance of the batch coder kernels runs (results are bit-identical, only the schedule differs):
- *   AUTO        by launch size: the latency-oriented instance when the launch leaves at most 2.5 waves on a SIMD
- *               (up to 640 streams per compute unit: 160 Ki streams on an MI355X), else the throughput one
+ *   AUTO        by launch size: the latency-oriented instance when the launch leaves at most two waves on a SIMD
+ *               (up to 512 streams per compute unit: 128 Ki streams on an MI355X), else the throughput one
  *   THROUGHPUT  fewest instructions per bin; relies on four resident waves per SIMD to hide LDS latency
  *   LATENCY     state prefetch + register forwarding, no LDS round trip on the range recurrence; for small batches
  * (a strong-scaled job leaves each GPU 1/N of the streams: SURVEY.md 8(e)) */

@@ -80,6 +80,8 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->lens) (void)hipFree(e->lens);
   if (e->scan_tmp) (void)hipFree(e->scan_tmp);
   if (e->flag) (void)hipFree(e->flag);
+  if (e->order) (void)hipFree(e->order);
+  if (e->order_tmp) (void)hipFree(e->order_tmp);
   for (void *p : e->stage)
     if (p) (void)hipFree(p);
   if (e->prof) {
@@ -168,18 +170,34 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   sh->nbins = nbins;
   sh->pitch = pitch;
   sh->nctx = (uint32_t)nctx;
+  sh->d_order = nullptr;
   // Kernel instance.  The throughput instance hides its three dependent LDS round trips per bin behind the other waves
-  // of the SIMD and needs four of them for that (4 workgroups x 4 waves per CU).  Measured on MI355X (tools/s_sweep.py,
-  // profiles/r02): with two waves per SIMD (128 Ki streams) the latency-oriented instance is 5 % faster, with one 17 %;
-  // with four or more the throughput instance wins by 5 %.  The switch sits at 2.5 waves per SIMD.
+  // of the SIMD and needs about three of them for that.  Measured on MI355X (tools/s_sweep.py, profiles/r02): with two
+  // waves per SIMD (128 Ki streams) the latency-oriented instance is 5 % faster, with one 17 %; from 2.5 waves per SIMD
+  // on the throughput instance wins by 3-5 %.  The switch sits at two waves per SIMD.
   sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY ||
-                (e->tuning == ISSCABAC_TUNE_AUTO && 2 * S <= 5ull * (uint64_t)e->num_cus * 4 * 64);
+                (e->tuning == ISSCABAC_TUNE_AUTO && S <= 2ull * (uint64_t)e->num_cus * 4 * 64);
   for (int c = 0; c < nctx; c++) {
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     sh->ctx_init[c] = ctx_init[c];
   }
   // contexts the caller did not initialise behave like the reference's default ContextModel(): (mps 1, state 0)
   for (int c = nctx; c < 256; c++) sh->ctx_init[c] = 1;
+  return ISSCABAC_OK;
+}
+
+// Ragged batch (per-stream bin counts on the device): sort the stream ids by length so that the 64 streams of a wave
+// are alike (cabac_order.hip).  Enqueued on the engine's stream in front of the coder kernel; sh->d_order stays null for
+// small or uniform batches.
+static int bucket_by_length(isscabac_engine *e, BatchShape *sh, const uint32_t *d_nbins) {
+  sh->d_order = nullptr;
+  if (!d_nbins || sh->S < 4096 || sh->S >= (1ull << 31) || e->tuning == ISSCABAC_TUNE_LATENCY) return ISSCABAC_OK;
+  int rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->order), &e->order_bytes, sh->S * sizeof(uint32_t)))) return rc;
+  const uint64_t need = order_tmp_bytes(sh->S);
+  if ((rc = grow(e, &e->order_tmp, &e->order_tmp_cap, need))) return rc;
+  HIP_TRY(e, launch_order(d_nbins, sh->S, sh->nbins, e->order, e->order_tmp, e->order_tmp_cap, e->stream));
+  sh->d_order = e->order;
   return ISSCABAC_OK;
 }
 
@@ -258,6 +276,7 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 0, &ps))) return rc;
 
+  if ((rc = bucket_by_length(e, &sh, d_nbins))) return rc;
   PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
   PROF_MARK(e, ps, 1);
@@ -310,6 +329,7 @@ int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 1, &ps))) return rc;
   HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+  if ((rc = bucket_by_length(e, &sh, d_nbins))) return rc;
   PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag, e->stream));
   PROF_MARK(e, ps, 1);

@@ -25,6 +25,10 @@ struct isscabac_engine {
   uint64_t lens_bytes = 0;
   void *scan_tmp = nullptr;
   uint64_t scan_tmp_bytes = 0;
+  uint32_t *order = nullptr;  // length bucketing of ragged batches: the sorted stream ids, and the sort's scratch
+  uint64_t order_bytes = 0;
+  void *order_tmp = nullptr;
+  uint64_t order_tmp_cap = 0;
   uint32_t *flag = nullptr;  // one word: "some stream needs the reference-formulation decoder" (see launch_decode_exact)
   // staging for the host-buffer entry points
   void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -76,6 +80,7 @@ struct BatchShape {
   uint32_t pitch;    // bytes between consecutive streams' rows, multiple of 16
   uint32_t nctx;     // contexts (1..255)
   bool latency;      // run the latency-oriented kernel instance (few waves per SIMD), see isscabac_set_tuning
+  const uint32_t *d_order;  // device: stream ids sorted by bin count (length-bucketed launch, cabac_order.hip) or null
   uint8_t ctx_init[256];
 };
 
@@ -102,6 +107,10 @@ hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_
 hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
                                const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
                                uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream);
+// ragged batches: stream ids sorted by min(d_nbins[s], nbins), longest first (cabac_order.hip); d_tmp needs order_tmp_bytes(S)
+uint64_t order_tmp_bytes(uint64_t S);
+hipError_t launch_order(const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t *d_order, void *d_tmp, uint64_t tmp_bytes,
+                        hipStream_t stream);
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);

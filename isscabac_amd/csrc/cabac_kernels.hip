@@ -141,6 +141,19 @@ struct Tile {
       else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(rows + voff) : make_uint4(0, 0, 0, 0);
     }
   }
+  // The same for a wave whose 64 streams are NOT neighbours in the array (length-bucketed launches, cabac_order.hip):
+  // rid[k] = stream id of the row this lane fetches a piece of with load k; one 64-bit multiply-add per load
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows(uint4 (&r)[NLD], const uint8_t *base, const uint32_t (&rid)[NLD], uint32_t pitch,
+                                                   uint32_t off, int lane) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint32_t boff = off + ch_of(lane) * 16;
+      const uint8_t *p = base + ((uint64_t)rid[k] * pitch + boff);
+      if (NT) r[k] = boff < pitch ? nt_load16(p) : make_uint4(0, 0, 0, 0);
+      else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
+    }
+  }
   // half h (0: bytes 0..31 of the round, 1: bytes 32..63) of the registers -> LDS
   __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
     if ((int)(ch_of(lane) >> 1) == h) {
@@ -285,6 +298,7 @@ struct SlotSink {
 struct EncArgs {
   const uint8_t *bins, *ctx;
   const uint32_t *nbins_per_stream;
+  const uint32_t *order;  // length-bucketed launch: lane l of wave w codes stream order[64 w + l] (else null)
   uint8_t *slots;
   uint32_t *lens;
   uint64_t S, slot_stride;
@@ -292,13 +306,14 @@ struct EncArgs {
   uint32_t ctx_init[64];
 };
 
-// LDS bytes of one wave: context states, two half tiles, (encoder) the output staging
-template <int CM>
+// LDS bytes of one wave: context states, two half tiles, (encoder) the output staging, (bucketed launches) the wave's stream ids
+template <int CM, bool PERM = false>
 struct WaveLds {
   static constexpr uint32_t SB = CM == 1 ? 4096u : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
-  static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE;
+  static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
+  static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE + IDS;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -314,7 +329,8 @@ struct WaveLds {
 
 // LAT: the latency-oriented instance for launches that leave fewer than four waves on a SIMD (see enc_bin_lat_acc):
 // the same bytes, three more VALU instructions per bin, one LDS round trip per bin instead of three behind each other
-template <int CM, bool LAT>
+// PERM: a length-bucketed launch (cabac_order.hip): the wave's 64 streams are order[s0 .. s0 + 63]
+template <int CM, bool LAT, bool PERM>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -328,12 +344,21 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
-  using WL = WaveLds<CM>;
+  using WL = WaveLds<CM, PERM>;
   uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
   uint8_t *tile_b = wbase + WL::SB, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
 
   const bool valid = s0 + lane < a.S;
-  const uint64_t s = valid ? s0 + lane : a.S - 1;
+  const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
+  const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
+  uint32_t rid[Tile::NLD] = {0, 0, 0, 0};
+  if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
+    uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);
+    wids[lane] = (uint32_t)s;
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < Tile::NLD; k++) rid[k] = wids[Tile::row_of(k, lane)];
+  }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
   const uint32_t nmax = wave_max_u32(n), nmin = wave_min_u32(n);
@@ -355,8 +380,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   enc_start(e);
   SlotSink sink;
   sink.stage = stage + lane * 16;
-  sink.slots = a.slots + s0 * a.slot_stride;
-  sink.mine = (uint32_t)(s - s0) * (uint32_t)a.slot_stride;
+  sink.slots = a.slots + (PERM ? s : s0) * a.slot_stride;
+  sink.mine = PERM ? 0u : (uint32_t)(s - s0) * (uint32_t)a.slot_stride;
   sink.pos = 0;
   sink.on = valid;
 
@@ -364,10 +389,16 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
   uint4 pb[Tile::NLD], pc[Tile::NLD];
-  if (nrounds) {
-    Tile::load(pb, bins_w, nrows, a.pitch, 0, lane);
-    Tile::load(pc, ctx_w, nrows, a.pitch, 0, lane);
-  }
+  auto fetch = [&](uint32_t off) {
+    if (PERM) {
+      Tile::load_rows(pb, a.bins, rid, a.pitch, off, lane);
+      Tile::load_rows(pc, a.ctx, rid, a.pitch, off, lane);
+    } else {
+      Tile::load(pb, bins_w, nrows, a.pitch, off, lane);
+      Tile::load(pc, ctx_w, nrows, a.pitch, off, lane);
+    }
+  };
+  if (nrounds) fetch(0);
   wave_lds_sync();
   for (uint32_t t = 0; t < nrounds; t++) {
 #pragma unroll
@@ -375,10 +406,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
       Tile::half_to_lds(tile_b, pb, h, lane);
       Tile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-      if (h == 1 && t + 1 < nrounds) {  // registers are free again: fetch the next round behind 32 bins of work
-        Tile::load(pb, bins_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
-        Tile::load(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
-      }
+      if (h == 1 && t + 1 < nrounds) fetch((t + 1) * Tile::T);  // registers are free again: the next round, behind 32 bins of work
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
         if (i0 >= nmax) break;
@@ -525,6 +553,7 @@ struct DecArgs {
   const uint8_t *payload, *ctx;
   const uint64_t *offsets;
   const uint32_t *nbins_per_stream;
+  const uint32_t *order;  // as in EncArgs
   uint8_t *bins_out;
   uint32_t *status;
   uint32_t *exact_flag;  // set when a stream of this launch needs k_decode_exact
@@ -538,7 +567,7 @@ struct DecArgs {
 #endif
 constexpr bool kDecNT = true;  // decode kernel: ctx loads and bin stores are streaming
 
-template <int CM, bool LAT>
+template <int CM, bool LAT, bool PERM>
 __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -552,12 +581,21 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
-  using WL = WaveLds<CM>;
+  using WL = WaveLds<CM, PERM>;
   uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
   uint8_t *tile_c = wbase + WL::SB, *tile_o = tile_c + WL::TILE;
+  const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_o + WL::TILE + WL::STAGE);  // PERM: the wave's stream ids
 
   const bool valid = s0 + lane < a.S;
-  const uint64_t s = valid ? s0 + lane : a.S - 1;
+  const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
+  const uint64_t s = PERM ? a.order[slot] : slot;           // the stream decoded here
+  uint32_t rid[Tile::NLD] = {0, 0, 0, 0};
+  if (PERM) {
+    const_cast<uint32_t *>(wids)[lane] = (uint32_t)s;
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < Tile::NLD; k++) rid[k] = wids[Tile::row_of(k, lane)];
+  }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
   const uint32_t nmin = wave_min_u32(n), nmax = wave_max_u32(n);
@@ -611,17 +649,22 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       v.z = collected_bytes(bits, 2);
       v.w = collected_bytes(bits, 3);
       const uint32_t boff = off + c * 16;
-      const uint32_t voff = row * a.pitch + boff;  // 32-bit: see Tile::load
       if (row < nrows && boff < a.pitch) {
-        if (kDecNT) nt_store16(out_w + voff, v);
-        else *reinterpret_cast<uint4 *>(out_w + voff) = v;
+        // 32-bit offset from the wave's first row (see Tile::load), or the row of stream wids[row]
+        uint8_t *p = PERM ? a.bins_out + ((uint64_t)wids[row] * a.pitch + boff) : out_w + (row * a.pitch + boff);
+        if (kDecNT) nt_store16(p, v);
+        else *reinterpret_cast<uint4 *>(p) = v;
       }
     }
   };
 
   const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
   uint4 pc[Tile::NLD];
-  if (nrounds) Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, 0, lane);
+  auto fetch = [&](uint32_t off) {
+    if (PERM) Tile::load_rows<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
+    else Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
+  };
+  if (nrounds) fetch(0);
   wave_lds_sync();
   bool have_out = false;
   uint32_t out_off = 0;
@@ -645,7 +688,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             have_out = false;
           }
           if (h == 1 && t + 1 < nrounds && (t + 1) * Tile::T < nmax)  // nothing to decode past the wave's longest stream
-            Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, (t + 1) * Tile::T, lane);
+            fetch((t + 1) * Tile::T);
         }
         if (live) {
           const uint4 wc = Tile::row_chunk(tile_c, lane, j);
@@ -965,57 +1008,62 @@ uint64_t slot_stride_for(uint32_t nbins) {
   return (bound + 16 + 15) & ~15ull;  // the sink writes whole 16-byte pieces
 }
 
-template <int CM>
+template <int CM, bool PERM>
 static size_t coder_lds_bytes() {
-  return kTabBytes + waves_per_block(CM) * WaveLds<CM>::BYTES;
+  return kTabBytes + waves_per_block(CM) * WaveLds<CM, PERM>::BYTES;
 }
 
-template <int CM, bool LAT>
+template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT>),
+  const size_t lds = coder_lds_bytes<CM, PERM>();
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   // LdsStates<.., NEXT16> addresses its table by absolute LDS address: the dynamic LDS must start at 0
   static int static_lds = -1;
   if (static_lds < 0) {
     hipFuncAttributes fa;
-    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode<CM, LAT>));
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>));
     if (err != hipSuccess) return err;
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_encode<CM, LAT>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
-template <int CM, bool LAT>
+template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<CM>();
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT>),
+  const size_t lds = coder_lds_bytes<CM, PERM>();
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   static int static_lds = -1;  // absolute LDS addresses, as in run_encode
   if (static_lds < 0) {
     hipFuncAttributes fa;
-    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode<CM, LAT>));
+    err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>));
     if (err != hipSuccess) return err;
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_decode<CM, LAT>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
 // sh.latency selects the latency-oriented instance (<= 64 contexts only: the bigger state images run single-wave
 // workgroups whose occupancy is set by LDS, not by the number of streams)
-#define ISSCABAC_DISPATCH(FN, ARGS)                                      \
-  do {                                                                   \
-    if (sh.nctx <= 64) return sh.latency ? FN<1, true>(ARGS, stream) : FN<1, false>(ARGS, stream); \
-    if (sh.nctx <= 128) return FN<3, false>(ARGS, stream);               \
-    return FN<2, false>(ARGS, stream);                                   \
+#define ISSCABAC_DISPATCH(FN, ARGS)                                                                     \
+  do {                                                                                                  \
+    if (sh.d_order) { /* length-bucketed launch */                                                      \
+      if (sh.nctx <= 64) return FN<1, false, true>(ARGS, stream);                                       \
+      if (sh.nctx <= 128) return FN<3, false, true>(ARGS, stream);                                      \
+      return FN<2, false, true>(ARGS, stream);                                                          \
+    }                                                                                                   \
+    if (sh.nctx <= 64) return sh.latency ? FN<1, true, false>(ARGS, stream) : FN<1, false, false>(ARGS, stream); \
+    if (sh.nctx <= 128) return FN<3, false, false>(ARGS, stream);                                       \
+    return FN<2, false, false>(ARGS, stream);                                                           \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
@@ -1024,6 +1072,7 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
   a.bins = d_bins;
   a.ctx = d_ctx;
   a.nbins_per_stream = d_nbins;
+  a.order = sh.d_order;
   a.slots = d_slots;
   a.lens = d_lens;
   a.S = sh.S;
@@ -1042,6 +1091,7 @@ static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_pay
   a.ctx = d_ctx;
   a.offsets = d_offsets;
   a.nbins_per_stream = d_nbins;
+  a.order = sh.d_order;
   a.bins_out = d_bins_out;
   a.status = d_status;
   a.exact_flag = d_flag;

@@ -615,6 +615,51 @@ def test_contexts_between_nctx_and_the_state_image_are_default_models(engine, or
         assert (status == 0).all() and (dec == bins).all(), C
 
 
+def test_length_bucketed_ragged_batches(engine, oracle):
+    """batches with per-stream bin counts on the device and at least 4 096 streams are length-bucketed (cabac_order.hip):
+    a wave's 64 streams are then not neighbours in the arrays.  Same bytes, same bins, same status, stream by stream."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(91)
+    for S, B, C, ep in ((4096, 256, 64, False), (9000, 528, 100, True), (5003, 144, 200, False)):
+        bins, ctx = oracle.synth(0xCABAC005, 7, S, B, min(C, 64), ep)
+        if C > 64:
+            ctx = np.where(ctx == 0xFF, ctx, (ctx.astype(np.int64) * 3 % C)).astype(np.uint8)
+        init = rng.integers(0, 126, C).astype(np.uint8)
+        nb = rng.integers(0, B + 1, S).astype(np.uint32)
+        nb[rng.integers(0, S, 50)] = 0
+        nb[rng.integers(0, S, 50)] = B
+        want_p, want_o = oracle.encode_batch(bins, ctx, init, nb)
+        pitch = (B + 15) // 16 * 16
+        tb = torch.zeros((S, pitch), dtype=torch.uint8, device=dev)
+        tc = torch.zeros((S, pitch), dtype=torch.uint8, device=dev)
+        tb[:, :B] = torch.from_numpy(bins).to(dev)
+        tc[:, :B] = torch.from_numpy(ctx).to(dev)
+        tn = torch.from_numpy(nb.astype(np.int32)).to(dev)
+        cap = int(want_p.size) + 64
+        payload = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        offsets = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        total = engine.encode_dev(tb.data_ptr(), tc.data_ptr(), S, B, pitch, init, payload.data_ptr(), cap, offsets.data_ptr(),
+                                  d_nbins=tn.data_ptr())
+        assert total == want_p.size and offsets.cpu().numpy().astype(np.uint64).tolist() == want_o.tolist()
+        assert payload[:total].cpu().numpy().tobytes() == want_p.tobytes()
+        out = torch.full((S, pitch), 7, dtype=torch.uint8, device=dev)
+        status = torch.full((S,), 9, dtype=torch.int32, device=dev)
+        engine.decode_dev(payload.data_ptr(), total, offsets.data_ptr(), tc.data_ptr(), S, B, pitch, init, out.data_ptr(),
+                          status.data_ptr(), d_nbins=tn.data_ptr())
+        got = out.cpu().numpy()[:, :B]
+        mask = np.arange(B)[None, :] < nb[:, None]
+        assert int(status.abs().sum()) == 0 and (got * mask == bins * mask).all() and not (got * ~mask).any()
+        # corrupted payload: bins and flags stream by stream like the oracle's
+        bad = want_p.copy()
+        bad[rng.integers(0, bad.size, bad.size // 40)] ^= 0x5A
+        wd, ws = oracle.decode_batch(bad, want_o, ctx, init, nb)
+        payload[:total] = torch.from_numpy(bad).to(dev)
+        engine.decode_dev(payload.data_ptr(), total, offsets.data_ptr(), tc.data_ptr(), S, B, pitch, init, out.data_ptr(),
+                          status.data_ptr(), d_nbins=tn.data_ptr())
+        assert (status.cpu().numpy().astype(np.uint32) == ws).all() and (out.cpu().numpy()[:, :B] * mask == wd * mask).all()
+
+
 def test_garbage_offsets_in_device_memory_are_clipped_not_followed(engine):
     """the device-pointer decode call cannot validate offsets that live in device memory: whatever they say, the kernels
     stay inside the payload buffer (streams clipped to it), flag the streams and return"""
