@@ -472,7 +472,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const uint32_t cw = word_of(wc, k >> 2);
             const CtxQuad z = stx.prep4(cw & kIn);
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-            const uint32_t mb = byte_bit_mask(cw, k & 3, 7), bm = byte_bit_mask(w1, k & 3, 0);
+            const uint32_t wbm = w1 & (cw >> 7);  // per word: bit 0 of byte k = "bypass bin of 1"
+            const uint32_t mb = byte_bit_mask(cw, k & 3, 7), bm = byte_bit_mask(wbm, k & 3, 0);
             with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed_acc(e, acc, (k & 3) == 0, bin, mb, bm, stx.addr_of(z, k & 3), stx); return 0; });
             if ((k & 3) == 3) {
               enc_word_close(e, acc);

@@ -304,7 +304,8 @@ CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
 // One select-based step for chunks that mix context-coded and bypass bins (BASELINE config 5: every other bin is a
 // bypass bin), again accumulated per input word: with  T' = ((T + a) << n) + b  a context bin has (a, n, b) =
 // (rmps & m, shift, 0) and a bypass bin (0, 1, bin ? range : 0) -- low = 2 low + bin * range, ref:
-// CABAC_ArithmeticEncoder.cpp:250-270.  mb = ~0 for a bypass bin, 0 for a context bin; bmask = ~0 if the bin is 1.
+// CABAC_ArithmeticEncoder.cpp:250-270.  mb = ~0 for a bypass bin, 0 for a context bin; bmask = ~0 for a bypass bin of 1
+// (the caller forms it for a whole input word at once).
 // A bypass lane still reads some state (its address is made valid by the caller) and writes it back unchanged, and its
 // range passes through the renormalisation untouched (it is normalised: shift 0).  No lane branches.
 // The bounds of EncWordAcc hold: a bypass bin adds one bit and a term below 2^9 like a context bin with shift 1.
@@ -319,7 +320,7 @@ CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, 
   const uint32_t r = select_mask(mb, e.range, select_mask(m, lps, rmps));
   const uint32_t n = clz32(r) - 23u;  // 0 for a bypass bin
   const uint32_t nt = n - mb;         // ... which moves low by one bit all the same
-  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & mb & bmask);
+  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & bmask);
   g.S = (first ? 0u : g.S) + nt;
   e.range = r << n;
 }

@@ -154,7 +154,7 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     if (mixedw && nctx <= 128 && i % 4 == 0 && i + 4 <= n && ctx_or_ep(i) && ctx_or_ep(i + 1) && ctx_or_ep(i + 2) && ctx_or_ep(i + 3)) {
       EncWordAcc acc;
       for (int k = 0; k < 4; k++) {  // the kernel's view: bit 7 = bypass, the state address masked into the image
-        const uint32_t c = ctx[i + k], mb = (c & 0x80u) ? ~0u : 0u, bm = bins[i + k] ? ~0u : 0u;
+        const uint32_t c = ctx[i + k], mb = (c & 0x80u) ? ~0u : 0u, bm = (bins[i + k] && mb) ? ~0u : 0u;
         enc_bin_mixed_acc(e, acc, k == 0, HostBin{bins[i + k]}, mb, bm, st.addr(c & (nctx <= 64 ? 0x3Fu : 0x7Fu)), st);
       }
       if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;

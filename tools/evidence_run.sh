@@ -1,16 +1,23 @@
-# usage (GPU box, repo root): bash tools/evidence_run.sh -- bench line, rocprof kernel stats, PMC passes and the other-shape
-# rates of the current build into gpurun_out/r01h; then: python tools/refresh_profiles.py gpurun_out/r01h r01
+# usage (GPU box, repo root): bash tools/evidence_run.sh <outdir>
+# bench line, rocprof kernel stats, PMC passes, the stream-count sweep and the other-shape rates of the current build into
+# <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r02
 set -u
-O=gpurun_out/r01h; mkdir -p $O
+O=${1:-gpurun_out/r02h}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify > $O/stats.log 2>&1
-bash tools/pmc_quick.sh $O/pmc > /dev/null 2>&1
-python3 tools/pmc_summary.py $O/pmc > $O/pmc_summary.json
-python3 tools/pmc_table.py $O/pmc > $O/pmc_table.txt
+PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config3 > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_config3 > $O/pmc_summary.json
+python3 tools/pmc_case_table.py $O/pmc_config3 1048576 4096 > $O/pmc_table.txt
+PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config5 --workload config5_per_gpu > /dev/null 2>&1
+python3 tools/pmc_case_table.py $O/pmc_config5 1048576 8192 >> $O/pmc_table.txt
+bash tools/pmc_case.sh $O/pmc_128k --streams 131072 > /dev/null 2>&1
+python3 tools/pmc_case_table.py $O/pmc_128k 131072 4096 >> $O/pmc_table.txt
+python tools/s_sweep.py --out $O/s_sweep.json > $O/s_sweep.txt 2>&1
 {
-echo "== bench.py --workload config5_per_gpu"; python bench.py --workload config5_per_gpu --steps 3 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernels_ms'], d['config']['workload'])"
-echo "== bench.py --workload config2"; python bench.py --workload config2 --steps 20 --warmup 3 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernels_ms'], d['config']['workload'])"
+echo "== bench.py --workload config5 (8 Mi streams x 8 Ki bins on ONE GPU, 8 launches per step)"; python bench.py --workload config5 --steps 3 --warmup 1 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernels_ms'], d['config']['workload'], 'verified', d['verified_bit_exact'])"
+echo "== bench.py --workload config5_per_gpu"; python bench.py --workload config5_per_gpu --steps 5 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernels_ms'], d['config']['workload'])"
+echo "== bench.py --workload config2"; python bench.py --workload config2 --steps 50 --warmup 3 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['kernels_ms'], d['config']['workload'])"
 echo "== tools/ctx_rates.py"; python tools/ctx_rates.py
 echo "== tools/ragged_rate.py"; python tools/ragged_rate.py
 echo "== tools/symbol_rate.py"; python tools/symbol_rate.py
