@@ -135,14 +135,12 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
         if hasattr(orc, "roundtrip_threads"):
             # the restatement with an in-memory sink on native threads, streams split evenly: no files, no Python between
             # streams -- the honest all-core CPU figure
-            nstreams = max(ncores * 8, int(budget_s * 0.3 * 0.03e9 * ncores / B))  # ~30 Mbin/s per core
-            nstreams = (nstreams + ncores - 1) // ncores * ncores
-            wall, ok = orc.roundtrip_threads(seed, 1 << 21, nstreams, B, C, ep, ncores)
+            nstreams, wall, ok = orc.roundtrip_threads(seed, 1 << 21, B, C, ep, ncores, budget_s * 0.3)
             assert ok, "in-memory restatement round trip failed"
             out["all_cores_in_memory"] = {"value": nstreams * B / wall / 1e9, "unit": "Gbin/s", "cores": ncores,
                                           "kind": "port",
-                                          "note": "C restatement, in-memory sink, %d native threads, %d streams split "
-                                                  "evenly, wall time of the slowest thread" % (ncores, nstreams)}
+                                          "note": "C restatement, in-memory sink, %d native threads for %.1f s, %d streams "
+                                                  "completed" % (ncores, wall, nstreams)}
     return out
 
 

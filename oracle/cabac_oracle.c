@@ -1052,10 +1052,17 @@ uint64_t orc_trace_stats(const uint8_t *bins, const uint8_t *ctx, uint64_t nbins
 
 typedef struct {
   uint32_t seed, B, C;
-  int ep;
-  uint64_t s0, n;
+  int ep, nthreads, t;
+  uint64_t s0, done;
+  double seconds;
   int ok;
 } orc_rt_job;
+
+static double orc_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static void *orc_rt_worker(void *arg) {
   orc_rt_job *j = (orc_rt_job *)arg;
@@ -1065,11 +1072,14 @@ static void *orc_rt_worker(void *arg) {
   uint8_t init[256];
   memset(init, 0, sizeof init); /* (mps 0, state 0): the workload's initialisation */
   j->ok = bins && ctx && dec && out;
-  for (uint64_t s = 0; j->ok && s < j->n; s++) {
-    orc_synth_fill(j->seed, j->s0 + s, 1, j->B, j->C, j->ep, bins, ctx);
+  const double deadline = orc_now() + j->seconds;
+  /* thread t takes streams s0 + t, s0 + t + nthreads, ... until the time is up */
+  for (uint64_t k = 0; j->ok && orc_now() < deadline; k++) {
+    orc_synth_fill(j->seed, j->s0 + (uint64_t)j->t + k * (uint64_t)j->nthreads, 1, j->B, j->C, j->ep, bins, ctx);
     const size_t len = orc_encode_stream(bins, ctx, j->B, init, (int)j->C, out, cap, NULL, NULL);
     const uint32_t st = orc_decode_stream(out, len, ctx, j->B, init, (int)j->C, dec, NULL);
     if (len == 0 || st != 0 || memcmp(dec, bins, j->B) != 0) j->ok = 0;
+    j->done++;
   }
   free(bins);
   free(ctx);
@@ -1078,26 +1088,25 @@ static void *orc_rt_worker(void *arg) {
   return NULL;
 }
 
-int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint64_t nstreams, uint32_t B, uint32_t C, int ep_half, int nthreads,
-                          double *wall_s) {
+/* runs for about `seconds`; *streams_done = round trips completed by all threads, *wall_s = first start to last end */
+int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint32_t B, uint32_t C, int ep_half, int nthreads, double seconds,
+                          uint64_t *streams_done, double *wall_s) {
   if (nthreads < 1 || nthreads > 1024 || C > 255) return 0;
-  pthread_t th[1024];
-  orc_rt_job job[1024];
-  struct timespec t0, t1;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
-  uint64_t at = s0;
+  static pthread_t th[1024];
+  static orc_rt_job job[1024];
+  const double t0 = orc_now();
   for (int t = 0; t < nthreads; t++) {
-    const uint64_t n = nstreams / (uint64_t)nthreads + ((uint64_t)t < nstreams % (uint64_t)nthreads ? 1 : 0);
-    job[t] = (orc_rt_job){seed, B, C, ep_half, at, n, 0};
-    at += n;
+    job[t] = (orc_rt_job){seed, B, C, ep_half, nthreads, t, s0, 0, seconds, 0};
     if (pthread_create(&th[t], NULL, orc_rt_worker, &job[t]) != 0) return 0;
   }
   int ok = 1;
+  uint64_t done = 0;
   for (int t = 0; t < nthreads; t++) {
     pthread_join(th[t], NULL);
     ok &= job[t].ok;
+    done += job[t].done;
   }
-  clock_gettime(CLOCK_MONOTONIC, &t1);
-  if (wall_s) *wall_s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (wall_s) *wall_s = orc_now() - t0;
+  if (streams_done) *streams_done = done;
   return ok;
 }

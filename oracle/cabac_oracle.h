@@ -193,8 +193,8 @@ void orc_synth_fill(uint32_t seed, uint64_t s0, uint64_t nS, uint32_t B, uint32_
                     int ep_half, uint8_t *bins, uint8_t *ctx);
 
 /* all-core CPU ceiling: the restatement, in-memory sink, native threads (bench.py cpu_baseline) */
-int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint64_t nstreams, uint32_t B, uint32_t C, int ep_half, int nthreads,
-                          double *wall_s);
+int orc_roundtrip_threads(uint32_t seed, uint64_t s0, uint32_t B, uint32_t C, int ep_half, int nthreads, double seconds,
+                          uint64_t *streams_done, double *wall_s);
 
 #ifdef __cplusplus
 }

@@ -389,14 +389,16 @@ class Oracle:
         st = self.lib.orc_demo_decode(_p(payload, u8p), payload.size, nsym, nq, _p(ctx_init, u8p), _p(sym, u32p))
         return sym, int(st)
 
-    def roundtrip_threads(self, seed, s0, nstreams, B, Cn, ep_half, nthreads):
-        """the restatement, in-memory sink, `nthreads` native threads -> (wall seconds, every round trip exact)"""
+    def roundtrip_threads(self, seed, s0, B, Cn, ep_half, nthreads, seconds):
+        """the restatement, in-memory sink, `nthreads` native threads for about `seconds` ->
+        (streams completed, wall seconds, every round trip exact)"""
         f = self.lib.orc_roundtrip_threads
         f.restype = C.c_int
-        f.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, f64p]
-        wall = C.c_double(0)
-        ok = f(int(seed), int(s0), int(nstreams), int(B), int(Cn), int(bool(ep_half)), int(nthreads), C.byref(wall))
-        return wall.value, bool(ok)
+        f.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double, u64p, f64p]
+        wall, done = C.c_double(0), C.c_uint64(0)
+        ok = f(int(seed), int(s0), int(B), int(Cn), int(bool(ep_half)), int(nthreads), float(seconds), C.byref(done),
+               C.byref(wall))
+        return int(done.value), wall.value, bool(ok)
 
     def synth(self, seed, s0, nS, B, Cn, ep_half=False):
         bins = np.zeros((nS, B), np.uint8)
