@@ -418,27 +418,46 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
           // every lane codes 16 context bins.  The state of bin k + 1 is read before the successor of bin k is stored
           // (after the store of bin k - 1: LDS operations of a wave complete in order) and replaced by that successor
           // in a register when both bins name the same context
+          // The arithmetic of bin k - 1 runs between the lookups of bin k and the store that waits for them.
           EncWordAcc acc;
           CtxQuad z = stx.prep4(wc.x);
           uint32_t at = stx.addr32_of(z, 0), at_prev = 0, nx_prev = 0;
           uint32_t qld = stx.load_at(at);
+          uint32_t q_p = 0, row_p = 0;  // state and row of the bin whose arithmetic is still due
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
             const uint32_t q = (k > 0 && at == at_prev) ? nx_prev : qld;
-            uint32_t at_next = 0;
+            uint32_t at_next = 0, row = 0;
             if (k < 15) {
               if ((k & 3) == 3) z = stx.prep4(word_of(wc, (k + 1) >> 2));
               at_next = stx.addr32_of(z, (k + 1) & 3);
               qld = stx.load_at(at_next);
             }
-            nx_prev = with_bin_of_word(k, w2, w1, [&](auto bin) { return enc_bin_lat_acc(e, acc, (k & 3) == 0, bin, at, q, stx); });
+            nx_prev = with_bin_of_word(k, w2, w1, [&](auto bin) { return enc_lat_lookup(bin, q, stx, row); });
+            if (k > 0) {
+              const uint32_t v1 = word_of(wb, (k - 1) >> 2), v2 = v1 << 1;
+              with_bin_of_word(k - 1, v2, v1, [&](auto bin) { enc_lat_arith(e, acc, ((k - 1) & 3) == 0, bin, q_p, row_p); return 0; });
+              if (((k - 1) & 3) == 3) {
+                enc_word_close(e, acc);
+                if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+              }
+            }
+            // The store, and with it the wait for the lookups, has to stay BEHIND that arithmetic (the scheduler pulls it in
+            // front otherwise, and a sched_barrier makes the wait-count pass drain the counter at the barrier): it is
+            // issued by hand and names the arithmetic's results as inputs it does not use.  (A store the wait-count pass
+            // does not know about only makes its later counts conservative: LDS operations complete in order.)
+            asm volatile("ds_write_b8 %0, %1" ::"v"(at), "v"(nx_prev), "v"(e.range), "v"(acc.T) : "memory");
+            q_p = q;
+            row_p = row;
             at_prev = at;
             at = at_next;
-            if ((k & 3) == 3) {
-              enc_word_close(e, acc);
-              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
-            }
+          }
+          {
+            const uint32_t v1 = wb.w, v2 = v1 << 1;
+            enc_lat_arith(e, acc, false, BinOfWord<3>{v2, v1}, q_p, row_p);
+            enc_word_close(e, acc);
+            if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
           }
         } else if (full && !hi) {
           // every lane codes 16 context bins: convergent

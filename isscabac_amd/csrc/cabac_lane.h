@@ -37,8 +37,21 @@
 // "does any lane of the wave see x": wave-uniform on the device, the lane itself on the host harness
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CABAC_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0ull)
+// "does any lane have a < b" (signed) for the guards that sit on the per-word path: one v_cmp into an SGPR pair and one
+// scalar test.  Around a nested per-lane test the ballot idiom above compiles to three VALU and five SALU instructions
+// on this target (the lane mask is materialised as 0/1 and compared again).  CABAC_RARE_BODY() opens the guarded block
+// so that the per-lane test inside is not hoisted in front of the branch and merged with it.
+static __device__ __forceinline__ bool cabac_wave_any_lt(int32_t a, int32_t b) {
+  uint64_t m;
+  asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m != 0ull;
+}
+#define CABAC_WAVE_ANY_LT(a, b) cabac_wave_any_lt((int32_t)(a), (int32_t)(b))
+#define CABAC_RARE_BODY() asm volatile("")
 #else
 #define CABAC_WAVE_ANY(x) (x)
+#define CABAC_WAVE_ANY_LT(a, b) ((int32_t)(a) < (int32_t)(b))
+#define CABAC_RARE_BODY() ((void)0)
 #endif
 
 namespace isscabac {
@@ -98,9 +111,10 @@ CABAC_HD uint32_t packed_from_q(uint32_t q) { return q >> 1; }
 // rangeTabLps[state][(range >> 6) & 3] out of the state's table row (range is 256..510)
 CABAC_HD uint32_t lps_of(uint32_t row, uint32_t range) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  // v_alignbyte_b32 shifts {row, row} right by (range >> 6) bytes; whether the hardware takes 2 or more bits of the
-  // byte count (range >> 6 is 4..7), the low byte of the result is byte (range >> 6) & 3 of row
-  return __builtin_amdgcn_alignbyte(row, row, range >> 6) & 0xFFu;
+  // range is 256..510, so range >> 6 is 4..7 with zeros above: as a v_perm_b32 selector its byte 0 picks byte
+  // (range >> 6) - 4 of the high operand (row) and its bytes 1..3 pick byte 0 of the low operand (0) -- the entry,
+  // clean, in two instructions
+  return __builtin_amdgcn_perm(row, 0u, range >> 6);
 #else
   return (row >> ((range >> 3) & 0x18u)) & 0xFFu;
 #endif
@@ -197,6 +211,14 @@ CABAC_HD CtxQuad lds_ctx_quad(uint32_t cw) {
 }
 CABAC_HD uint32_t quad_field(const CtxQuad &z, int k) {
   return k == 0 ? (z.z01 & 0xFFFFu) : k == 1 ? (z.z01 >> 16) : k == 2 ? (z.z23 & 0xFFFFu) : (z.z23 >> 16);
+}
+// x, but the compiler may assume nothing about its value (stops it from narrowing a select of two zero-extended bytes to a
+// byte select followed by a mask); no instruction
+CABAC_HD uint32_t opaque(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(x));
+#endif
+  return x;
 }
 // (m & a) | (~m & b) in one instruction (v_bfi_b32); written out for the host build
 CABAC_HD uint32_t select_mask(uint32_t m, uint32_t a, uint32_t b) {
@@ -332,11 +354,20 @@ CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, 
 // picked in a register (lps_of), so the range -> LPS -> range recurrence never touches memory.  Same arithmetic, same
 // results.  Returns the successor state (what the caller forwards).
 // States policy: lps_row_mem(q) -> the row, next_mem(q | bin), store_at.
-template <class States, class Addr, class Bin>
-CABAC_HD uint32_t enc_bin_lat_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, uint32_t q, States &st) {
-  const uint32_t nx = st.next_mem(bin.or_q(q));
-  const uint32_t row = st.lps_row_mem(q);
-  st.store_at(at, nx);
+// ... in two halves, so that the caller can put the arithmetic of bin k - 1 between the lookups of bin k and the store that
+// has to wait for them (the arithmetic touches neither LDS nor the state chain):
+//   enc_lat_lookup  issues the two lookups of a bin, returns the successor (to store and to forward) and the row
+//   enc_lat_arith   range / low arithmetic of a bin from its state and row
+template <class States, class Bin>
+CABAC_HD uint32_t enc_lat_lookup(Bin bin, uint32_t q, States &st, uint32_t &row) {
+  // (opaque: the byte load's zero extension stays folded into the load although the value is both stored as a byte and
+  // selected against as a word)
+  const uint32_t nx = opaque(st.next_mem(bin.or_q(q)));
+  row = st.lps_row_mem(q);
+  return nx;
+}
+template <class Bin>
+CABAC_HD void enc_lat_arith(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t q, uint32_t row) {
   const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
   const uint32_t lps = lps_of(row, e.range);
   const uint32_t rmps = e.range - lps;
@@ -345,6 +376,13 @@ CABAC_HD uint32_t enc_bin_lat_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin
   g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
   g.S = (first ? 0u : g.S) + n;
   e.range = r << n;
+}
+template <class States, class Addr, class Bin>
+CABAC_HD uint32_t enc_bin_lat_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, uint32_t q, States &st) {
+  uint32_t row;
+  const uint32_t nx = enc_lat_lookup(bin, q, st, row);
+  st.store_at(at, nx);
+  enc_lat_arith(e, g, first, bin, q, row);
   return nx;
 }
 
@@ -609,7 +647,8 @@ CABAC_HD void dec_topup_nocheck(DecCore &d, Src &src) {
 // practically never, tops up the lanes that need it.
 template <class Src>
 CABAC_HD void dec_guard(DecCore &d, Src &src, int32_t min_sh) {
-  if (CABAC_WAVE_ANY(d.sh < min_sh)) {
+  if (CABAC_WAVE_ANY_LT(d.sh, min_sh)) {
+    CABAC_RARE_BODY();
     if (d.sh < min_sh) dec_topup(d, src);
   }
 }
@@ -696,7 +735,7 @@ CABAC_HD uint32_t dec_bin_mixed(DecCore &d, uint32_t mb, Addr at, States &st) {
 template <class States, class Addr>
 CABAC_HD uint32_t dec_bin_lat(DecCore &d, Addr at, uint32_t q, States &st, uint32_t &nx) {
   const uint32_t row = st.lps_row_mem(q);
-  const uint32_t nx_l = st.next_lps_mem(q), nx_m = st.next_mps_mem(q);
+  const uint32_t nx_l = opaque(st.next_lps_mem(q)), nx_m = opaque(st.next_mps_mem(q));  // (see enc_lat_lookup)
   const uint32_t lps = lps_of(row, d.range);
   const uint32_t rmps = d.range - lps;
   const uint32_t scaled = rmps << d.sh;
@@ -1010,7 +1049,8 @@ struct WindowSrc {
   }
   // wave-uniform: re-base when some lane's window holds fewer than n bits
   CABAC_HD void ensure(int32_t n) {
-    if (CABAC_WAVE_ANY(avail_bits() < n)) {
+    if (CABAC_WAVE_ANY_LT(avail_bits(), n)) {
+      CABAC_RARE_BODY();
       if (avail_bits() < n) rebase();
     }
   }
