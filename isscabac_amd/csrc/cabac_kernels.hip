@@ -80,9 +80,11 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 // waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
 // let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
 constexpr int waves_per_block(int cm) { return cm == 1 ? 4 : 1; }
-constexpr int kTabBytes = 768;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
-                                // encoder's --, [512,768) by (packed state, path) -- the decoder's
-constexpr int kTabBinOff = 256, kTabPathOff = 512;
+constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
+                                 // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
+                                 // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
+                                 // by packed state, the state's row and its two successors (by bin / by path)
+constexpr int kTabBinOff = 256, kTabPathOff = 512, kTabRowOff = 768;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -183,6 +185,16 @@ template <int K>
 struct BinOfWord {
   uint32_t w2;  // input word << 1
   uint32_t w;   // input word
+  uint32_t w8;  // input word << 3: byte k = 8 * bin k, what next_of shifts by (only the single-lookup step reads it)
+  // the successor for bin K out of the entry's high word (byte 0: bin 0, byte 1: bin 1); the store takes the low byte
+  __device__ __forceinline__ uint32_t next_of(uint32_t hi) const {
+    uint32_t r;
+    if (K == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else if (K == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else if (K == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    return r;
+  }
   __device__ __forceinline__ uint32_t or_q(uint32_t q) const {
     uint32_t r;
     if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w));
@@ -205,10 +217,10 @@ struct BinOfWord {
 template <class F>
 __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1, F &&f) {
   switch (k & 3) {
-    case 0: return f(BinOfWord<0>{w2, w1});
-    case 1: return f(BinOfWord<1>{w2, w1});
-    case 2: return f(BinOfWord<2>{w2, w1});
-    default: return f(BinOfWord<3>{w2, w1});
+    case 0: return f(BinOfWord<0>{w2, w1, 0u});
+    case 1: return f(BinOfWord<1>{w2, w1, 0u});
+    case 2: return f(BinOfWord<2>{w2, w1, 0u});
+    default: return f(BinOfWord<3>{w2, w1, 0u});
   }
 }
 
@@ -251,13 +263,12 @@ struct LdsStates {
   __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
   }
-  // lookups of the latency-oriented steps (cabac_lane.h: enc_bin_lat_acc / dec_bin_lat): everything by q alone
-  __device__ __forceinline__ uint32_t lps_row_mem(uint32_t q) const {  // the state's 4-byte rangeTabLps row
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(q & 0xFCu));
+  // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
+  __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + (q << 2)));
   }
-  __device__ __forceinline__ uint32_t next_lps_mem(uint32_t q) const { return next_path_mem(kTabPathOff + q); }
-  __device__ __forceinline__ uint32_t next_mps_mem(uint32_t q) const { return next_path_mem(kTabPathOff + 1u + q); }
   // state addresses as plain 32-bit LDS addresses (the latency-oriented paths compare them)
+  __device__ __forceinline__ uint32_t base32() const { return (uint32_t)(uintptr_t)(lds_u8 *)base; }
   __device__ __forceinline__ uint32_t addr32_of(const CtxQuad &z, int k) const { return (uint32_t)(uintptr_t)addr_of(z, k); }
   __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return *(const lds_u8 *)(uintptr_t)a; }
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t p) const { *(lds_u8 *)(uintptr_t)a = (uint8_t)p; }
@@ -292,6 +303,113 @@ struct SlotSink {
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
   __device__ __forceinline__ void close() {
     if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slots + (mine + (pos & ~15u))) = *reinterpret_cast<const uint4 *>(stage);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The latency-oriented encoder's state pass (k_encode<.., LAT, ..>), issued by hand.
+// In the encoder the context states evolve from the bins and contexts alone -- no range, no low -- so the state pass
+// (state -> successor -> state ...) and the arithmetic are two separate recurrences.  At one or two waves per SIMD the
+// state pass is an LDS round trip per bin that nothing hides unless the wave's own arithmetic sits in its shadow, and the
+// compiler's scheduler does not put it there (it issues the independent arithmetic BEFORE the lookup the chain waits
+// for).  So the LDS operations of the state pass and the wait for them are inline assembly in a fixed order:
+//   step j:  wait | successor(j-1) out of entry(j-1) (one byte, zero-padded: it may be the next table index)
+//            q(j) = same context ? successor(j-1) : state(j)
+//            read entry(j) by q(j) | store successor(j-1) | read state(j+1)
+//   then, in C++, the arithmetic of bin j - 1 (cabac_lane.h: enc_lat_arith) -- behind the reads, in front of the next wait.
+// entry = the 8 bytes of the single-lookup step (enc_bin_row_acc): the state's rangeTabLps row and its successors by bin.
+// A wave's LDS operations complete in order; the compiler's own LDS operations in between only make the waits here (all
+// lgkmcnt(0)) longer.  Registers with a read in flight (entry, qld) are named by nothing but the next step's assembly.
+// ------------------------------------------------------------------------------------------------
+struct EncLatPipe {
+  uint32_t at, at_prev;      // LDS address of the state of bin j / bin j - 1
+  uint64_t same;             // lane mask: bin j names the context of bin j - 1
+  uint32_t qld;              // state(j), read in flight
+  uint32_t q_prev;           // q(j - 1)
+  uint64_t ent_prev;         // entry(j - 1), read in flight
+  uint32_t q_done, row_done; // state and row of the bin whose arithmetic is due
+
+  __device__ __forceinline__ void start(uint32_t sb32, uint32_t z01) {
+    asm volatile(
+        "v_add_u32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+        "ds_read_u8 %1, %0"
+        : "=&v"(at), "=&v"(qld)
+        : "v"(sb32), "v"(z01)
+        : "memory");
+    at_prev = q_prev = q_done = row_done = 0;
+    same = 0;
+    ent_prev = 0;
+  }
+  // w8_prev: the word of bin j - 1, << 3 (byte k = 8 * bin k); zz_next: the CtxQuad half that holds bin j + 1
+  // dep: a value the arithmetic of bin j - 2 ends in (the range): keeps that arithmetic in front of this step's wait
+  template <int J>
+  __device__ __forceinline__ void step(uint32_t sb32, uint32_t w8_prev, uint32_t zz_next, uint32_t &dep) {
+    uint32_t q, nx = 0, t, at_next = 0, qld_next = 0;
+    uint64_t ent, same_next = 0;
+    // gfx950: a VALU result written with a destination select (the zero-padded successor byte) may not be read by the
+    // very next VALU instruction -- the address of the next state (or a no-op in the last step) sits in between
+    if (J == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   "v_add_u32_sdwa %2, %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                   : "+v"(qld), "+v"(dep), "=&v"(at_next)
+                   : "v"(sb32), "v"(zz_next)
+                   : "memory");
+      q = qld;
+    } else {
+#define ISSCABAC_LAT_HEAD(SEL, BETWEEN)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+               "v_lshrrev_b32_sdwa %0, %4, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD\n\t"     \
+               BETWEEN "\n\t"                                                                                               \
+               "v_cndmask_b32_e64 %1, %6, %0, %7"                                                                            \
+               : "=&v"(nx), "=&v"(q), "+v"(dep), "=&v"(at_next)                                                              \
+               : "v"(w8_prev), "v"((uint32_t)(ent_prev >> 32)), "v"(qld), "s"(same), "v"(sb32), "v"(zz_next)                 \
+               : "memory")
+#define ISSCABAC_LAT_AT0 "v_add_u32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+#define ISSCABAC_LAT_AT1 "v_add_u32_sdwa %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+      constexpr int kb = (J - 1) & 3;
+      if (J == 15) ISSCABAC_LAT_HEAD("BYTE_2", "s_nop 0");
+      else if (kb == 0) ISSCABAC_LAT_HEAD("BYTE_0", ISSCABAC_LAT_AT0);  // J = 1, 5, 9, 13: bin J + 1 is an even bin
+      else if (kb == 1) ISSCABAC_LAT_HEAD("BYTE_1", ISSCABAC_LAT_AT1);  // J = 2, 6, 10, 14
+      else if (kb == 2) ISSCABAC_LAT_HEAD("BYTE_2", ISSCABAC_LAT_AT0);  // J = 3, 7, 11
+      else ISSCABAC_LAT_HEAD("BYTE_3", ISSCABAC_LAT_AT1);               // J = 4, 8, 12
+#undef ISSCABAC_LAT_HEAD
+#undef ISSCABAC_LAT_AT0
+#undef ISSCABAC_LAT_AT1
+    }
+    asm volatile("v_lshlrev_b32_e32 %1, 2, %2\n\t"
+                 "ds_read_b64 %0, %1 offset:768"
+                 : "=&v"(ent), "=&v"(t)
+                 : "v"(q)
+                 : "memory");
+    static_assert(kTabRowOff == 768, "the offset in the assembly above");
+    if (J > 0) asm volatile("ds_write_b8 %0, %1" : : "v"(at_prev), "v"(nx) : "memory");
+    if (J < 15)
+      asm volatile("ds_read_u8 %0, %2\n\t"
+                   "v_cmp_eq_u32_e64 %1, %2, %3"
+                   : "=&v"(qld_next), "=&s"(same_next)
+                   : "v"(at_next), "v"(at)
+                   : "memory");
+    q_done = q_prev;
+    row_done = (uint32_t)ent_prev;  // complete: it came with the high word the head has just used
+    q_prev = q;
+    ent_prev = ent;
+    at_prev = at;
+    at = at_next;
+    qld = qld_next;
+    same = same_next;
+  }
+  // after step 15: the last successor goes to LDS, the last row is complete
+  __device__ __forceinline__ void finish(uint32_t w8_last, uint32_t &dep) {
+    uint32_t nx;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshrrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "ds_write_b8 %4, %0"
+        : "=&v"(nx), "+v"(dep)
+        : "v"(w8_last), "v"((uint32_t)(ent_prev >> 32)), "v"(at_prev)
+        : "memory");
+    q_done = q_prev;
+    row_done = (uint32_t)ent_prev;
   }
 };
 
@@ -339,6 +457,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
     tab[kTabBinOff / 4 + tid] = c_next.eb[tid];
+  }
+  for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by bin
+    tab[kTabRowOff / 4 + 2 * ps] = c_lps_rows[ps >> 1];
+    tab[kTabRowOff / 4 + 2 * ps + 1] = (c_next.eb[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
@@ -415,47 +537,39 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const bool full = i0 + 16 <= nmin;
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         if (LAT && full && !hi) {
-          // every lane codes 16 context bins.  The state of bin k + 1 is read before the successor of bin k is stored
-          // (after the store of bin k - 1: LDS operations of a wave complete in order) and replaced by that successor
-          // in a register when both bins name the same context
-          // The arithmetic of bin k - 1 runs between the lookups of bin k and the store that waits for them.
+          // every lane codes 16 context bins, the state pass issued by hand (EncLatPipe): the lookup of bin j goes out as
+          // soon as the successor of bin j - 1 is back, and the range / low arithmetic of bin j - 1 runs behind it
           EncWordAcc acc;
+          EncLatPipe p;
+          const uint32_t sb32 = stx.base32();
           CtxQuad z = stx.prep4(wc.x);
-          uint32_t at = stx.addr32_of(z, 0), at_prev = 0, nx_prev = 0;
-          uint32_t qld = stx.load_at(at);
-          uint32_t q_p = 0, row_p = 0;  // state and row of the bin whose arithmetic is still due
+          p.start(sb32, z.z01);
 #pragma unroll
           for (int k = 0; k < 16; k++) {
-            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-            const uint32_t q = (k > 0 && at == at_prev) ? nx_prev : qld;
-            uint32_t at_next = 0, row = 0;
-            if (k < 15) {
-              if ((k & 3) == 3) z = stx.prep4(word_of(wc, (k + 1) >> 2));
-              at_next = stx.addr32_of(z, (k + 1) & 3);
-              qld = stx.load_at(at_next);
+            if ((k & 3) == 3 && k < 15) z = stx.prep4(word_of(wc, (k + 1) >> 2));
+            const uint32_t zz = ((k + 1) & 2) ? z.z23 : z.z01;
+            const uint32_t w8p = k > 0 ? word_of(wb, (k - 1) >> 2) << 3 : 0u;
+            switch (k) {  // k is a constant once the loop is unrolled
+#define ISSCABAC_LAT_STEP(K) case K: p.template step<K>(sb32, w8p, zz, e.range); break;
+              ISSCABAC_LAT_STEP(0) ISSCABAC_LAT_STEP(1) ISSCABAC_LAT_STEP(2) ISSCABAC_LAT_STEP(3)
+              ISSCABAC_LAT_STEP(4) ISSCABAC_LAT_STEP(5) ISSCABAC_LAT_STEP(6) ISSCABAC_LAT_STEP(7)
+              ISSCABAC_LAT_STEP(8) ISSCABAC_LAT_STEP(9) ISSCABAC_LAT_STEP(10) ISSCABAC_LAT_STEP(11)
+              ISSCABAC_LAT_STEP(12) ISSCABAC_LAT_STEP(13) ISSCABAC_LAT_STEP(14) ISSCABAC_LAT_STEP(15)
+#undef ISSCABAC_LAT_STEP
             }
-            nx_prev = with_bin_of_word(k, w2, w1, [&](auto bin) { return enc_lat_lookup(bin, q, stx, row); });
             if (k > 0) {
               const uint32_t v1 = word_of(wb, (k - 1) >> 2), v2 = v1 << 1;
-              with_bin_of_word(k - 1, v2, v1, [&](auto bin) { enc_lat_arith(e, acc, ((k - 1) & 3) == 0, bin, q_p, row_p); return 0; });
+              with_bin_of_word(k - 1, v2, v1, [&](auto bin) { enc_lat_arith(e, acc, ((k - 1) & 3) == 0, bin, p.q_done, p.row_done); return 0; });
               if (((k - 1) & 3) == 3) {
                 enc_word_close(e, acc);
                 if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
               }
             }
-            // The store, and with it the wait for the lookups, has to stay BEHIND that arithmetic (the scheduler pulls it in
-            // front otherwise, and a sched_barrier makes the wait-count pass drain the counter at the barrier): it is
-            // issued by hand and names the arithmetic's results as inputs it does not use.  (A store the wait-count pass
-            // does not know about only makes its later counts conservative: LDS operations complete in order.)
-            asm volatile("ds_write_b8 %0, %1" ::"v"(at), "v"(nx_prev), "v"(e.range), "v"(acc.T) : "memory");
-            q_p = q;
-            row_p = row;
-            at_prev = at;
-            at = at_next;
           }
+          p.finish(wb.w << 3, e.range);
           {
             const uint32_t v1 = wb.w, v2 = v1 << 1;
-            enc_lat_arith(e, acc, false, BinOfWord<3>{v2, v1}, q_p, row_p);
+            enc_lat_arith(e, acc, false, BinOfWord<3>{v2, v1, 0u}, p.q_done, p.row_done);
             enc_word_close(e, acc);
             if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
           }
@@ -465,13 +579,13 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
-            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1, w8 = w1 << 3;
             // `low` takes the word's four additions at once (EncWordAcc): one 64-bit shift + add per word, not per bin
-            if ((k & 3) == 0) enc_bin_at_mem_acc(e, acc, true, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-            else if ((k & 3) == 1) enc_bin_at_mem_acc(e, acc, false, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-            else if ((k & 3) == 2) enc_bin_at_mem_acc(e, acc, false, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
+            if ((k & 3) == 0) enc_bin_row_acc(e, acc, true, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_row_acc(e, acc, false, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_row_acc(e, acc, false, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
             else {
-              enc_bin_at_mem_acc(e, acc, false, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+              enc_bin_row_acc(e, acc, false, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
               enc_word_close(e, acc);
             }
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
@@ -511,10 +625,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             if (full || i0 + k < n) {
               const uint32_t cb = byte_of(wc, k);
               if (is_ctx_byte<CM>(cb)) {
-                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1}, stx.addr_of(z, 0), stx);
-                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1}, stx.addr_of(z, 1), stx);
-                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1}, stx.addr_of(z, 2), stx);
-                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1}, stx.addr_of(z, 3), stx);
+                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1, 0u}, stx.addr_of(z, 0), stx);
+                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1, 0u}, stx.addr_of(z, 1), stx);
+                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1, 0u}, stx.addr_of(z, 2), stx);
+                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1, 0u}, stx.addr_of(z, 3), stx);
               } else if (cb == kBypass || cb == kProbBase + 50u) {
                 enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
               } else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase)) {
@@ -596,6 +710,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
     tab[kTabPathOff / 4 + tid] = c_next.ep[tid];
+  }
+  for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by path
+    tab[kTabRowOff / 4 + 2 * ps] = c_lps_rows[ps >> 1];
+    tab[kTabRowOff / 4 + 2 * ps + 1] = (c_next.ep[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;

@@ -303,18 +303,24 @@ CABAC_HD void enc_bin_at_mem(EncCore &e, Bin bin, Addr at, States &st) {
 struct EncWordAcc {
   uint32_t T, S;
 };
-// enc_bin_at_mem for one bin of an input word (first: the word's first bin): everything except `low` and W, which
-// enc_word_close updates
+// The encoder's step for one bin of an input word (first: the word's first bin) -- everything except `low` and W, which
+// enc_word_close updates -- on ONE table lookup: entry_mem(q) -> 64 bits by packed state (q >> 1): the state's 4-byte rangeTabLps row
+// in the low word, its two successors -- by bin value: byte 0 for a bin of 0, byte 1 for a bin of 1 -- in the high word.
+// Three LDS operations per bin instead of four (an 8-byte read costs the LDS pipe what a 1-byte read does, measured:
+// tools/ubench/lds_tp.hip), two round trips behind each other instead of three, and none of them inside the
+// range -> LPS -> range recurrence: the LPS column is picked from the row in a register (lps_of).
+// Bin policy: next_of(hi) -> the successor for this bin out of the high word, xor_q as before.
 template <class States, class Addr, class Bin>
-CABAC_HD void enc_bin_at_mem_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
+CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
-  st.store_at(at, st.next_mem(bin.or_q(q)));
+  const uint64_t ent = st.entry_mem(q);
+  st.store_at(at, bin.next_of((uint32_t)(ent >> 32)));
   const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
-  const uint32_t lps = st.lps_mem(q, e.range);
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   const uint32_t r = select_mask(m, lps, rmps);
   const uint32_t n = clz32(r) - 23u;
-  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;  // v_add_lshl_u32
+  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
   g.S = (first ? 0u : g.S) + n;
   e.range = r << n;
 }
@@ -347,24 +353,19 @@ CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, 
   e.range = r << n;
 }
 
-// Latency-oriented form of enc_bin_at_mem_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides
-// an LDS round trip, so none may sit on a bin-to-bin dependency chain).  The caller hands in the state q -- loaded one
-// bin ahead, with the previous bin's successor forwarded in a register when both bins use the same context -- and both
-// lookups depend on q only: the successor by (q, bin) and the state's whole 4-byte rangeTabLps row, whose column is
-// picked in a register (lps_of), so the range -> LPS -> range recurrence never touches memory.  Same arithmetic, same
-// results.  Returns the successor state (what the caller forwards).
-// States policy: lps_row_mem(q) -> the row, next_mem(q | bin), store_at.
-// ... in two halves, so that the caller can put the arithmetic of bin k - 1 between the lookups of bin k and the store that
-// has to wait for them (the arithmetic touches neither LDS nor the state chain):
-//   enc_lat_lookup  issues the two lookups of a bin, returns the successor (to store and to forward) and the row
+// Latency-oriented form of enc_bin_row_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides an
+// LDS round trip, so none may sit on a bin-to-bin dependency chain).  The caller hands in the state q -- loaded one bin
+// ahead, with the previous bin's successor forwarded in a register when both bins use the same context.  In two halves,
+// because the kernel issues the first by hand (cabac_kernels.hip: EncLatPipe) and runs the arithmetic of bin k - 1 behind
+// the lookup of bin k:
+//   enc_lat_lookup  the lookup of a bin: returns the successor (one clean byte: to store and to forward) and the row
 //   enc_lat_arith   range / low arithmetic of a bin from its state and row
+// Same arithmetic, same results.
 template <class States, class Bin>
 CABAC_HD uint32_t enc_lat_lookup(Bin bin, uint32_t q, States &st, uint32_t &row) {
-  // (opaque: the byte load's zero extension stays folded into the load although the value is both stored as a byte and
-  // selected against as a word)
-  const uint32_t nx = opaque(st.next_mem(bin.or_q(q)));
-  row = st.lps_row_mem(q);
-  return nx;
+  const uint64_t ent = st.entry_mem(q);
+  row = (uint32_t)ent;
+  return bin.next_of((uint32_t)(ent >> 32)) & 0xFFu;
 }
 template <class Bin>
 CABAC_HD void enc_lat_arith(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t q, uint32_t row) {
@@ -705,6 +706,47 @@ CABAC_HD uint32_t dec_bin_at_mem(DecCore &d, Addr at, States &st) {
   d.sh -= (int32_t)n;
   return idx;
 }
+// The same step on ONE table lookup (see enc_bin_row_acc): entry_mem(q) -> the state's rangeTabLps row in the low word and
+// its two successors by path in the high word (byte 0: LPS path, byte 1: MPS path).  The lookup depends on q alone, so
+// the range -> LPS -> range recurrence never touches memory.  Returns q + path like dec_bin_at_mem; nx receives the
+// successor (a clean byte: the latency-oriented instance forwards it as the next state).
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_row_q(DecCore &d, Addr at, uint32_t q, States &st, uint32_t &nx) {
+  const uint64_t ent = st.entry_mem(q);
+  const uint32_t lps = lps_of((uint32_t)ent, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the decision and everything it selects, on the borrow in VCC: the successor byte comes out of the entry with an
+  // SDWA source select (no shift), the value, the new range and the (mps, path) pair with one instruction each
+  uint32_t diff, r, idx;
+  asm("v_sub_co_u32_e32 %0, vcc, %4, %5\n\t"
+      "v_cndmask_b32_sdwa %1, %6, %6, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %7, %8, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %4, vcc\n\t"
+      "v_addc_co_u32_e32 %3, vcc, 0, %9, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r), "=&v"(idx)
+      : "v"(d.v), "v"(scaled), "v"((uint32_t)(ent >> 32)), "v"(lps), "v"(rmps), "v"(q)
+      : "vcc");
+  st.store_at(at, nx);
+  const uint32_t n = clz32(r) - 23u;
+  d.v = diff;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return idx;
+#else
+  uint32_t diff;
+  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
+  nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  st.store_at(at, nx);
+  const uint32_t r = mps_path ? rmps : lps;
+  const uint32_t n = clz32(r) - 23u;
+  d.v = mps_path ? d.v : diff;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return q + (uint32_t)mps_path;
+#endif
+}
 // The decoder's select-based step for chunks that mix context-coded and bypass bins (see enc_bin_mixed_acc): a bypass
 // bin compares the value with the whole range one bit further down (ref: CABAC_ArithmeticDecoder.cpp:288-331) and leaves
 // range and state alone.  Returns the (mps, path) pair of dec_bin_at_mem; a bypass bin reports mps 0, which makes
@@ -728,27 +770,12 @@ CABAC_HD uint32_t dec_bin_mixed(DecCore &d, uint32_t mb, Addr at, States &st) {
   return idx & ~(mb & 2u);
 }
 
-// Latency-oriented form of dec_bin_at_mem (see enc_bin_lat_acc): q comes from the caller (loaded one bin ahead, the
-// previous successor forwarded for a repeated context); the row and BOTH successors are fetched as soon as q is known,
-// so the decision needs no lookup behind it and the next bin's state is one select away.  nx receives the successor.
-// States policy: lps_row_mem(q), next_lps_mem(q), next_mps_mem(q), store_at.
+// Latency-oriented form (see enc_bin_lat_acc): q comes from the caller (loaded one bin ahead, the previous successor
+// forwarded for a repeated context); the single lookup by q brings the row and both successors, so the decision needs no
+// lookup behind it and the next bin's state is one select away.  nx receives the successor.
 template <class States, class Addr>
 CABAC_HD uint32_t dec_bin_lat(DecCore &d, Addr at, uint32_t q, States &st, uint32_t &nx) {
-  const uint32_t row = st.lps_row_mem(q);
-  const uint32_t nx_l = opaque(st.next_lps_mem(q)), nx_m = opaque(st.next_mps_mem(q));  // (see enc_lat_lookup)
-  const uint32_t lps = lps_of(row, d.range);
-  const uint32_t rmps = d.range - lps;
-  const uint32_t scaled = rmps << d.sh;
-  uint32_t diff;
-  const bool mps_path = __builtin_sub_overflow(d.v, scaled, &diff);
-  nx = mps_path ? nx_m : nx_l;
-  st.store_at(at, nx);
-  const uint32_t r = mps_path ? rmps : lps;
-  const uint32_t n = clz32(r) - 23u;
-  d.v = mps_path ? d.v : diff;
-  d.range = r << n;
-  d.sh -= (int32_t)n;
-  return q + (uint32_t)mps_path;  // low two bits = (mps, path), as dec_bin_at_mem returns them
+  return dec_bin_row_q(d, at, q, st, nx);
 }
 // collected (mps, path) pairs -> the collect_bin() format: bin = mps ^ !path at the odd bits, even bits 0
 CABAC_HD uint32_t pairs_to_bins(uint32_t acc) { return ~(acc ^ (acc << 1)) & 0xAAAAAAAAu; }

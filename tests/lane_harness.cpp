@@ -45,11 +45,13 @@ struct HostStates {
   // the byte tables of the kernels' fast paths (cabac_kernels.hip: LdsStates::lps_mem / next_mem / next_lps_mem)
   uint32_t lps_mem(uint32_t q, uint32_t range) const { return (kLpsRow[q >> 2] >> (8 * ((range >> 6) & 3u))) & 0xFFu; }
   uint32_t next_mem(uint32_t q_or_bin) const { return next_state_by_bin(q_or_bin >> 1, q_or_bin & 1u, kTransLps[q_or_bin >> 2]); }
-  // ... and of the latency-oriented instance (LdsStates::lps_row_mem / next_lps_mem / next_mps_mem)
-  uint32_t lps_row_mem(uint32_t q) const { return kLpsRow[q >> 2]; }
-  uint32_t next_lps_mem(uint32_t q) const { return next_path_mem(q); }
-  uint32_t next_mps_mem(uint32_t q) const { return next_path_mem(q + 1u); }
   uint32_t path_index(uint32_t q) const { return q; }
+  // ... and of the single-lookup steps (LdsStates::entry_mem): row | successors << 32, by bin (encoder) or by path (decoder)
+  bool by_path = false;
+  uint64_t entry_mem(uint32_t q) const {
+    const uint32_t b0 = by_path ? next_path_mem(q) : next_mem(q), b1 = by_path ? next_path_mem(q + 1u) : next_mem(q | 1u);
+    return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(b0 | b1 << 8) << 32;
+  }
   uint32_t next_path_mem(uint32_t q_plus_path) const {  // path 1 = MPS
     return (next_state_entry16(q_plus_path >> 1, kTransLps[q_plus_path >> 2]) >> (8 * (1u - (q_plus_path & 1u)))) & 0xFFu;
   }
@@ -58,6 +60,7 @@ struct HostBin {  // Bin policy of enc_bin_at_mem
   uint32_t bin;
   uint32_t xor_q(uint32_t q) const { return (bin << 1) ^ q; }
   uint32_t or_q(uint32_t q) const { return q | bin; }
+  uint32_t next_of(uint32_t hi) const { return hi >> (8 * bin); }  // the store takes the low byte
 };
 
 struct HostSink {
@@ -136,7 +139,8 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   // 19: the latency-oriented instance of that path: state read one bin ahead, successor forwarded for a repeated context
   const bool lat = flush_every == 19;
   if (lat) flush_every = 18;
-  // 18: the kernel's plain path -- an aligned word of four context bins adds to `low` once (EncWordAcc / enc_word_close)
+  // 18: the kernel's plain path -- an aligned word of four context bins adds to `low` once (EncWordAcc / enc_word_close),
+  //     each bin on the single-lookup step (enc_bin_row_acc)
   const bool wordacc = flush_every == 18;
   if (wordacc) flush_every = 17;
   const bool memtab = flush_every == 17;  // ... with the kernel's byte-table bin step (enc_bin_at_mem)
@@ -181,7 +185,7 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
           at = at_next;
         }
       } else {
-        for (int k = 0; k < 4; k++) enc_bin_at_mem_acc(e, acc, k == 0, HostBin{bins[i + k]}, st.addr(ctx[i + k]), st);
+        for (int k = 0; k < 4; k++) enc_bin_row_acc(e, acc, k == 0, HostBin{bins[i + k]}, st.addr(ctx[i + k]), st);
       }
       if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
       enc_word_close(e, acc);
@@ -248,6 +252,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   const int32_t min_sh = has_bypass ? 8 : 7;
   HostStates st;
   st.init(ctx_init, nctx);
+  st.by_path = true;
   uint32_t fast = 0, slow = 0, slow_refills = 0;
   // like the kernel: the window works from the 4-byte aligned address below the stream's first byte
   const uint64_t abase = start & ~3ull;
@@ -297,7 +302,7 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
         lat_have_prev = lat_have_qld;  // forwarding only ever pairs with a read-ahead value
       } else {
         lat_have_prev = lat_have_qld = false;
-        pairs = collect_bin(pairs, !is_ep(i) ? dec_bin_at_mem(d, st.addr(ctx[i]), st) : pair_of_bin(dec_bin_ep(d)));
+        pairs = collect_bin(pairs, is_ep(i) ? pair_of_bin(dec_bin_ep(d)) : dec_bin_at_mem(d, st.addr(ctx[i]), st));
       }
       if (i % 16 == 15 || i + 1 == n) {  // a chunk's worth: pairs -> bins -> bytes, like the kernel's store path
         const uint32_t done = i % 16 + 1;
