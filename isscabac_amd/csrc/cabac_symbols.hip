@@ -34,6 +34,14 @@ __device__ const SymNextTab y_next{};
 
 constexpr int kSymWaves = 4;
 constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
+// the code-tree kernels: 32 bytes of output staging and (encoder) a 32-byte ring of input symbols per lane, see SymPhase
+constexpr uint32_t kSymTrieStageBytes = 2048, kSymTrieRingBytes = 2048;
+// ... and a state image of the batch's own size (256 bytes per four contexts), so that config 4's 23 contexts leave room
+// for five workgroups on a CU
+__host__ __device__ constexpr uint32_t sym_trie_state_bytes(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
+__host__ __device__ constexpr uint32_t sym_trie_wave_bytes(uint32_t nctx) {
+  return sym_trie_state_bytes(nctx) + kSymTrieStageBytes + kSymTrieRingBytes;
+}
 // LDS of a workgroup: [0,256) rangeTabLps rows = [state][column] bytes, [256,512) next-state entries, [512,768) successor
 // bytes by (packed state, bin), [768,1024) by (packed state, path), then {bits, len | np << 8} per symbol value
 constexpr uint32_t kSymByBin = 512, kSymByPath = 768, kSymBinTab = 1024, kSymTab = 1024 + 256 * 8;
@@ -103,7 +111,7 @@ struct SymEncArgs {
 };
 
 __device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, uint8_t *&wbase, int tid,
-                                                uint32_t tab_bytes = kSymTab) {
+                                                uint32_t tab_bytes = kSymTab, uint32_t wave_bytes = kSymWaveBytes) {
   tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = y_lps_rows[tid];
@@ -112,7 +120,7 @@ __device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, u
     tab[192 + tid] = y_next.ep[tid];
   }
   __syncthreads();
-  wbase = smem + tab_bytes + (tid >> 6) * kSymWaveBytes;
+  wbase = smem + tab_bytes + (tid >> 6) * wave_bytes;
 }
 
 __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
@@ -355,6 +363,36 @@ __device__ __forceinline__ uint32_t trie_step(uint32_t node, uint32_t bin, uint3
   return *reinterpret_cast<const sym_lds_u16 *>((uintptr_t)(kSymTrieStep + ((node * 2u + bin) * kTrieUp + up) * 2u));
 }
 
+// Global memory in phases.  Every lane is somewhere else in its column (symbols binarise to different lengths), so a load or
+// store issued when a lane needs it lands in some lane's iteration nearly every time, and the wave's in-order vmcnt makes
+// everybody wait for it: the loop ran at the global-memory latency per bin.  The code-tree kernels touch global memory
+// only at phase boundaries, every kSymPhase iterations and wave-uniformly: a lane's next 16 symbols are requested one
+// phase before they are committed to its LDS ring (a lane takes at most one symbol per iteration: 32 bytes of ring and a
+// request at <= 16 symbols left never run dry), and finished 16-byte pieces of output leave at the boundary after they
+// were completed.  Whatever a boundary waits for was issued a phase ago.
+constexpr uint32_t kSymPhase = 8;
+
+// byte sink of the code-tree encoder: 32 bytes of LDS per lane, whole 16-byte pieces leave at phase boundaries
+struct SymPhaseSink {
+  uint8_t *stage, *slot;
+  uint32_t pos, out;  // bytes produced / bytes stored (a multiple of 16)
+  __device__ __forceinline__ void store_piece() {
+    *reinterpret_cast<uint4 *>(slot + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
+    out += 16;
+  }
+  __device__ __forceinline__ void put(uint32_t b) {
+    if (pos - out >= 32u) store_piece();  // a long run of buffered 0xFF bytes resolved at once: rare
+    stage[pos & 31u] = (uint8_t)b;
+    pos++;
+  }
+  __device__ __forceinline__ void boundary() {
+    if (pos - out >= 16u) store_piece();
+  }
+  __device__ __forceinline__ void close() {
+    while (out < pos) store_piece();  // (the slot is padded to whole pieces)
+  }
+};
+
 __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SymEncArgs &a = ta.a;
@@ -367,58 +405,76 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     bt[tid] = make_uint2(g.bits, g.len);
   }
   sym_trie_to_lds(smem, ta.trie, tid);
-  sym_init_common(smem, tab, wbase, tid, kSymTabTrie);
+  sym_init_common(smem, tab, wbase, tid, kSymTabTrie, sym_trie_wave_bytes(a.nctx));
+  const uint32_t sb = sym_trie_state_bytes(a.nctx);
   const uint2 *bintab = reinterpret_cast<const uint2 *>(smem + kSymBinTab);
   const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   SymStates st{wbase + lane * 4, tab};
-  if (!valid) return;
+  if (!valid) return;  // (the only cross-lane operations below are ballots over the lanes still here)
   const uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   const uint8_t *row_in = a.sym + s * a.pitch;
   EncCore e;
   enc_start(e);
-  SymSink sink{wbase + kSymStateBytes + lane * 16, a.slots + s * a.slot_stride, 0};
+  SymPhaseSink sink{wbase + sb + lane * 32, a.slots + s * a.slot_stride, 0, 0};
+  uint8_t *ring = wbase + sb + kSymTrieStageBytes + lane * 32;  // symbols [fill - 32, fill) of this column
+  const uint32_t n_pad = (n_my + 15u) & ~15u;  // rows are padded to whole 16-byte pieces (pitch)
+  uint32_t fill = 0;
+  uint4 piece = make_uint4(0, 0, 0, 0);
+  bool pending = false;
+  for (; fill < min(n_pad, 32u); fill += 16)
+    *reinterpret_cast<uint4 *>(ring + fill) = *reinterpret_cast<const uint4 *>(row_in + fill);
   uint32_t idx = 0, n = 1, node = 0, up = kTrieNoUp, row = 0, nbins = 0, bits = 0, len = 0, v = 0;
-  uint4 buf = make_uint4(0, 0, 0, 0);
   const uint32_t vmax = a.P.nq - 1;
   const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
   uint32_t c = c_top;
-  while (idx < n_my) {
-    if (n == 1) {
-      if ((idx & 15u) == 0) buf = *reinterpret_cast<const uint4 *>(row_in + idx);
-      const uint32_t wi = (idx >> 2) & 3u;
-      // (two levels of selects: the chained comparison form compiled to nested branches)
-      const uint32_t w_lo = (wi & 1u) ? buf.y : buf.x, w_hi = (wi & 1u) ? buf.w : buf.z;
-      const uint32_t word = (wi & 2u) ? w_hi : w_lo;
-      v = min((word >> (8 * (idx & 3u))) & 0xFFu, vmax);  // (values >= nq cannot be coded: they go out as nq - 1, like the general kernel)
-      const uint2 g = bintab[v];
-      bits = g.x;
-      len = g.y;
-      node = 0;
+  while (CABAC_WAVE_ANY(idx < n_my)) {
+    // phase boundary (wave-uniform): commit the piece requested a phase ago, request the next, let finished output go
+    if (pending) {
+      *reinterpret_cast<uint4 *>(ring + (fill & 16u)) = piece;
+      fill += 16;
+      pending = false;
     }
-    const uint32_t bin = (bits >> (n - 1)) & 1u;
-    const uint32_t step = trie_step(node, bin, up);  // does not wait for the coder: its latency hides behind the bin
-    enc_bin_at_mem(e, SymBin{bin}, st.addr(c), st);
-    if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);  // bytes are the same at any cadence, see k_encode_symbols
-    nbins++;
-    c = step >> 8;
-    if (n == len) {
-      idx++;
-      n = 1;
-      up = v;
-      row++;
-      if (row == a.P.col_rows) {  // first row of the next column: no symbol above (the demo selector keeps its predecessor)
-        row = 0;
-        if (a.P.selector != 0) {
-          up = kTrieNoUp;
-          c = c_top;
+    if (fill < n_pad && fill - idx <= 16u) {
+      piece = *reinterpret_cast<const uint4 *>(row_in + fill);
+      pending = true;
+    }
+    sink.boundary();
+#pragma unroll 1
+    for (uint32_t it = 0; it < kSymPhase; it++) {
+      if (idx < n_my) {
+        if (n == 1) {
+          v = min((uint32_t)ring[idx & 31u], vmax);  // (values >= nq cannot be coded: they go out as nq - 1, like the general kernel)
+          const uint2 g = bintab[v];
+          bits = g.x;
+          len = g.y;
+          node = 0;
+        }
+        const uint32_t bin = (bits >> (n - 1)) & 1u;
+        const uint32_t step = trie_step(node, bin, up);  // does not wait for the coder: its latency hides behind the bin
+        enc_bin_at_mem(e, SymBin{bin}, st.addr(c), st);
+        if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);  // bytes are the same at any cadence, see k_encode_symbols
+        nbins++;
+        c = step >> 8;
+        if (n == len) {
+          idx++;
+          n = 1;
+          up = v;
+          row++;
+          if (row == a.P.col_rows) {  // first row of the next column: no symbol above (the demo selector keeps its predecessor)
+            row = 0;
+            if (a.P.selector != 0) {
+              up = kTrieNoUp;
+              c = c_top;
+            }
+          }
+        } else {
+          node = step & 0xFFu;
+          n++;
         }
       }
-    } else {
-      node = step & 0xFFu;
-      n++;
     }
   }
   enc_finish(e, sink);
@@ -434,7 +490,8 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   uint32_t *tab;
   uint8_t *wbase;
   sym_trie_to_lds(smem, ta.trie, tid);
-  sym_init_common(smem, tab, wbase, tid, kSymTabTrie);
+  sym_init_common(smem, tab, wbase, tid, kSymTabTrie, sym_trie_wave_bytes(a.nctx));
+  const uint32_t sb = sym_trie_state_bytes(a.nctx);
   const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
@@ -458,16 +515,25 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   // decoder, see RefDec) and bin strings that are no code word of the alphabet -- corrupt input both
   bool handed_over = needs_ref_decoder(d.v >> 24);
   uint8_t *row_out = a.sym_out + s * a.pitch;
-  uint8_t *stage = wbase + kSymStateBytes + lane * 16;  // this lane's 16 bytes of output staging
-  uint32_t idx = 0, node = 0, up = kTrieNoUp, row = 0, it = 0;
+  uint8_t *stage = wbase + sb + lane * 32;  // this lane's 32 bytes of output staging (see kSymPhase)
+  uint32_t idx = 0, node = 0, up = kTrieNoUp, row = 0, it = 0, out = 0;  // out: symbols stored, a multiple of 16
   const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
   uint32_t c = c_top;
   const bool cols = a.P.col_rows != 0 && a.P.selector != 0;  // (uniform) the symbol above restarts with every column
   while (!handed_over && idx < n_my) {
     // every pass tops v up to sh = 23 for all lanes (one bin takes at most 6 bits): no per-lane refill branch.  The window
     // is re-based from the prefetched piece every 16 passes and, wave-uniformly, whenever a lane is short of a top-up
-    if ((it++ & 15u) == 0) src.boundary();
-    else src.ensure(24);
+    if ((it++ & 15u) == 0) {
+      src.boundary();
+      // finished 16-symbol pieces leave here, right behind the boundary's wait for the payload piece (vmcnt counts stores
+      // too, and in order: a store issued when a lane completes a piece would be waited for by everybody)
+      if (idx - out >= 16u) {
+        *reinterpret_cast<uint4 *>(row_out + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
+        out += 16;
+      }
+    } else {
+      src.ensure(24);
+    }
     dec_topup_nocheck(d, src);
     const uint32_t pair = dec_bin_at_mem(d, st.addr(c), st);  // bit 1 = mps, bit 0 = MPS path
     const uint32_t bin = ((pair >> 1) ^ ~pair) & 1u;
@@ -476,10 +542,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
     c = step >> 8;
     const bool leaf = (nx & 0x80u) != 0;  // end of a code word (or no code word at all: handed over below)
     const uint32_t v = nx & 0x7Fu;
-    if (leaf) {  // symbols leave 16 at a time: a byte store per symbol costs the memory pipe one transaction per lane and pass
-      stage[idx & 15u] = (uint8_t)v;
-      if ((idx & 15u) == 15u) *reinterpret_cast<uint4 *>(row_out + (idx & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
-    }
+    if (leaf) stage[idx & 31u] = (uint8_t)v;  // (a lane finishes at most one symbol per pass, 16 per boundary)
     handed_over = nx == kTrieNone;
     idx += leaf ? 1u : 0u;
     node = leaf ? 0u : nx;
@@ -497,11 +560,9 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
     *a.redo_any = 1u;
     return;
   }
-  // the last, incomplete group of 16 and the symbols the stream does not have: zeros (rows are padded to a multiple of 16)
-  if (n_my & 15u) {
-    for (uint32_t i = n_my & 15u; i < 16u; i++) stage[i] = 0;
-    *reinterpret_cast<uint4 *>(row_out + (n_my & ~15u)) = *reinterpret_cast<const uint4 *>(stage);
-  }
+  // what is still staged, the last, incomplete group of 16 padded with zeros (rows are padded to a multiple of 16)
+  for (uint32_t i = n_my; i < ((n_my + 15u) & ~15u); i++) stage[i & 31u] = 0;
+  for (; out < n_my; out += 16) *reinterpret_cast<uint4 *>(row_out + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
   for (uint32_t i = (n_my + 15u) & ~15u; i < a.nsym; i++) row_out[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
@@ -798,7 +859,7 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   if (!d_stats && sym_use_trie(a.P, &ta.trie)) {
     ta.a = a;
     if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie)))) return rc;
-    hipLaunchKernelGGL(k_encode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * kSymWaveBytes, e->stream, ta);
+    hipLaunchKernelGGL(k_encode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * sym_trie_wave_bytes(a.nctx), e->stream, ta);
   } else {
     if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
     hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), kSymTab + kSymWaves * kSymWaveBytes, e->stream, a);
@@ -853,7 +914,7 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
     a.redo_any = e->flag;
     ta.a = a;
     if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie)))) return rc;
-    hipLaunchKernelGGL(k_decode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * kSymWaveBytes, e->stream, ta);
+    hipLaunchKernelGGL(k_decode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * sym_trie_wave_bytes(a.nctx), e->stream, ta);
     HIP_TRY(e, hipGetLastError());
   }
   if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols)))) return rc;
