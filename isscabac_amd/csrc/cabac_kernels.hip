@@ -203,6 +203,7 @@ struct BinOfWord {
     else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w));
     return r;
   }
+  __device__ __forceinline__ uint32_t lps_mask(uint32_t q) const { return mask_from_bit1(xor_q(q)); }
   __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
     uint32_t r;
     if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));

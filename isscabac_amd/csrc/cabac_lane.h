@@ -309,13 +309,13 @@ struct EncWordAcc {
 // Three LDS operations per bin instead of four (an 8-byte read costs the LDS pipe what a 1-byte read does, measured:
 // tools/ubench/lds_tp.hip), two round trips behind each other instead of three, and none of them inside the
 // range -> LPS -> range recurrence: the LPS column is picked from the row in a register (lps_of).
-// Bin policy: next_of(hi) -> the successor for this bin out of the high word, xor_q as before.
+// Bin policy: next_of(hi) -> the successor for this bin out of the high word, lps_mask(q) -> ~0 if the bin is not q's mps.
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
   const uint64_t ent = st.entry_mem(q);
   st.store_at(at, bin.next_of((uint32_t)(ent >> 32)));
-  const uint32_t m = mask_from_bit1(bin.xor_q(q));  // ~0: bin != mps
+  const uint32_t m = bin.lps_mask(q);  // ~0: bin != mps
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   const uint32_t r = select_mask(m, lps, rmps);

@@ -187,7 +187,7 @@ inline bool sym_trie_build(const SymParams &P, SymTrie *T) {
   T->nodes = 1;
   for (uint32_t v = 0; v < P.nq; v++) {
     const BinString g = binarize(v, P);
-    if (g.len == 0 || g.len > 32) return false;
+    if (g.len == 0 || g.len > 29) return false;  // (the encoder keeps a bin string << 3 in 32 bits)
     uint32_t node = 0;
     for (uint32_t n = 1; n <= g.len; n++) {
       const uint32_t bit = (g.bits >> (n - 1)) & 1u;

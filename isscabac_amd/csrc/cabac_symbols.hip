@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "cabac_internal.h"
 #include "cabac_lane.h"
@@ -34,24 +35,36 @@ __device__ const SymNextTab y_next{};
 
 constexpr int kSymWaves = 4;
 constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
-// the code-tree kernels: 32 bytes of output staging and (encoder) a 32-byte ring of input symbols per lane, see SymPhase
-constexpr uint32_t kSymTrieStageBytes = 2048, kSymTrieRingBytes = 2048;
-// ... and a state image of the batch's own size (256 bytes per four contexts), so that config 4's 23 contexts leave room
-// for five workgroups on a CU
-__host__ __device__ constexpr uint32_t sym_trie_state_bytes(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
-__host__ __device__ constexpr uint32_t sym_trie_wave_bytes(uint32_t nctx) {
-  return sym_trie_state_bytes(nctx) + kSymTrieStageBytes + kSymTrieRingBytes;
+// the code-tree kernels: 32 bytes of output staging and (encoder) a 32-byte ring of input symbols per lane (see kSymPhase),
+// and a state image of the batch's own size (256 bytes per four contexts): config 4's 23 contexts leave room for six
+// workgroups on a CU
+constexpr uint32_t kWalkStageBytes = 2048, kWalkRingBytes = 2048;
+__host__ __device__ constexpr uint32_t sym_walk_state_bytes(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
+__host__ __device__ constexpr uint32_t sym_walk_wave_bytes(uint32_t nctx, bool encoder) {
+  return sym_walk_state_bytes(nctx) + kWalkStageBytes + (encoder ? kWalkRingBytes : 0u);
 }
 // LDS of a workgroup: [0,256) rangeTabLps rows = [state][column] bytes, [256,512) next-state entries, [512,768) successor
 // bytes by (packed state, bin), [768,1024) by (packed state, path), then {bits, len | np << 8} per symbol value
 constexpr uint32_t kSymByBin = 512, kSymByPath = 768, kSymBinTab = 1024, kSymTab = 1024 + 256 * 8;
 constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
-// the code-tree kernels (cabac_symbols.h: SymTrie) keep the tree behind the binarisation table
-// ... and, made from it in the kernel, the table the loop actually reads: for (node, bin, symbol above) the 16-bit pair
-// {where the walk goes (SymTrie::child), context of the bin coded there} -- one LDS round trip per bin instead of two in a row
-constexpr uint32_t kSymTrieChild = kSymTab, kSymTrieCtx = kSymTab + kTrieNodes * 2;
-constexpr uint32_t kSymTrieStep = (kSymTrieCtx + kTrieNodes * kTrieUp + 15u) & ~15u;
-constexpr uint32_t kSymTabTrie = (kSymTrieStep + kTrieNodes * 2 * kTrieUp * 2 + 255u) & ~255u;
+// LDS of a workgroup of the code-tree kernels (cabac_symbols.h: SymTrie), read by absolute address:
+//   [0, 1024)     the single-lookup step's 8-byte entries by packed state (cabac_lane.h: enc_bin_row_acc / dec_bin_row_q)
+//   [1024, 2048)  per symbol byte: its bin string << 3 (encoder: the bin in turn sits at bit 3, where it is 8 * bin)
+//   [2048, ...)   the walk table: one dword per (node, slot, symbol above) at node * stride + slot * 128 + up * 4; the
+//                 encoder's slot is the bin (stride 256), the decoder's the (mps, path) pair its bin step returns (stride
+//                 512: no instruction turns the pair into the bin) --
+//                 bits 0..13  where the walk stands after this bin: (child node, same symbol above), or after a code word's
+//                             last bin (root, the symbol just finished above)
+//                 bit 14      no code word goes on here (corrupt stream: the general kernel decodes it again)
+//                 bit 15      the bin ended a code word, bits 28..31 its symbol
+//                 bits 16..27 LDS offset of the context state the NEXT bin is coded with
+//   so that per bin the walk, the context selection and the end-of-symbol test are one LDS read and a few bit operations.
+constexpr uint32_t kWalkBits = 1024, kWalkTab = 2048, kWalkSlot = 128, kWalkMaxNodes = 32;
+constexpr uint32_t kWalkNextMask = 0x3FFFu, kWalkBadBit = 14, kWalkLeafBit = 15, kWalkOffShift = 16, kWalkOffBits = 12, kWalkSymShift = 28;
+__host__ __device__ constexpr uint32_t walk_node_stride(bool encoder) { return encoder ? 2 * kWalkSlot : 4 * kWalkSlot; }
+__host__ __device__ constexpr uint32_t sym_walk_tab_bytes(uint32_t nodes, bool encoder) { return kWalkTab + nodes * walk_node_stride(encoder); }
+static_assert(kWalkSlot == (8u << 4) && kWalkSlot == (1u << 7) && kTrieUp * 4 <= kWalkSlot, "the shifts in the kernels");
+static_assert(kWalkMaxNodes * 4 * kWalkSlot <= kWalkNextMask + 1u, "walk positions are 14 bits");
 
 // states in LDS (same conflict-free layout as the bin kernels), tables in LDS memory (lanes finish at different times)
 struct SymStates {
@@ -320,9 +333,9 @@ __global__ void __launch_bounds__(256) k_decode_symbols(SymDecArgs a) {
   }
 }
 
-// ---- the same two kernels on the code tree (SymTrie): binarisation walk and context selection are two byte look-ups per
-// bin instead of ~100 VALU of per-lane string handling.  Small alphabets only (nq <= 16: every reference configuration);
-// no statistics (they want the reference's write-out cadence, see k_encode_symbols).
+// ---- the same two kernels on the code tree (SymTrie): walk, context selection and end-of-symbol test are one table read
+// per bin instead of ~100 VALU of per-lane string handling.  Small alphabets only (nq <= 16: every reference
+// configuration); no statistics (they want the reference's write-out cadence, see k_encode_symbols).
 struct SymTrieEncArgs {
   SymEncArgs a;
   SymTrie trie;
@@ -331,59 +344,101 @@ struct SymTrieDecArgs {
   SymDecArgs a;
   SymTrie trie;
 };
-// (all 256 threads; ends with a barrier)
-__device__ __forceinline__ void sym_trie_to_lds(uint8_t *smem, const SymTrie &T, int tid) {
-  for (uint32_t i = tid; i < kTrieNodes * 2; i += 256) smem[kSymTrieChild + i] = T.child[i];
-  for (uint32_t i = tid; i < kTrieNodes * kTrieUp; i += 256) smem[kSymTrieCtx + i] = T.ctx[i];
-  __syncthreads();
-  // step[(node * 2 + bin) * kTrieUp + up] = child | ctx of the next bin << 8.  After an inner node that is the child's
-  // context under the same symbol above; after a leaf it is the root's context with the symbol just finished above.
-  uint16_t *step = reinterpret_cast<uint16_t *>(smem + kSymTrieStep);
-  for (uint32_t i = tid; i < kTrieNodes * 2 * kTrieUp; i += 256) {
-    const uint32_t nb = i / kTrieUp, up = i - nb * kTrieUp;
-    const uint32_t nx = smem[kSymTrieChild + nb];
-    const uint32_t v = nx & 0x7Fu;
-    uint32_t c = 0;
-    if (nx == kTrieNone) c = 0;
-    else if (nx & 0x80u) c = v < kTrieUp ? smem[kSymTrieCtx + v] : 0;  // root is node 0
-    else c = smem[kSymTrieCtx + nx * kTrieUp + up];
-    step[i] = (uint16_t)(nx | (c << 8));
+__device__ __forceinline__ uint32_t walk_state_off(uint32_t c) { return ((c & ~3u) << 6) | (c & 3u); }
+// (all 256 threads; the caller's barrier follows)
+template <bool ENC>
+__device__ __forceinline__ void sym_walk_to_lds(uint8_t *smem, const SymTrie &T, int tid) {
+  uint32_t *wt = reinterpret_cast<uint32_t *>(smem + kWalkTab);
+  constexpr uint32_t stride = walk_node_stride(ENC), per_node = stride / 4;
+  for (uint32_t i = tid; i < T.nodes * per_node; i += 256) {
+    const uint32_t node = i / per_node, slot = (i / 32u) % (per_node / 32u), up = i & 31u;
+    // the decoder's slot is (mps << 1 | path): bin = mps on the MPS path, !mps on the LPS path
+    const uint32_t bin = ENC ? slot : ((slot >> 1) ^ (slot & 1u) ^ 1u);
+    uint32_t E = (1u << kWalkBadBit) | (node * stride + min(up, kTrieNoUp) * 4u);  // stays where it is
+    const uint32_t nx = T.child[node * 2 + bin];
+    if (up < kTrieUp && nx != kTrieNone) {
+      const uint32_t leaf = nx >> 7, v = nx & 0x7Fu;
+      // the next bin: under the same symbol above inside a code word, at the root under the symbol just finished after one
+      const uint32_t c = leaf ? (v < kTrieUp ? T.ctx[v] : 0u) : T.ctx[nx * kTrieUp + up];
+      const uint32_t next = leaf ? min(v, kTrieNoUp) * 4u : nx * stride + up * 4u;
+      E = next | (leaf << kWalkLeafBit) | (walk_state_off(c) << kWalkOffShift) | (leaf ? (v & 15u) << kWalkSymShift : 0u);
+    }
+    wt[i] = E;
   }
-  __syncthreads();
 }
 typedef __attribute__((address_space(3))) uint8_t sym_lds_u8;
-__device__ __forceinline__ uint32_t trie_ctx(uint32_t node, uint32_t up) {
-  return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)(kSymTrieCtx + node * kTrieUp + up));
-}
-__device__ __forceinline__ uint32_t trie_child(uint32_t node, uint32_t bin) {
-  return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)(kSymTrieChild + node * 2u + bin));
-}
-typedef __attribute__((address_space(3))) uint16_t sym_lds_u16;
-__device__ __forceinline__ uint32_t trie_step(uint32_t node, uint32_t bin, uint32_t up) {
-  return *reinterpret_cast<const sym_lds_u16 *>((uintptr_t)(kSymTrieStep + ((node * 2u + bin) * kTrieUp + up) * 2u));
-}
+typedef __attribute__((address_space(3))) uint32_t sym_lds_u32;
+typedef __attribute__((address_space(3))) uint64_t sym_lds_u64;
+__device__ __forceinline__ uint32_t walk_entry(uint32_t wa) { return *reinterpret_cast<const sym_lds_u32 *>((uintptr_t)(kWalkTab + wa)); }
+
+// context states of the code-tree kernels: addresses are 32-bit LDS addresses, the coder's tables the 8-byte entries at 0
+struct WalkStates {
+  __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)a); }
+  __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)a) = (uint8_t)q; }
+  __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(q << 2)); }
+};
+// Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where the mps of q << 2 -- the entry's
+// address -- sits too
+struct WalkBin {
+  uint32_t bits8, b8;  // b8 = bits8 & 8
+  __device__ __forceinline__ uint32_t lps_mask(uint32_t q) const { return (uint32_t)__builtin_amdgcn_sbfe((q << 2) ^ bits8, 3, 1); }
+  __device__ __forceinline__ uint32_t next_of(uint32_t hi) const { return hi >> b8; }
+};
+
+// 32 bytes per lane in 2 KiB of a wave's LDS, laid out like the context states: byte k of lane l at
+// (k / 4) * 256 + l * 4 + k % 4, so that whatever k each of the 64 lanes is at, lane l only touches bank l % 32.  (Lane-major
+// -- l * 32 + k -- puts sixteen lanes on every bank: the symbol ring read and the symbol store of every bin then cost the
+// LDS pipe sixteen passes each.)
+struct LaneBytes32 {
+  uint32_t base;  // LDS address of the region + lane * 4
+  __device__ __forceinline__ uint32_t addr(uint32_t k) const { return base + (((k << 6) & 0x700u) | (k & 3u)); }
+  __device__ __forceinline__ uint32_t get(uint32_t k) const { return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)addr(k)); }
+  __device__ __forceinline__ void put(uint32_t k, uint32_t b) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)addr(k)) = (uint8_t)b; }
+  // bytes k, k + 1 (k even): they share a dword
+  __device__ __forceinline__ void put16(uint32_t k, uint32_t x) const {
+    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)addr(k)) = (uint16_t)x;
+  }
+  // bytes 16 h .. 16 h + 15 (h = 0, 1)
+  __device__ __forceinline__ uint4 piece(uint32_t h) const {
+    const sym_lds_u32 *p = reinterpret_cast<const sym_lds_u32 *>((uintptr_t)(base + h * 1024u));
+    return make_uint4(p[0], p[64], p[128], p[192]);
+  }
+  __device__ __forceinline__ void put_piece(uint32_t h, uint4 v) const {
+    sym_lds_u32 *p = reinterpret_cast<sym_lds_u32 *>((uintptr_t)(base + h * 1024u));
+    p[0] = v.x;
+    p[64] = v.y;
+    p[128] = v.z;
+    p[192] = v.w;
+  }
+};
 
 // Global memory in phases.  Every lane is somewhere else in its column (symbols binarise to different lengths), so a load or
 // store issued when a lane needs it lands in some lane's iteration nearly every time, and the wave's in-order vmcnt makes
-// everybody wait for it: the loop ran at the global-memory latency per bin.  The code-tree kernels touch global memory
-// only at phase boundaries, every kSymPhase iterations and wave-uniformly: a lane's next 16 symbols are requested one
-// phase before they are committed to its LDS ring (a lane takes at most one symbol per iteration: 32 bytes of ring and a
-// request at <= 16 symbols left never run dry), and finished 16-byte pieces of output leave at the boundary after they
-// were completed.  Whatever a boundary waits for was issued a phase ago.
-constexpr uint32_t kSymPhase = 8;
+// everybody wait for it.  The code-tree kernels touch global memory only at phase boundaries, wave-uniformly: a lane's
+// next 16 symbols are requested one phase before they are committed to its LDS ring (a lane takes at most one symbol per
+// bin: 32 bytes of ring and a request at <= 16 symbols left never run dry, and the symbol after the current one is always
+// there to be looked at), and finished 16-byte pieces of output leave at the boundary after they were completed.
+constexpr uint32_t kSymPhase = 8;  // bins per lane between two boundaries of the encoder (the decoder: 16, its window's chunk)
 
 // byte sink of the code-tree encoder: 32 bytes of LDS per lane, whole 16-byte pieces leave at phase boundaries
 struct SymPhaseSink {
-  uint8_t *stage, *slot;
+  LaneBytes32 stage;
+  uint8_t *slot;
   uint32_t pos, out;  // bytes produced / bytes stored (a multiple of 16)
   __device__ __forceinline__ void store_piece() {
-    *reinterpret_cast<uint4 *>(slot + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
+    *reinterpret_cast<uint4 *>(slot + out) = stage.piece((out >> 4) & 1u);
     out += 16;
   }
   __device__ __forceinline__ void put(uint32_t b) {
-    if (pos - out >= 32u) store_piece();  // a long run of buffered 0xFF bytes resolved at once: rare
-    stage[pos & 31u] = (uint8_t)b;
+    if (pos - out >= 32u) store_piece();  // a long run of pending 0xFF bytes resolved at once: rare
+    stage.put(pos & 31u, b);
     pos++;
+  }
+  // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
+  __device__ __forceinline__ void put16(uint32_t x) {
+    if (pos - out >= 32u) store_piece();
+    stage.put16(pos & 31u, __builtin_amdgcn_perm(x, x, 0x0C0C0001u));
+    pos += 2;
   }
   __device__ __forceinline__ void boundary() {
     if (pos - out >= 16u) store_piece();
@@ -393,47 +448,76 @@ struct SymPhaseSink {
   }
 };
 
+template <bool COLS>  // the symbol above restarts with every column (ISS selector with col_rows set)
 __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SymEncArgs &a = ta.a;
   const int tid = threadIdx.x, lane = tid & 63;
-  uint32_t *tab;
-  uint8_t *wbase;
   {
-    uint2 *bt = reinterpret_cast<uint2 *>(smem + kSymBinTab);
-    const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);
-    bt[tid] = make_uint2(g.bits, g.len);
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    if (tid < 128) {  // packed state: its row, its successors by bin
+      tab[2 * tid] = y_lps_rows[tid >> 1];
+      tab[2 * tid + 1] = (y_next.eb[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+    }
+    const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);  // (values >= nq cannot be coded: they go out as nq - 1)
+    reinterpret_cast<uint32_t *>(smem + kWalkBits)[tid] = g.bits << 3;  // (at most 29 bins: sym_trie_build)
+    sym_walk_to_lds<true>(smem, ta.trie, tid);
   }
-  sym_trie_to_lds(smem, ta.trie, tid);
-  sym_init_common(smem, tab, wbase, tid, kSymTabTrie, sym_trie_wave_bytes(a.nctx));
-  const uint32_t sb = sym_trie_state_bytes(a.nctx);
-  const uint2 *bintab = reinterpret_cast<const uint2 *>(smem + kSymBinTab);
+  __syncthreads();
+  const uint32_t sb = sym_walk_state_bytes(a.nctx);
+  uint8_t *wbase = smem + sym_walk_tab_bytes(ta.trie.nodes, true) + (tid >> 6) * sym_walk_wave_bytes(a.nctx, true);
   const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
-  SymStates st{wbase + lane * 4, tab};
   if (!valid) return;  // (the only cross-lane operations below are ballots over the lanes still here)
   const uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   const uint8_t *row_in = a.sym + s * a.pitch;
+  WalkStates st;
+  const uint32_t sbase = (uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + lane * 4);  // this lane's states
   EncCore e;
   enc_start(e);
-  SymPhaseSink sink{wbase + sb + lane * 32, a.slots + s * a.slot_stride, 0, 0};
-  uint8_t *ring = wbase + sb + kSymTrieStageBytes + lane * 32;  // symbols [fill - 32, fill) of this column
+  SymPhaseSink sink{LaneBytes32{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + lane * 4)}, a.slots + s * a.slot_stride, 0, 0};
+  const LaneBytes32 ring{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + kWalkStageBytes + lane * 4)};  // symbols [fill - 32, fill) of this column
   const uint32_t n_pad = (n_my + 15u) & ~15u;  // rows are padded to whole 16-byte pieces (pitch)
   uint32_t fill = 0;
   uint4 piece = make_uint4(0, 0, 0, 0);
   bool pending = false;
   for (; fill < min(n_pad, 32u); fill += 16)
-    *reinterpret_cast<uint4 *>(ring + fill) = *reinterpret_cast<const uint4 *>(row_in + fill);
-  uint32_t idx = 0, n = 1, node = 0, up = kTrieNoUp, row = 0, nbins = 0, bits = 0, len = 0, v = 0;
-  const uint32_t vmax = a.P.nq - 1;
-  const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
-  uint32_t c = c_top;
+    ring.put_piece(fill >> 4, *reinterpret_cast<const uint4 *>(row_in + fill));
+  const sym_lds_u32 *bt8 = reinterpret_cast<const sym_lds_u32 *>((uintptr_t)kWalkBits);
+  const uint32_t wa_top = kTrieNoUp * 4u;                                      // the root, no symbol above
+  const uint32_t sa_top = sbase + walk_state_off(ta.trie.ctx[kTrieNoUp]);       // ... and the context of its bin
+  uint32_t idx = 0, wa = wa_top, sa = sa_top, row = 0, nbins = 0;
+  uint32_t bits8 = n_my ? bt8[ring.get(0)] : 0u;
+  // one bin of this lane's current symbol; guarded: the lane may have run out of symbols
+  auto one_bin = [&](EncWordAcc &acc, auto guarded) {
+    if (decltype(guarded)::value) {
+      if (idx >= n_my) return;
+      nbins++;
+    }
+    // the next symbol's string: wanted if this bin ends the current one
+    const uint32_t nb8 = bt8[ring.get(idx + 1u)];
+    const uint32_t b8 = opaque(bits8 & 8u);                  // 8 * bin (opaque: stays one AND, shared by both uses)
+    const uint32_t E = walk_entry(wa + (b8 << 4));           // (kWalkSlot = 8 << 4)
+    enc_bin_row_acc(e, acc, false, WalkBin{bits8, b8}, sa, st);
+    const uint32_t lastm = (uint32_t)__builtin_amdgcn_sbfe(E, kWalkLeafBit, 1);  // ~0: the symbol's last bin
+    bits8 = select_mask(lastm, nb8, bits8 >> 1);
+    idx -= lastm;
+    wa = E & kWalkNextMask;
+    sa = sbase + ((E >> kWalkOffShift) & ((1u << kWalkOffBits) - 1u));
+    if (COLS) {
+      row -= lastm;
+      const bool top = row == a.P.col_rows;  // (only ever true right after a last bin)
+      row = top ? 0u : row;
+      wa = top ? wa_top : wa;
+      sa = top ? sa_top : sa;
+    }
+  };
   while (CABAC_WAVE_ANY(idx < n_my)) {
     // phase boundary (wave-uniform): commit the piece requested a phase ago, request the next, let finished output go
     if (pending) {
-      *reinterpret_cast<uint4 *>(ring + (fill & 16u)) = piece;
+      ring.put_piece((fill >> 4) & 1u, piece);
       fill += 16;
       pending = false;
     }
@@ -442,62 +526,52 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
       pending = true;
     }
     sink.boundary();
-#pragma unroll 1
-    for (uint32_t it = 0; it < kSymPhase; it++) {
-      if (idx < n_my) {
-        if (n == 1) {
-          v = min((uint32_t)ring[idx & 31u], vmax);  // (values >= nq cannot be coded: they go out as nq - 1, like the general kernel)
-          const uint2 g = bintab[v];
-          bits = g.x;
-          len = g.y;
-          node = 0;
-        }
-        const uint32_t bin = (bits >> (n - 1)) & 1u;
-        const uint32_t step = trie_step(node, bin, up);  // does not wait for the coder: its latency hides behind the bin
-        enc_bin_at_mem(e, SymBin{bin}, st.addr(c), st);
-        if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);  // bytes are the same at any cadence, see k_encode_symbols
-        nbins++;
-        c = step >> 8;
-        if (n == len) {
-          idx++;
-          n = 1;
-          up = v;
-          row++;
-          if (row == a.P.col_rows) {  // first row of the next column: no symbol above (the demo selector keeps its predecessor)
-            row = 0;
-            if (a.P.selector != 0) {
-              up = kTrieNoUp;
-              c = c_top;
-            }
-          }
-        } else {
-          node = step & 0xFFu;
-          n++;
-        }
+    // while every lane has more symbols left than a phase can take, nobody needs a guard
+    const bool tail = CABAC_WAVE_ANY(idx + kSymPhase > n_my);
+#pragma unroll
+    for (uint32_t g = 0; g < kSymPhase / 4; g++) {
+      EncWordAcc acc{0u, 0u};
+      if (!tail) {
+        nbins += 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) one_bin(acc, std::false_type{});
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) one_bin(acc, std::true_type{});
       }
+      enc_word_close(e, acc);
+      if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush16_wave(e, sink);  // bytes are the same at any cadence
     }
   }
-  enc_finish(e, sink);
+  enc_finish16(e, sink);
   sink.close();
   a.lens[s] = sink.pos;
   if (a.nbins_out) a.nbins_out[s] = nbins;
 }
 
+template <bool COLS>
 __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SymDecArgs &a = ta.a;
   const int tid = threadIdx.x, lane = tid & 63;
-  uint32_t *tab;
-  uint8_t *wbase;
-  sym_trie_to_lds(smem, ta.trie, tid);
-  sym_init_common(smem, tab, wbase, tid, kSymTabTrie, sym_trie_wave_bytes(a.nctx));
-  const uint32_t sb = sym_trie_state_bytes(a.nctx);
+  {
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    if (tid < 128) {  // packed state: its row, its successors by path
+      tab[2 * tid] = y_lps_rows[tid >> 1];
+      tab[2 * tid + 1] = (y_next.ep[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+    }
+    sym_walk_to_lds<false>(smem, ta.trie, tid);
+  }
+  __syncthreads();
+  const uint32_t sb = sym_walk_state_bytes(a.nctx);
+  uint8_t *wbase = smem + sym_walk_tab_bytes(ta.trie.nodes, false) + (tid >> 6) * sym_walk_wave_bytes(a.nctx, false);
   const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
-  SymStates st{wbase + lane * 4, tab};
   if (!valid) return;
+  WalkStates st;
+  const uint32_t sbase = (uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + lane * 4);  // this lane's states
   const uint32_t n_my = a.nsym_per_stream ? min(a.nsym_per_stream[s], a.nsym) : a.nsym;
   uint64_t start = a.offsets[s];
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
@@ -513,56 +587,73 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   dec_start(d, src);
   // streams this kernel does not finish go to the general kernel behind it: a first byte of 0xFF (reference-formulation
   // decoder, see RefDec) and bin strings that are no code word of the alphabet -- corrupt input both
-  bool handed_over = needs_ref_decoder(d.v >> 24);
+  uint32_t bad = needs_ref_decoder(d.v >> 24) ? (1u << kWalkBadBit) : 0u;
   uint8_t *row_out = a.sym_out + s * a.pitch;
-  uint8_t *stage = wbase + sb + lane * 32;  // this lane's 32 bytes of output staging (see kSymPhase)
-  uint32_t idx = 0, node = 0, up = kTrieNoUp, row = 0, it = 0, out = 0;  // out: symbols stored, a multiple of 16
-  const uint32_t c_top = trie_ctx(0, kTrieNoUp);  // context of a symbol's first bin when there is no symbol above
-  uint32_t c = c_top;
-  const bool cols = a.P.col_rows != 0 && a.P.selector != 0;  // (uniform) the symbol above restarts with every column
-  while (!handed_over && idx < n_my) {
-    // every pass tops v up to sh = 23 for all lanes (one bin takes at most 6 bits): no per-lane refill branch.  The window
-    // is re-based from the prefetched piece every 16 passes and, wave-uniformly, whenever a lane is short of a top-up
-    if ((it++ & 15u) == 0) {
-      src.boundary();
-      // finished 16-symbol pieces leave here, right behind the boundary's wait for the payload piece (vmcnt counts stores
-      // too, and in order: a store issued when a lane completes a piece would be waited for by everybody)
-      if (idx - out >= 16u) {
-        *reinterpret_cast<uint4 *>(row_out + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
-        out += 16;
-      }
-    } else {
-      src.ensure(24);
-    }
-    dec_topup_nocheck(d, src);
-    const uint32_t pair = dec_bin_at_mem(d, st.addr(c), st);  // bit 1 = mps, bit 0 = MPS path
-    const uint32_t bin = ((pair >> 1) ^ ~pair) & 1u;
-    const uint32_t step = trie_step(node, bin, up);  // where the walk goes | context of the next bin << 8
-    const uint32_t nx = step & 0xFFu;
-    c = step >> 8;
-    const bool leaf = (nx & 0x80u) != 0;  // end of a code word (or no code word at all: handed over below)
-    const uint32_t v = nx & 0x7Fu;
-    if (leaf) stage[idx & 31u] = (uint8_t)v;  // (a lane finishes at most one symbol per pass, 16 per boundary)
-    handed_over = nx == kTrieNone;
-    idx += leaf ? 1u : 0u;
-    node = leaf ? 0u : nx;
-    up = leaf ? v : up;
-    if (cols) {
-      row += leaf ? 1u : 0u;
-      const bool top = leaf && row == a.P.col_rows;
+  const LaneBytes32 stage{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + lane * 4)};  // 32 bytes of output staging (see kSymPhase)
+  const uint32_t wa_top = kTrieNoUp * 4u;
+  const uint32_t sa_top = sbase + walk_state_off(ta.trie.ctx[kTrieNoUp]);
+  uint32_t idx = 0, wa = wa_top, sa = sa_top, row = 0, out = 0;  // out: symbols stored, a multiple of 16
+  auto live = [&]() { return idx < n_my && !(bad >> kWalkBadBit & 1u); };
+  auto one_bin = [&](auto guarded) {
+    if (decltype(guarded)::value && !live()) return;
+    uint32_t nx;
+    const uint32_t pair = dec_bin_row_q(d, sa, st.load_at(sa), st, nx);  // bit 1 = mps, bit 0 = MPS path
+    const uint32_t E = walk_entry(wa + ((pair & 3u) << 7));               // (kWalkSlot = 1 << 7)
+    // the symbol of a code word that ends here -- anything else is overwritten when its code word does end
+    stage.put(idx, E >> kWalkSymShift);
+    bad |= E;
+    idx += (E >> kWalkLeafBit) & 1u;
+    wa = E & kWalkNextMask;
+    sa = sbase + ((E >> kWalkOffShift) & ((1u << kWalkOffBits) - 1u));
+    if (COLS) {
+      row += (E >> kWalkLeafBit) & 1u;
+      const bool top = row == a.P.col_rows;  // (only ever true right after a code word's last bin)
       row = top ? 0u : row;
-      up = top ? kTrieNoUp : up;
-      c = top ? c_top : c;
+      wa = top ? wa_top : wa;
+      sa = top ? sa_top : sa;
+    }
+  };
+  while (CABAC_WAVE_ANY(live())) {
+    // chunk boundary (wave-uniform): the window moves on to the piece fetched a chunk ago, and finished 16-symbol pieces
+    // leave right behind its wait for that piece (vmcnt counts stores too, and in order)
+    src.boundary();
+    if (idx - out >= 16u) {
+      *reinterpret_cast<uint4 *>(row_out + out) = stage.piece((out >> 4) & 1u);
+      out += 16;
+    }
+    // while every lane has more symbols left than a chunk can finish (and none has left the tree), nobody needs a guard
+    const bool tail = CABAC_WAVE_ANY(idx + 16u > n_my || (bad >> kWalkBadBit & 1u));
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check then
+      // covers words 2 and 3.  One bit-granular top-up per four bins (sh = 23 afterwards): a bin takes at most 6 bits and
+      // needs sh >= 7, so three never run short and only the fourth is guarded
+      if (g == 2) src.ensure(47);
+      dec_topup_nocheck(d, src);
+      if (!tail) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k == 3) dec_guard(d, src, 7);
+          one_bin(std::false_type{});
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k == 3) dec_guard(d, src, 7);
+          one_bin(std::true_type{});
+        }
+      }
     }
   }
+  const bool handed_over = (bad >> kWalkBadBit & 1u) != 0;
   a.redo[s] = handed_over ? 1u : 0u;
   if (handed_over) {
     *a.redo_any = 1u;
     return;
   }
   // what is still staged, the last, incomplete group of 16 padded with zeros (rows are padded to a multiple of 16)
-  for (uint32_t i = n_my; i < ((n_my + 15u) & ~15u); i++) stage[i & 31u] = 0;
-  for (; out < n_my; out += 16) *reinterpret_cast<uint4 *>(row_out + out) = *reinterpret_cast<const uint4 *>(stage + (out & 16u));
+  for (uint32_t i = n_my; i < ((n_my + 15u) & ~15u); i++) stage.put(i, 0u);
+  for (; out < n_my; out += 16) *reinterpret_cast<uint4 *>(row_out + out) = stage.piece((out >> 4) & 1u);
   for (uint32_t i = (n_my + 15u) & ~15u; i < a.nsym; i++) row_out[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
@@ -802,7 +893,7 @@ static bool sym_use_trie(const SymParams &P, SymTrie *T) {
     const char *v = getenv("ISSCABAC_SYM_NO_TRIE");
     return v && v[0] && v[0] != '0';
   }();
-  return !off && sym_trie_build(P, T);
+  return !off && sym_trie_build(P, T) && T->nodes <= kWalkMaxNodes;  // (walk positions are 14 bits)
 }
 
 // the symbol kernels read their tables by absolute LDS address: their dynamic LDS must start at 0
@@ -858,8 +949,14 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   SymTrieEncArgs ta;
   if (!d_stats && sym_use_trie(a.P, &ta.trie)) {
     ta.a = a;
-    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie)))) return rc;
-    hipLaunchKernelGGL(k_encode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * sym_trie_wave_bytes(a.nctx), e->stream, ta);
+    const size_t wlds = sym_walk_tab_bytes(ta.trie.nodes, true) + kSymWaves * sym_walk_wave_bytes(a.nctx, true);
+    if (a.P.col_rows != 0 && a.P.selector != 0) {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie<true>)))) return rc;
+      hipLaunchKernelGGL(k_encode_symbols_trie<true>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
+    } else {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie<false>)))) return rc;
+      hipLaunchKernelGGL(k_encode_symbols_trie<false>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
+    }
   } else {
     if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
     hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), kSymTab + kSymWaves * kSymWaveBytes, e->stream, a);
@@ -913,8 +1010,14 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
     a.redo = e->lens;
     a.redo_any = e->flag;
     ta.a = a;
-    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie)))) return rc;
-    hipLaunchKernelGGL(k_decode_symbols_trie, dim3((unsigned)nblk), dim3(256), kSymTabTrie + kSymWaves * sym_trie_wave_bytes(a.nctx), e->stream, ta);
+    const size_t wlds = sym_walk_tab_bytes(ta.trie.nodes, false) + kSymWaves * sym_walk_wave_bytes(a.nctx, false);
+    if (a.P.col_rows != 0 && a.P.selector != 0) {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie<true>)))) return rc;
+      hipLaunchKernelGGL(k_decode_symbols_trie<true>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
+    } else {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie<false>)))) return rc;
+      hipLaunchKernelGGL(k_decode_symbols_trie<false>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
+    }
     HIP_TRY(e, hipGetLastError());
   }
   if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols)))) return rc;

@@ -61,6 +61,7 @@ struct HostBin {  // Bin policy of enc_bin_at_mem
   uint32_t xor_q(uint32_t q) const { return (bin << 1) ^ q; }
   uint32_t or_q(uint32_t q) const { return q | bin; }
   uint32_t next_of(uint32_t hi) const { return hi >> (8 * bin); }  // the store takes the low byte
+  uint32_t lps_mask(uint32_t q) const { return mask_from_bit1(xor_q(q)); }
 };
 
 struct HostSink {
