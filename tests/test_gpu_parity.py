@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP engine, called through its C ABI, against the oracle and the golden vectors.
 Bit-exact (integer/byte work): payload bytes, per-stream lengths, decoded bins and decoder status flags."""
+import os
+
 import numpy as np
 import pytest
 
@@ -779,3 +781,53 @@ def test_async_entry_points_chain_without_the_host(engine, oracle):
     assert ei.value.code == 4 and str(want_p.size) in str(ei.value)
     engine.sync()  # the error is reported once
     engine.set_profiling(False)
+
+
+def test_code_tree_kernels_match_the_general_kernels_on_ragged_and_corrupt_input(engine, tmp_path):
+    """The symbol-level fast path (walk-table kernels, cabac_symbols.hip) against the general kernels run in a second
+    process with ISSCABAC_SYM_NO_TRIE=1: ragged symbol counts (a stream may end anywhere inside a phase), symbol values
+    >= nq, and corrupted payloads -- bin strings that leave the code tree and first bytes of 0xFF are handed over to the
+    general kernel on the device, every other stream is decoded by the walk and must read the same garbage."""
+    import subprocess
+    import sys
+    from isscabac_amd import SymbolParams, init_by_prob
+    rng = np.random.default_rng(77)
+    cases = []
+    for ci, (S, R, nq, method, k, types, nlbp, col_rows) in enumerate([(700, 150, 8, "EG", 0, 15, 3, 0), (333, 61, 16, "TU", 0, 31, 2, 0),
+                                                                       (260, 96, 8, "EG", 0, 15, 3, 24), (129, 40, 4, "EG", 1, 15, 3, 0)]):
+        sym = np.minimum(rng.exponential(1.3, (S, R)).astype(np.int64), nq - 1).astype(np.uint8)
+        sym[rng.random((S, R)) < 0.01] = 200  # cannot be coded: goes out as nq - 1
+        nsym = rng.integers(0, R + 1, S).astype(np.uint32)
+        nsym[:8] = [0, 1, 7, 8, 9, 15, 16, R]
+        init = init_by_prob(np.round(rng.uniform(0.05, 0.95, 7 * nlbp + 2) * 255) / 255)
+        params = SymbolParams.iss(nq, method, k, types, nlbp, col_rows=col_rows)
+        payload, offsets, nbins = engine.encode_symbols(sym, params, init, nsym=nsym)
+        bad = payload.copy()
+        bad[rng.integers(0, bad.size, max(1, bad.size // 30))] ^= 0xA5
+        for s0 in rng.integers(0, S, 5):
+            if offsets[s0 + 1] > offsets[s0]:
+                bad[int(offsets[s0])] = 0xFF
+        got = [engine.decode_symbols(p, offsets, R, params, init, nsym=nsym) for p in (payload, bad)]
+        mask = np.arange(R)[None, :] < nsym[:, None]
+        assert (got[0][1] == 0).all() and (got[0][0] * mask == np.minimum(sym, nq - 1) * mask).all() and not (got[0][0] * ~mask).any()
+        np.savez(tmp_path / ("case%d.npz" % ci), sym=sym, nsym=nsym, init=init, payload=payload, bad=bad, offsets=offsets,
+                 nbins=nbins, good_sym=got[0][0], bad_sym=got[1][0], bad_status=got[1][1],
+                 par=np.array([nq, k, types, nlbp, col_rows, R]), method=method)
+        cases.append(ci)
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from isscabac_amd import Engine, SymbolParams
+eng = Engine(0)
+for ci in %r:
+    z = np.load(%r + "/case%%d.npz" %% ci)
+    nq, k, types, nlbp, col_rows, R = [int(x) for x in z["par"]]
+    params = SymbolParams.iss(nq, str(z["method"]), k, types, nlbp, col_rows=col_rows)
+    payload, offsets, nbins = eng.encode_symbols(z["sym"], params, z["init"], nsym=z["nsym"])
+    assert payload.tobytes() == z["payload"].tobytes() and (offsets == z["offsets"]).all() and (nbins == z["nbins"]).all(), ci
+    s, st = eng.decode_symbols(z["bad"], z["offsets"], R, params, z["init"], nsym=z["nsym"])
+    assert (s == z["bad_sym"]).all() and (st == z["bad_status"]).all(), ci
+print("same")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases, str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, ISSCABAC_SYM_NO_TRIE="1"), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
