@@ -203,7 +203,7 @@ struct BinOfWord {
     else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w));
     return r;
   }
-  __device__ __forceinline__ uint32_t lps_mask(uint32_t q) const { return mask_from_bit1(xor_q(q)); }
+  __device__ __forceinline__ uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)__builtin_amdgcn_sbfe(t, 16, 1); }
   __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
     uint32_t r;
     if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));
@@ -461,7 +461,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   }
   for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by bin
     tab[kTabRowOff / 4 + 2 * ps] = c_lps_rows[ps >> 1];
-    tab[kTabRowOff / 4 + 2 * ps + 1] = (c_next.eb[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
+    const uint32_t sb = c_next.eb[ps >> 1] >> (16 * (ps & 1));
+    tab[kTabRowOff / 4 + 2 * ps + 1] = enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;

@@ -303,19 +303,26 @@ CABAC_HD void enc_bin_at_mem(EncCore &e, Bin bin, Addr at, States &st) {
 struct EncWordAcc {
   uint32_t T, S;
 };
+// high word of the encoder's 8-byte entry for packed state ps (= q >> 1; its mps is bit 0), see enc_bin_row_acc
+constexpr uint32_t enc_entry_hi(uint32_t ps, uint32_t succ_bin0, uint32_t succ_bin1) {
+  return succ_bin0 | succ_bin1 << 8 | ((ps & 1u) ? 1u : 0u) << 16 | ((ps & 1u) ? 0u : 1u) << 24;
+}
 // The encoder's step for one bin of an input word (first: the word's first bin) -- everything except `low` and W, which
 // enc_word_close updates -- on ONE table lookup: entry_mem(q) -> 64 bits by packed state (q >> 1): the state's 4-byte rangeTabLps row
-// in the low word, its two successors -- by bin value: byte 0 for a bin of 0, byte 1 for a bin of 1 -- in the high word.
+// in the low word, its two successors -- by bin value: byte 0 for a bin of 0, byte 1 for a bin of 1 -- in the high word,
+// followed by two flags at bits 16 and 24: "a bin of 0 / of 1 is not this state's mps" (enc_entry_hi), so that the shift
+// that picks the successor also brings the LPS flag to bit 16.
 // Three LDS operations per bin instead of four (an 8-byte read costs the LDS pipe what a 1-byte read does, measured:
 // tools/ubench/lds_tp.hip), two round trips behind each other instead of three, and none of them inside the
 // range -> LPS -> range recurrence: the LPS column is picked from the row in a register (lps_of).
-// Bin policy: next_of(hi) -> the successor for this bin out of the high word, lps_mask(q) -> ~0 if the bin is not q's mps.
+// Bin policy: next_of(hi) -> hi >> (8 * bin), lps_mask(q, t) -> ~0 if the bin is not q's mps (t = next_of(hi)).
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
   const uint64_t ent = st.entry_mem(q);
-  st.store_at(at, bin.next_of((uint32_t)(ent >> 32)));
-  const uint32_t m = bin.lps_mask(q);  // ~0: bin != mps
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));  // low byte: the successor; bit 16: the bin is not q's mps
+  st.store_at(at, t);
+  const uint32_t m = bin.lps_mask(q, t);  // ~0: bin != mps
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   const uint32_t r = select_mask(m, lps, rmps);

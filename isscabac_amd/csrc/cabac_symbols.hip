@@ -377,11 +377,10 @@ struct WalkStates {
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)a) = (uint8_t)q; }
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(q << 2)); }
 };
-// Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where the mps of q << 2 -- the entry's
-// address -- sits too
+// Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where it is the shift that picks the successor
 struct WalkBin {
-  uint32_t bits8, b8;  // b8 = bits8 & 8
-  __device__ __forceinline__ uint32_t lps_mask(uint32_t q) const { return (uint32_t)__builtin_amdgcn_sbfe((q << 2) ^ bits8, 3, 1); }
+  uint32_t b8;  // bits8 & 8
+  __device__ __forceinline__ uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)__builtin_amdgcn_sbfe(t, 16, 1); }
   __device__ __forceinline__ uint32_t next_of(uint32_t hi) const { return hi >> b8; }
 };
 
@@ -457,7 +456,8 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     if (tid < 128) {  // packed state: its row, its successors by bin
       tab[2 * tid] = y_lps_rows[tid >> 1];
-      tab[2 * tid + 1] = (y_next.eb[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+      const uint32_t sb = y_next.eb[tid >> 1] >> (16 * (tid & 1));
+      tab[2 * tid + 1] = enc_entry_hi(tid, sb & 0xFFu, (sb >> 8) & 0xFFu);
     }
     const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);  // (values >= nq cannot be coded: they go out as nq - 1)
     reinterpret_cast<uint32_t *>(smem + kWalkBits)[tid] = g.bits << 3;  // (at most 29 bins: sym_trie_build)
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     const uint32_t nb8 = bt8[ring.get(idx + 1u)];
     const uint32_t b8 = opaque(bits8 & 8u);                  // 8 * bin (opaque: stays one AND, shared by both uses)
     const uint32_t E = walk_entry(wa + (b8 << 4));           // (kWalkSlot = 8 << 4)
-    enc_bin_row_acc(e, acc, false, WalkBin{bits8, b8}, sa, st);
+    enc_bin_row_acc(e, acc, false, WalkBin{b8}, sa, st);
     const uint32_t lastm = (uint32_t)__builtin_amdgcn_sbfe(E, kWalkLeafBit, 1);  // ~0: the symbol's last bin
     bits8 = select_mask(lastm, nb8, bits8 >> 1);
     idx -= lastm;

@@ -50,7 +50,7 @@ struct HostStates {
   bool by_path = false;
   uint64_t entry_mem(uint32_t q) const {
     const uint32_t b0 = by_path ? next_path_mem(q) : next_mem(q), b1 = by_path ? next_path_mem(q + 1u) : next_mem(q | 1u);
-    return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(b0 | b1 << 8) << 32;
+    return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(by_path ? (b0 | b1 << 8) : enc_entry_hi(q >> 1, b0, b1)) << 32;
   }
   uint32_t next_path_mem(uint32_t q_plus_path) const {  // path 1 = MPS
     return (next_state_entry16(q_plus_path >> 1, kTransLps[q_plus_path >> 2]) >> (8 * (1u - (q_plus_path & 1u)))) & 0xFFu;
@@ -61,7 +61,7 @@ struct HostBin {  // Bin policy of enc_bin_at_mem
   uint32_t xor_q(uint32_t q) const { return (bin << 1) ^ q; }
   uint32_t or_q(uint32_t q) const { return q | bin; }
   uint32_t next_of(uint32_t hi) const { return hi >> (8 * bin); }  // the store takes the low byte
-  uint32_t lps_mask(uint32_t q) const { return mask_from_bit1(xor_q(q)); }
+  uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)((int32_t)(t << 15) >> 31); }  // bit 16 of the shifted entry
 };
 
 struct HostSink {

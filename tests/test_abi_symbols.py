@@ -113,3 +113,20 @@ def test_iss_side_info_container_round_trip(tmp_path):
     open(fn, "wb").write(b"not a container at all, really not" * 3)
     with pytest.raises(eng.EngineError, match="not an ISS container"):
         eng.iss_container_read(fn)
+
+
+def test_no_instruction_touches_an_lds_read_in_flight():
+    """tools/check_inflight_regs.py on the coder kernels' ISA: the latency-oriented encoder issues its state pass in inline
+    assembly with the waits placed by hand; a copy or spill the compiler put between such a read and its wait would be a
+    race no parity test is sure to catch.  Negative control: the checker does flag a hand-made violation."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_inflight_regs as chk
+    bad, counts = chk.check("_Zfoo:\n\tds_read_b64 v[4:5], v1 offset:768\n\tv_mov_b32_e32 v9, v5\n\ts_waitcnt lgkmcnt(0)\n")
+    assert len(bad) == 1 and counts == {"_Zfoo": 1}
+    bad, _ = chk.check("_Zfoo:\n\tds_read_b64 v[4:5], v1 offset:768\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v9, v5\n")
+    assert not bad
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "k_encodeILi1ELb1ELb0E" in out.stdout  # the latency-oriented encoder was among the kernels checked
