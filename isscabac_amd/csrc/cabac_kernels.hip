@@ -218,10 +218,10 @@ struct BinOfWord {
 template <class F>
 __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1, F &&f) {
   switch (k & 3) {
-    case 0: return f(BinOfWord<0>{w2, w1, 0u});
-    case 1: return f(BinOfWord<1>{w2, w1, 0u});
-    case 2: return f(BinOfWord<2>{w2, w1, 0u});
-    default: return f(BinOfWord<3>{w2, w1, 0u});
+    case 0: return f(BinOfWord<0>{w2, w1, w1 << 3});
+    case 1: return f(BinOfWord<1>{w2, w1, w1 << 3});
+    case 2: return f(BinOfWord<2>{w2, w1, w1 << 3});
+    default: return f(BinOfWord<3>{w2, w1, w1 << 3});
   }
 }
 

@@ -348,9 +348,11 @@ template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t mb, uint32_t bmask, Addr at,
                                 States &st) {
   const uint32_t q = st.load_at(at);
-  st.store_at(at, select_mask(mb, q, st.next_mem(bin.or_q(q))));
-  const uint32_t m = mask_from_bit1(bin.xor_q(q)) & ~mb;  // ~0: a context bin that is not its mps
-  const uint32_t lps = st.lps_mem(q, e.range);
+  const uint64_t ent = st.entry_mem(q);  // one lookup: row + successors by bin + LPS flags, see enc_bin_row_acc
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  st.store_at(at, select_mask(mb, q, t));
+  const uint32_t m = bin.lps_mask(q, t) & ~mb;  // ~0: a context bin that is not its mps
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   const uint32_t r = select_mask(mb, e.range, select_mask(m, lps, rmps));
   const uint32_t n = clz32(r) - 23u;  // 0 for a bypass bin
@@ -761,14 +763,16 @@ CABAC_HD uint32_t dec_bin_row_q(DecCore &d, Addr at, uint32_t q, States &st, uin
 template <class States, class Addr>
 CABAC_HD uint32_t dec_bin_mixed(DecCore &d, uint32_t mb, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
-  const uint32_t lps = st.lps_mem(q, d.range);
+  const uint64_t ent = st.entry_mem(q);  // one lookup: row + successors by path, see dec_bin_row_q
+  const uint32_t lps = lps_of((uint32_t)ent, d.range);
   const uint32_t rmps = d.range - lps;
   const int32_t sh = d.sh + (int32_t)mb;  // mb = -1: the bypass bin's bit
   const uint32_t scaled = select_mask(mb, d.range, rmps) << sh;
   uint32_t diff;
   const bool below = __builtin_sub_overflow(d.v, scaled, &diff);  // the MPS path / a bypass bin of 0
-  const uint32_t idx = st.path_index(q) + (uint32_t)below;
-  st.store_at(at, select_mask(mb, q, st.next_path_mem(idx)));
+  const uint32_t idx = q + (uint32_t)below;
+  const uint32_t hi = (uint32_t)(ent >> 32);
+  st.store_at(at, select_mask(mb, q, below ? (hi >> 8) : hi));  // (the store takes the low byte)
   const uint32_t r = select_mask(mb, d.range, below ? rmps : lps);
   const uint32_t n = clz32(r) - 23u;
   d.v = below ? d.v : diff;
