@@ -33,6 +33,25 @@
 #include "cabac_internal.h"
 #include "cabac_lane.h"
 
+#ifndef ISSCABAC_DEC_SPLIT_TAB
+#define ISSCABAC_DEC_SPLIT_TAB 0
+#endif
+#ifndef ISSCABAC_EXP_NOLOAD  // timing experiments, never in the product build
+#define ISSCABAC_EXP_NOLOAD 0
+#endif
+#ifndef ISSCABAC_EXP_NOPAYLOAD
+#define ISSCABAC_EXP_NOPAYLOAD 0
+#endif
+#ifndef ISSCABAC_DEC_ROLLED  // the four chunks of a load round as a real loop: a quarter of the code
+#define ISSCABAC_DEC_ROLLED 0
+#endif
+#ifndef ISSCABAC_ENC_ROLLED
+#define ISSCABAC_ENC_ROLLED 0
+#endif
+#ifndef ISSCABAC_EXP_CLK  // stall accounting of the decode kernel into the status words (tools/dec_stalls.py)
+#define ISSCABAC_EXP_CLK 0
+#endif
+
 namespace isscabac {
 
 __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
@@ -116,15 +135,21 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // every HBM request is a full 64-byte segment -- 32-byte segments were measured to double FETCH_SIZE), keeps
 // them in registers, and moves one 32-byte half at a time through LDS, where lane r reads its own stream's
 // row back with ds_read_b128.  Halving the LDS residency is what lets 4 workgroups share a CU.
-struct Tile {
-  static constexpr int T = 64;   // bytes per stream per load round
-  static constexpr int H = 32;   // bytes per stream resident in LDS
-  static constexpr int NLD = 4;  // wave-wide load instructions per round (16 streams each)
+// LPR = lanes per row and load instruction: 4 -> 64-byte row segments, a load round is 64 bytes per stream in 4
+// instructions per array (16 registers); 8 -> 128-byte segments, 128 bytes per stream in 8 instructions (32 registers).
+// Whole 128-byte lines per request are what the memory system likes (tools/ubench/store_seg.hip: two arrays read this
+// way, 1.30 ms against 2.54 ms with 64-byte segments at the coder kernels' occupancy), registers permitting.
+template <int LPR>
+struct TileT {
+  static constexpr int T = 16 * LPR;  // bytes per stream per load round
+  static constexpr int H = 32;        // bytes per stream resident in LDS
+  static constexpr int NLD = LPR;     // wave-wide load instructions per round (64 / LPR streams each)
+  static constexpr int NP = T / H;    // 32-byte parts per round
   // LDS image: row r = 32 bytes = two 16-byte chunks; chunk c sits in slot c ^ ((r >> 3) & 1), which makes
   // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row
   __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
-  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * 16 + (lane >> 2); }
-  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane & 3; }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * (64 / LPR) + lane / LPR; }
+  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % LPR; }
 
   // rows = this wave's first row in the [S][pitch] array (wave-uniform pointer), nrows = how many of the wave's 64 rows
   // exist (wave-uniform); the per-lane part of the address is a 32-bit offset (pitch <= 2^25, checked by the C ABI), so
@@ -143,6 +168,29 @@ struct Tile {
       else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(rows + voff) : make_uint4(0, 0, 0, 0);
     }
   }
+  // The same when the whole round lies inside the rows (off + T <= pitch): exactly NLD load instructions, no
+  // predicate -- the decode kernel counts on that (WindowDev::boundary_async)
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_full(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch,
+                                                   uint32_t off, int lane) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint32_t row = min(row_of(k, lane), nrows - 1u);
+      const uint32_t voff = row * pitch + off + ch_of(lane) * 16;
+      if (NT) r[k] = nt_load16(rows + voff);
+      else r[k] = *reinterpret_cast<const uint4 *>(rows + voff);
+    }
+  }
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows_full(uint4 (&r)[NLD], const uint8_t *base, const uint32_t (&rid)[NLD], uint32_t pitch,
+                                                        uint32_t off, int lane) {
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint8_t *p = base + ((uint64_t)rid[k] * pitch + off + ch_of(lane) * 16);
+      if (NT) r[k] = nt_load16(p);
+      else r[k] = *reinterpret_cast<const uint4 *>(p);
+    }
+  }
   // The same for a wave whose 64 streams are NOT neighbours in the array (length-bucketed launches, cabac_order.hip):
   // rid[k] = stream id of the row this lane fetches a piece of with load k; one 64-bit multiply-add per load
   template <bool NT = false>
@@ -156,7 +204,7 @@ struct Tile {
       else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
     }
   }
-  // half h (0: bytes 0..31 of the round, 1: bytes 32..63) of the registers -> LDS
+  // part h (bytes 32 h .. 32 h + 31 of the round) of the registers -> LDS
   __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
     if ((int)(ch_of(lane) >> 1) == h) {
 #pragma unroll
@@ -170,8 +218,42 @@ struct Tile {
     *reinterpret_cast<uint4 *>(tile + lds_off(lane, j)) = v;
   }
 };
+typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
+#ifndef ISSCABAC_ENC_LPR
+#define ISSCABAC_ENC_LPR 4
+#endif
+typedef TileT<ISSCABAC_ENC_LPR> ETile;  // the encode kernel's
+
+// The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
+// are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
+// leave as full 128-byte row segments (64-byte segments, one per load round, were measured at 3.1 TB/s against 4.7 for
+// load + store: tools/ubench/tile_bw.hip, store_seg.hip -- the kernel was store-bound with them).  Dword (c, row) of the
+// eight chunks c sits at c * 64 + (row ^ 8 c): a lane writes its own row (all banks distinct), and the store pass
+// reads (8 rows) x (8 chunks) per instruction, again all banks distinct.
+struct OutBuf {
+  static constexpr uint32_t BYTES = 8 * 64 * 4;
+  __device__ static __forceinline__ uint32_t idx(uint32_t c, uint32_t row) { return c * 64 + (row ^ (c * 8)); }
+  __device__ static __forceinline__ uint32_t pack(const uint4 &v) {
+    const uint32_t M = 0x01010101u;
+    uint32_t d = v.x & M;
+    d |= (v.y & M) << 1;
+    d |= (v.z & M) << 2;
+    d |= (v.w & M) << 3;
+    return d;
+  }
+  __device__ static __forceinline__ uint4 unpack(uint32_t d) {
+    const uint32_t M = 0x01010101u;
+    return make_uint4(d & M, (d >> 1) & M, (d >> 2) & M, (d >> 3) & M);
+  }
+};
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ void set_word(uint4 &v, int i, uint32_t w) {
+  if (i == 0) v.x = w;
+  else if (i == 1) v.y = w;
+  else if (i == 2) v.z = w;
+  else v.w = w;
+}
 __device__ __forceinline__ uint32_t byte_of(const uint4 &v, int k) { return (word_of(v, k >> 2) >> (8 * (k & 3))) & 0xFFu; }
 // a word whose bit 1 is bin k of the chunk (bins are bytes 0/1): what enc_bin's b1 wants, one shift
 __device__ __forceinline__ uint32_t bin_at_bit1(const uint4 &v, int k) {
@@ -267,6 +349,22 @@ struct LdsStates {
   // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + (q << 2)));
+  }
+  // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
+  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
+#if ISSCABAC_DEC_SPLIT_TAB
+    // two conflict-free reads -- either table is 256 bytes = one LDS bank row -- instead of one 8-byte read from 2 KiB:
+    // the rangeTabLps row by state at (qb & 0xFC), the successor pair by packed state at 256 + (qb & 0xFE)
+    const uint32_t row = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(qb & 0xFCu));
+    const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
+    return (uint64_t)row | (uint64_t)sp << 32;
+#else
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(qb << 3));
+#endif
+  }
+  // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
+  __device__ __forceinline__ void store_at_hi(uint32_t a, uint32_t p) const {
+    asm volatile("ds_write_b8_d16_hi %0, %1" : : "v"(a), "v"(p) : "memory");
   }
   // state addresses as plain 32-bit LDS addresses (the latency-oriented paths compare them)
   __device__ __forceinline__ uint32_t base32() const { return (uint32_t)(uintptr_t)(lds_u8 *)base; }
@@ -475,13 +573,13 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
-  uint32_t rid[Tile::NLD] = {0, 0, 0, 0};
+  uint32_t rid[ETile::NLD] = {};
   if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
     uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);
     wids[lane] = (uint32_t)s;
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < Tile::NLD; k++) rid[k] = wids[Tile::row_of(k, lane)];
+    for (int k = 0; k < ETile::NLD; k++) rid[k] = wids[ETile::row_of(k, lane)];
   }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
@@ -509,33 +607,43 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   sink.pos = 0;
   sink.on = valid;
 
-  const uint32_t nrounds = (nmax + Tile::T - 1) / Tile::T;
+  const uint32_t nrounds = (nmax + ETile::T - 1) / ETile::T;
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
-  uint4 pb[Tile::NLD], pc[Tile::NLD];
+  uint4 pb[ETile::NLD], pc[ETile::NLD];
   auto fetch = [&](uint32_t off) {
     if (PERM) {
-      Tile::load_rows(pb, a.bins, rid, a.pitch, off, lane);
-      Tile::load_rows(pc, a.ctx, rid, a.pitch, off, lane);
+      ETile::load_rows(pb, a.bins, rid, a.pitch, off, lane);
+      ETile::load_rows(pc, a.ctx, rid, a.pitch, off, lane);
     } else {
-      Tile::load(pb, bins_w, nrows, a.pitch, off, lane);
-      Tile::load(pc, ctx_w, nrows, a.pitch, off, lane);
+      ETile::load(pb, bins_w, nrows, a.pitch, off, lane);
+      ETile::load(pc, ctx_w, nrows, a.pitch, off, lane);
     }
   };
   if (nrounds) fetch(0);
   wave_lds_sync();
   for (uint32_t t = 0; t < nrounds; t++) {
+#if ISSCABAC_ENC_ROLLED
+#pragma unroll 1
+#else
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      Tile::half_to_lds(tile_b, pb, h, lane);
-      Tile::half_to_lds(tile_c, pc, h, lane);
+#endif
+    for (int h = 0; h < ETile::NP; h++) {
+      if (t * ETile::T + h * ETile::H >= nmax) break;
+      ETile::half_to_lds(tile_b, pb, h, lane);
+      ETile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-      if (h == 1 && t + 1 < nrounds) fetch((t + 1) * Tile::T);  // registers are free again: the next round, behind 32 bins of work
+#if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's bytes again and again)
+      if (h == ETile::NP - 1 && t + 1 < nrounds) fetch((t + 1) * ETile::T);  // registers are free again: the next round, behind 32 bins of work
+#endif
+#if ISSCABAC_ENC_ROLLED
+#pragma unroll 1
+#endif
       for (int j = 0; j < 2; j++) {
-        const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
+        const uint32_t i0 = t * ETile::T + h * ETile::H + j * 16;
         if (i0 >= nmax) break;
-        const uint4 wb = Tile::row_chunk(tile_b, lane, j);
-        const uint4 wc = Tile::row_chunk(tile_c, lane, j);
+        const uint4 wb = ETile::row_chunk(tile_b, lane, j);
+        const uint4 wc = ETile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         if (LAT && full && !hi) {
@@ -672,7 +780,11 @@ struct DevMem {
     return r;
   }
   __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
+#if ISSCABAC_EXP_NOPAYLOAD  // (timing experiment: every lane reads the same few lines)
+    const uint64_t at = off & 0xFFCu;
+#else
     const uint64_t at = abase + off;
+#endif
     if ((int32_t)off <= lim) {  // off is far below 2^31 (a stream's payload is bounded by 6/8 of its <= 2^25 bins)
       const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
@@ -682,6 +794,99 @@ struct DevMem {
       lo = r.lo;
       hi = r.hi;
     }
+  }
+};
+
+// The decode kernel's bit source: WindowSrc with the payload piece fetched and awaited BY HAND.
+// Every chunk boundary waits for the piece requested one boundary earlier.  vmcnt counts loads and stores alike and
+// completes in order, and the compiler's wait in front of the piece's first use is vmcnt(0) (the requests sit in
+// branches), so the ctx loads and the output stores issued right behind a boundary had one chunk -- 16 bins -- to
+// complete before the wave stalled on them: measured, 1.0 ms of a 3.5 ms launch (bench.py with the loads / stores taken out
+// one at a time).  Here the request is inline assembly under an exec mask (always exactly one instruction, no branch), the
+// piece in flight (X) is named by nothing but the wait in front of adopt, and that wait allows the K operations issued
+// behind the request -- 8 output stores or 4 ctx loads, counted exactly by the kernel -- to stay in flight: they get two
+// chunks.  tools/check_inflight_regs.py checks in the compiled code that nothing touches X between request and wait.
+struct WindowDev : WindowSrc<DevMem> {
+  // The piece in flight -- bytes [npos, npos + 16) as loaded -- lives in v[124:127] and is no C++ value at all: a value
+  // the register allocator knows of gets copied (measured: out of the load's destination right behind the request, and
+  // back in front of the wait), and a copy reads registers whose data has not arrived.  Only the assembly below names
+  // these four registers -- they are in its clobber lists, so the compiler keeps nothing in them across it -- and
+  // tools/check_inflight_regs.py fails the build's test if any other instruction of a decode kernel does.
+  __device__ __forceinline__ void request() {
+    const uint32_t np = byte_pos() & ~3u;
+    const bool want = bpos - pbit >= ISSCABAC_PREFETCH_BITS;
+    const bool fast = want && (int32_t)np <= mem.lim;
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(fast);
+    const uint8_t *addr = mem.payload + (mem.abase + np);
+    uint64_t sv;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\t"
+                 "global_load_dwordx4 v[124:127], %2, off\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(mask), "v"(addr)
+                 : "memory", "v124", "v125", "v126", "v127");
+    if (want) npos = np;
+    if (wave_any(want && !fast)) {
+      // the last 16 bytes of the whole payload buffer (one wave per launch at most): everything lands first, then the
+      // lanes concerned read byte by byte
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory", "v124", "v125", "v126", "v127");
+      if (want && !fast) {
+        const DevMem::Pair r = DevMem::load16_tail(mem.payload, mem.total, mem.abase + np);
+        asm volatile("v_mov_b32 v124, %0\n\t"
+                     "v_mov_b32 v125, %1\n\t"
+                     "v_mov_b32 v126, %2\n\t"
+                     "v_mov_b32 v127, %3"
+                     :
+                     : "v"((uint32_t)r.lo), "v"((uint32_t)(r.lo >> 32)), "v"((uint32_t)r.hi), "v"((uint32_t)(r.hi >> 32))
+                     : "v124", "v125", "v126", "v127");
+      }
+    }
+  }
+  // waits for the piece and takes it out byte-swapped (what adopt() starts with).  K: vector memory operations issued
+  // behind the most recent request() that may stay in flight
+  template <int K>
+  __device__ __forceinline__ void await_adopt() {
+    uint32_t hh, hl, lh, ll;
+    asm volatile("s_waitcnt vmcnt(%4)\n\t"
+                 "v_perm_b32 %0, 0, v124, %5\n\t"
+                 "v_perm_b32 %1, 0, v125, %5\n\t"
+                 "v_perm_b32 %2, 0, v126, %5\n\t"
+                 "v_perm_b32 %3, 0, v127, %5"
+                 : "=&v"(hh), "=&v"(hl), "=&v"(lh), "=&v"(ll)
+                 : "n"(K), "s"(0x00010203u)
+                 : "memory", "v124", "v125", "v126", "v127");
+    adopt_from((uint64_t)hh << 32 | hl, (uint64_t)lh << 32 | ll);
+  }
+  __device__ __forceinline__ void start_async(uint32_t first_byte) {
+    bpos = 8u * first_byte;
+    cend = bpos;
+    cur = 0;
+    ph = pl1 = 0;
+    asm volatile("v_mov_b32 v124, 0\n\t"
+                 "v_mov_b32 v125, 0\n\t"
+                 "v_mov_b32 v126, 0\n\t"
+                 "v_mov_b32 v127, 0"
+                 :
+                 :
+                 : "v124", "v125", "v126", "v127");
+    pbit = bpos - ISSCABAC_PREFETCH_BITS;  // (so that request() wants a piece)
+    request();
+    pbit = 8u * npos;
+  }
+#if ISSCABAC_EXP_CLK
+  uint64_t clk_await = 0;
+#endif
+  template <int K>
+  __device__ __forceinline__ void boundary_async() {
+#if ISSCABAC_EXP_CLK
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    clk_await += __builtin_amdgcn_s_memtime() - c0;
+#endif
+    await_adopt<K>();
+    rebase();
+    request();
   }
 };
 
@@ -701,7 +906,24 @@ struct DecArgs {
 #ifndef ISSCABAC_DEC_OCC
 #define ISSCABAC_DEC_OCC 4  // waves per SIMD the decode kernel is register-limited to (4 measured 6% faster than 3)
 #endif
-constexpr bool kDecNT = true;  // decode kernel: ctx loads and bin stores are streaming
+#ifndef ISSCABAC_DEC_NT
+#define ISSCABAC_DEC_NT 1
+#endif
+#ifndef ISSCABAC_DEC_NOSTORE
+#define ISSCABAC_DEC_NOSTORE 0
+#endif
+constexpr bool kDecNT = ISSCABAC_DEC_NT != 0;  // decode kernel: ctx loads and bin stores are streaming
+
+// LDS of the decode kernel: the raw-byte entries (256 x 8 bytes, cabac_lane.h: dec_bin_out) at 0, then per wave the
+// context states, the round tile and (bucketed launches) the wave's stream ids
+constexpr int kDecTabBytes = 2048;
+template <int CM, bool PERM>
+struct DecLds {
+  static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
+  static constexpr uint32_t TILE = Tile::H * 64;  // the ctx half tile
+  static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
+  static constexpr uint32_t BYTES = SB + TILE + OutBuf::BYTES + IDS;
+};
 
 template <int CM, bool LAT, bool PERM>
 __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
@@ -709,22 +931,29 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+#if ISSCABAC_DEC_SPLIT_TAB
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
-    tab[kTabPathOff / 4 + tid] = c_next.ep[tid];
+    const uint32_t e = c_next.ep[tid];  // state tid: (mps 0: LPS path, MPS path), (mps 1: LPS path, MPS path)
+    tab[64 + tid] = dec_entry_hi_out(2 * tid, e & 0xFFu, (e >> 8) & 0xFFu) | dec_entry_hi_out(2 * tid + 1, (e >> 16) & 0xFFu, e >> 24) << 16;
   }
-  for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by path
-    tab[kTabRowOff / 4 + 2 * ps] = c_lps_rows[ps >> 1];
-    tab[kTabRowOff / 4 + 2 * ps + 1] = (c_next.ep[ps >> 1] >> (16 * (ps & 1))) & 0xFFFFu;
+#else
+  for (int qb = tid; qb < 256; qb += blockDim.x) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin
+    const uint32_t ps = (uint32_t)qb >> 1;
+    const uint32_t sp = c_next.ep[ps >> 1] >> (16 * (ps & 1));  // byte 0: successor on the LPS path, byte 1: on the MPS path
+    tab[2 * qb] = c_lps_rows[ps >> 1];
+    tab[2 * qb + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
   }
+#endif
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
-  using WL = WaveLds<CM, PERM>;
-  uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
-  uint8_t *tile_c = wbase + WL::SB, *tile_o = tile_c + WL::TILE;
-  const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_o + WL::TILE + WL::STAGE);  // PERM: the wave's stream ids
+  using DL = DecLds<CM, PERM>;
+  uint8_t *wbase = smem + kDecTabBytes + wib * DL::BYTES;
+  uint8_t *tile_c = wbase + DL::SB;
+  uint32_t *obuf = reinterpret_cast<uint32_t *>(tile_c + DL::TILE);
+  const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_c + DL::TILE + OutBuf::BYTES);  // PERM: the wave's stream ids
 
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
@@ -738,7 +967,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
-  const uint32_t nmin = wave_min_u32(n), nmax = wave_max_u32(n);
+  // wave-uniform, and known to the compiler as such: chunk classification is scalar compares and branches
+  const uint32_t nmin = __builtin_amdgcn_readfirstlane(wave_min_u32(n)), nmax = __builtin_amdgcn_readfirstlane(wave_max_u32(n));
 
   // doubled states q = m_ucState << 1, four per dword
   {
@@ -747,7 +977,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     // is_ctx_byte() and must find the reference's default ContextModel() (mps 1, state 0: the C ABI pads ctx_init
     // with it), never a stale LDS byte -- a stale 0xFC..0xFF would be state 63, whose LPS of 2 shifts 7 bits per bin
     // and overruns the slot bound of 6
-    constexpr uint32_t ngrp = WL::SB / 256;
+    constexpr uint32_t ngrp = DL::SB / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   LdsStates stx{wbase + lane * 4};
@@ -757,14 +987,14 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
   const uint64_t abase = start & ~3ull;
   const uint32_t skew = (uint32_t)(start - abase);
-  WindowSrc<DevMem> src;
+  WindowDev src;
   src.mem.payload = a.payload;
   src.mem.total = a.payload_bytes;
   src.mem.abase = abase;
   src.mem.lim = a.payload_bytes >= abase + 16 ? (int32_t)min(a.payload_bytes - 16 - abase, (uint64_t)0x7FFFFFFF) : -1;
   src.len = skew + len;
-  src.start(skew);
-  src.boundary();
+  src.start_async(skew);
+  src.template boundary_async<0>();
   DecCore d;
   dec_start(d, src);
   // v now holds the stream's first four bytes.  A first byte of 0xFF (corrupt input only) makes the reference's value
@@ -774,20 +1004,33 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
   uint8_t *out_w = a.bins_out + s0 * a.pitch;
-  // decoded bins are kept as BITS in LDS, 128 bins (16 bytes) per stream, and leave as full 128-byte row segments:
-  // 32-byte segment stores were measured at 1.35 TB/s, 128-byte ones at 4 TB/s (tools/ubench/tile_bw.hip)
-  // (two bits per bin as collect_bin() leaves them: bin j of a 16-bin chunk at bit 2j + 1 of the chunk's dword)
-  uint32_t *obits = reinterpret_cast<uint32_t *>(tile_o);  // [8 chunks][64 lanes]
-  auto store_out = [&](uint32_t off) {
+  // 128 bins of every stream leave the staging buffer as full 128-byte row segments: lane l of pass k takes chunk l % 8 of
+  // row 8 k + l / 8.  Ordinarily -- all 64 rows exist, the block lies inside the row -- the eight stores are issued by
+  // hand: one wave-uniform base per pass (SGPRs) + one 32-bit lane offset for all of them (the compiler hoists eight 64-bit
+  // lane addresses out of the bin loop otherwise: 16 registers), no per-store exec masks, and the compiler's wait-count
+  // pass, which does not look inside, keeps counting loads only (with stores pending beside loads it waits for vmcnt(0)).
+  const uint32_t st_voff = (uint32_t)(lane >> 3) * a.pitch + (uint32_t)(lane & 7) * 16;
+  const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(lane & 7, lane >> 3);
+  auto store_out = [&](uint32_t off) -> bool {  // true: exactly eight stores went out, issued by hand
+    if (!PERM && nrows == 64 && off + 128 <= a.pitch) {
 #pragma unroll
+      for (int k = 0; k < 8; k++) {
+        // idx(c, 8 k + i) = idx(c, i) ^ 8 k
+        const uint4 v = OutBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
+        const u32x4 w = {v.x, v.y, v.z, v.w};
+        uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
+#if ISSCABAC_DEC_NOSTORE  // timing experiment only
+        if (v.x == 0x12345678u)
+#endif
+        if (kDecNT) asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+      }
+      return true;
+    }
+#pragma unroll 1
     for (int k = 0; k < 8; k++) {
       const uint32_t row = k * 8 + (lane >> 3), c = lane & 7;
-      const uint32_t bits = obits[c * 64 + row];
-      uint4 v;
-      v.x = collected_bytes(bits, 0);
-      v.y = collected_bytes(bits, 1);
-      v.z = collected_bytes(bits, 2);
-      v.w = collected_bytes(bits, 3);
+      const uint4 v = OutBuf::unpack(obuf[OutBuf::idx(c, row)]);
       const uint32_t boff = off + c * 16;
       if (row < nrows && boff < a.pitch) {
         // 32-bit offset from the wave's first row (see Tile::load), or the row of stream wids[row]
@@ -796,130 +1039,193 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         else *reinterpret_cast<uint4 *>(p) = v;
       }
     }
+    return false;
   };
 
   const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
   uint4 pc[Tile::NLD];
-  auto fetch = [&](uint32_t off) {
+  auto fetch = [&](uint32_t off) -> bool {  // true: exactly four loads went out
+    if (off + Tile::T <= a.pitch) {
+      if (PERM) Tile::load_rows_full<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
+      else Tile::load_full<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
+      return true;
+    }
     if (PERM) Tile::load_rows<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
     else Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
+    return false;
   };
   if (nrounds) fetch(0);
   wave_lds_sync();
+#if ISSCABAC_EXP_CLK
+  uint64_t clk_ctx = 0;
+  const uint64_t clk_start = __builtin_amdgcn_s_memtime();
+#endif
   bool have_out = false;
   uint32_t out_off = 0;
+  uint32_t kw = 0;  // vector memory operations issued behind the most recent payload request (wave-uniform)
   for (uint32_t t = 0; t < nrounds; t++) {
+#if ISSCABAC_DEC_ROLLED
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int h = 0; h < 2; h++) {
+#if ISSCABAC_EXP_CLK
+      if (h == 0) {
+        const uint64_t c0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+        clk_ctx += __builtin_amdgcn_s_memtime() - c0;
+      }
+#endif
       Tile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
+#if ISSCABAC_DEC_ROLLED
+#pragma unroll 1
+#endif
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
-        const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output tile
-        uint32_t ob = 0;
+        const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output block
+        uint4 ov = make_uint4(0, 0, 0, 0);
         const bool live = i0 < nmax;  // past the longest stream of the wave: zeros
-        if (live) src.boundary();
+        if (live) {
+          if (kw == 8) src.template boundary_async<8>();
+          else if (kw == 4) src.template boundary_async<4>();
+          else src.template boundary_async<0>();
+          kw = 0;
+        }
         if (j == 0) {
-          // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
-          // anything issued just before the boundary's wait for the payload piece would be waited for as well
+          // global stores and loads go out right BEHIND the boundary's payload request: the next boundary's wait for the
+          // piece lets them stay in flight (WindowDev), the one after that is the first to wait for them
           if (have_out) {
-            store_out(out_off);
-            wave_lds_sync();  // the bit tile is rewritten from here on
+            kw = store_out(out_off) ? 8 : 0;
+            wave_lds_sync();  // the staging buffer is rewritten from here on
             have_out = false;
           }
+#if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's ctx bytes again and again)
           if (h == 1 && t + 1 < nrounds && (t + 1) * Tile::T < nmax)  // nothing to decode past the wave's longest stream
-            fetch((t + 1) * Tile::T);
+            kw = fetch((t + 1) * Tile::T) ? 4 : 0;
+#endif
         }
         if (live) {
-          const uint4 wc = Tile::row_chunk(tile_c, lane, j);
-          const bool full = i0 + 16 <= nmin;
-          const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
-          {
-            // One bit-granular top-up per four bins (sh = 23 afterwards): a context bin takes at most 6 bits and needs
-            // sh >= 7, a bypass bin takes 1 and needs sh >= 8, so three bins never run short and only the fourth is
-            // guarded (wave-uniform, practically never taken); the window is re-based at the chunk boundary and,
-            // wave-uniformly, whenever a lane has fewer than the 24 bits a top-up can take.  ob collects (mps, path)
-            // pairs, turned into bins after the chunk.  `plain` (wave-uniform): every lane decodes 16 context bins.
-            // Otherwise -- bypass bins in the chunk, or streams that end inside it -- every lane takes its own branch
-            // under the exec mask: context bin, bypass bin, or nothing (its output reads 0) once its stream is over.
-            const bool plain = full && !hi;
-            // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed), see k_encode
-            const bool mixed = CM != 2 && full && hi &&
-                               !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0);
-            constexpr uint32_t kIn = CM == 1 ? 0x3F3F3F3Fu : 0x7F7F7F7Fu;
-            // latency-oriented instance (see dec_bin_lat): the state of the next bin is loaded one bin ahead, the
-            // successor forwarded in a register for a repeated context
-            uint32_t at = 0, at_prev = 0, nx_prev = 0, qld = 0;
-            CtxQuad zl = stx.prep4(wc.x);
-            if (LAT && plain) {
-              at = stx.addr32_of(zl, 0);
-              qld = stx.load_at(at);
+        const uint4 wc = Tile::row_chunk(tile_c, lane, j);
+        const bool full = i0 + 16 <= nmin;
+        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
+        // One bit-granular top-up per four bins (sh = 23 afterwards).  Four context or bypass bins shift at most 22 bits
+        // (tests/lane_harness.cpp: lane_max_shift_sum), so the plain and mixed words never run short and carry no guard;
+        // the window is re-based at the chunk boundary and, wave-uniformly, whenever a lane has fewer than the 24 bits a
+        // top-up can take.  oa / ob collect the bins of a word as bytes (cabac_lane.h: dec_bin_out).
+        uint32_t oa = 0, ob = 0;
+        if (full && !hi) {
+          // every lane decodes 16 context bins
+          // latency-oriented instance: the state of the next bin is loaded one bin ahead, the successor forwarded in a
+          // register for a repeated context
+          uint32_t at = 0, at_prev = 0, nx_prev = 0, qld = 0;
+          CtxQuad zl = stx.prep4(wc.x);
+          if (LAT) {
+            at = stx.addr32_of(zl, 0);
+            qld = stx.load_at(at);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check
+            // then covers words 2 and 3
+            if (g == 2) src.ensure(47);
+            dec_topup_nocheck(d, src);
+            if (LAT) {
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const uint32_t q = (4 * g + k > 0 && at == at_prev) ? nx_prev : qld;
+                uint32_t at_next = 0;
+                if (4 * g + k < 15) {
+                  if (k == 3) zl = stx.prep4(word_of(wc, (g + 1) & 3));
+                  at_next = stx.addr32_of(zl, (k + 1) & 3);
+                  qld = stx.load_at(at_next);
+                }
+                nx_prev = dec_bin_nx(d, at, q, stx);
+                if (k == 0) put_out_byte<0>(oa, ob, nx_prev);
+                else if (k == 1) put_out_byte<1>(oa, ob, nx_prev);
+                else if (k == 2) put_out_byte<2>(oa, ob, nx_prev);
+                else put_out_byte<3>(oa, ob, nx_prev);
+                at_prev = at;
+                at = at_next;
+              }
+            } else {
+              const CtxQuad z = stx.prep4(word_of(wc, g));
+              const uint32_t a0 = stx.addr32_of(z, 0), a1 = stx.addr32_of(z, 1), a2 = stx.addr32_of(z, 2), a3 = stx.addr32_of(z, 3);
+              dec_bin_out<0>(d, a0, stx.load_at(a0), stx, oa, ob);
+              dec_bin_out<1>(d, a1, stx.load_at(a1), stx, oa, ob);
+              dec_bin_out<2>(d, a2, stx.load_at(a2), stx, oa, ob);
+              dec_bin_out<3>(d, a3, stx.load_at(a3), stx, oa, ob);
             }
+            set_word(ov, g, out_word(oa, ob));
+          }
+        } else if (CM != 2 && full &&
+                   !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
+          // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed_nx), see k_encode
+          constexpr uint32_t kIn = CM == 1 ? 0x3F3F3F3Fu : 0x7F7F7F7Fu;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-              // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check
-              // then covers words 2 and 3
-              if (g == 2) src.ensure(47);
-              const uint32_t cw = word_of(wc, g);
-              dec_topup_nocheck(d, src);
-              const CtxQuad z = stx.prep4(cw);
-              if (LAT && plain) {
+          for (int g = 0; g < 4; g++) {
+            if (g == 2) src.ensure(47);
+            const uint32_t cw = word_of(wc, g);
+            dec_topup_nocheck(d, src);
+            const CtxQuad zs = stx.prep4(cw & kIn);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  const uint32_t q = (4 * g + k > 0 && at == at_prev) ? nx_prev : qld;
-                  uint32_t at_next = 0;
-                  if (4 * g + k < 15) {
-                    if (k == 3) zl = stx.prep4(word_of(wc, (g + 1) & 3));
-                    at_next = stx.addr32_of(zl, (k + 1) & 3);
-                    qld = stx.load_at(at_next);
-                  }
-                  if (k == 3) dec_guard(d, src, 7);
-                  ob = collect_bin(ob, dec_bin_lat(d, at, q, stx, nx_prev));
-                  at_prev = at;
-                  at = at_next;
-                }
-              } else if (plain) {
+            for (int k = 0; k < 4; k++) {
+              const uint32_t ak = stx.addr32_of(zs, k);
+              const uint32_t nx = dec_bin_mixed_nx(d, byte_bit_mask(cw, k, 7), ak, stx.load_at(ak), stx);
+              if (k == 0) put_out_byte<0>(oa, ob, nx);
+              else if (k == 1) put_out_byte<1>(oa, ob, nx);
+              else if (k == 2) put_out_byte<2>(oa, ob, nx);
+              else put_out_byte<3>(oa, ob, nx);
+            }
+            set_word(ov, g, out_word(oa, ob));
+          }
+        } else {
+          // fixed-probability bins, contexts >= 128 beside bypass bins, or streams that end inside this chunk: every lane
+          // takes its own branch under the exec mask -- context bin, bypass bin, fixed-probability bin, or nothing (its
+          // output reads 0) once its stream is over.  Three bins after a top-up cannot run short (<= 6 bits each); the
+          // fourth is guarded, wave-uniformly.
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  if (k == 3) dec_guard(d, src, 7);
-                  ob = collect_bin(ob, dec_bin_at_mem(d, stx.addr_of(z, k), stx));
-                }
-              } else if (mixed) {
-                const CtxQuad zs = stx.prep4(cw & kIn);
+          for (int g = 0; g < 4; g++) {
+            if (g == 2) src.ensure(47);
+            const uint32_t cw = word_of(wc, g);
+            dec_topup_nocheck(d, src);
+            const CtxQuad z = stx.prep4(cw);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  if (k == 3) dec_guard(d, src, 8);
-                  ob = collect_bin(ob, dec_bin_mixed(d, byte_bit_mask(cw, k, 7), stx.addr_of(zs, k), stx));
-                }
-              } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  if (k == 3) dec_guard(d, src, 8);
-                  uint32_t w = pair_of_bin(0u);
-                  if (full || i0 + 4 * g + k < n) {
-                    const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
-                    if (is_ctx_byte<CM>(cb)) w = dec_bin_at_mem(d, stx.addr_of(z, k), stx);
-                    else if (cb == kBypass || cb == kProbBase + 50u) w = pair_of_bin(dec_bin_ep(d));
-                    else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase))
-                      w = pair_of_bin(dec_bin_prob(d, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]));
-                  }
-                  ob = collect_bin(ob, w);
+            for (int k = 0; k < 4; k++) {
+              if (k == 3) dec_guard(d, src, 8);
+              uint32_t w = 0;
+              if (full || i0 + 4 * g + k < n) {
+                const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
+                if (is_ctx_byte<CM>(cb)) {
+                  const uint32_t ak = stx.addr32_of(z, k);
+                  w = dec_bin_nx(d, ak, stx.load_at(ak), stx);
+                } else if (cb == kBypass || cb == kProbBase + 50u) {
+                  w = dec_bin_ep(d);
+                } else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase)) {
+                  w = dec_bin_prob(d, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]);
                 }
               }
+              if (k == 0) put_out_byte<0>(oa, ob, w);
+              else if (k == 1) put_out_byte<1>(oa, ob, w);
+              else if (k == 2) put_out_byte<2>(oa, ob, w);
+              else put_out_byte<3>(oa, ob, w);
             }
-            ob = pairs_to_bins(ob);
+            set_word(ov, g, out_word(oa, ob));
           }
         }
-        obits[cidx * 64 + lane] = ob;
+        }
+        obuf[OutBuf::idx(cidx, lane)] = OutBuf::pack(ov);
       }
       wave_lds_sync();
     }
-    if ((t & 1u) == 1u || t + 1 == nrounds) {  // a 128-bin output tile is complete (or the stream ends)
+    if ((t & 1u) == 1u || t + 1 == nrounds) {  // a 128-bin output block is complete (or the stream ends)
       have_out = true;
       out_off = (t & ~1u) * Tile::T;
       if (t + 1 == nrounds && (t & 1u) == 0) {
-        // odd number of rounds: the upper half of the last tile was never written
-        for (int c = 4; c < 8; c++) obits[c * 64 + lane] = 0;
+        // odd number of rounds: the upper half of the last block was never written
+        for (uint32_t c = 4; c < 8; c++) obuf[OutBuf::idx(c, lane)] = 0;
         wave_lds_sync();
       }
     }
@@ -931,6 +1237,12 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     const uint32_t sk = (uint32_t)first & 3u;
     const uint8_t *p = a.payload + first;
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
+#if ISSCABAC_EXP_CLK
+    const uint64_t tot = __builtin_amdgcn_s_memtime() - clk_start;
+    if (lane == 0) a.status[s] = (uint32_t)src.clk_await;
+    if (lane == 1) a.status[s] = (uint32_t)clk_ctx;
+    if (lane == 2) a.status[s] = (uint32_t)tot;
+#endif
   }
 }
 
@@ -1175,7 +1487,7 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<CM, PERM>();
+  const size_t lds = kDecTabBytes + waves_per_block(CM) * DecLds<CM, PERM>::BYTES;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

@@ -756,6 +756,151 @@ CABAC_HD uint32_t dec_bin_row_q(DecCore &d, Addr at, uint32_t q, States &st, uin
   return q + (uint32_t)mps_path;
 #endif
 }
+// ------------------------------------------------------------------------------------------------
+// The decoder's steps with the decoded bin riding in bit 0 of the successor byte.
+// A doubled state q = (state << 2) | (mps << 1) is even, so bit 0 of the state byte is free: the decoder's entries hold
+// `successor | bin decoded on that path` (dec_entry_hi_out), the byte picked by the decision is at once the value the state
+// image takes and -- its bit 0 -- the output.  No (mps, path) pair, no collect, no expansion to bytes afterwards: the
+// picked byte lands in its place of the output word (dec_bin_out), garbage above bit 0 is masked off when the tile leaves.
+// State bytes in the image therefore carry a stale bin in bit 0 and every decoder lookup goes by the RAW byte:
+// States::entry_raw(qb) -> the 8-byte entry of state qb >> 1 = row | dec_entry_hi_out << 32 (256 entries, odd ones
+// duplicate their even neighbour); the mps is bit 1 as ever.
+// ------------------------------------------------------------------------------------------------
+// high word of the raw-byte entry of packed state ps (= qb >> 1, mps = ps & 1) from its two successors:
+// byte 0 = LPS path: successor | (mps ^ 1), byte 1 = MPS path: successor | mps
+constexpr uint32_t dec_entry_hi_out(uint32_t ps, uint32_t succ_lps, uint32_t succ_mps) {
+  return (succ_lps | ((ps & 1u) ^ 1u)) | (succ_mps | (ps & 1u)) << 8;
+}
+// Bin K of a word (0..3) into the output pair: bins 0 and 1 start oa and ob (byte 0 = the low byte of w, the rest 0), bins 2
+// and 3 add byte 2, everything else preserved (one SDWA move on the device)
+template <int K>
+CABAC_HD void put_out_byte(uint32_t &oa, uint32_t &ob, uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (K == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(oa) : "v"(w));
+  else if (K == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(ob) : "v"(w));
+  else if (K == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(oa) : "v"(w));
+  else asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(ob) : "v"(w));
+#else
+  uint32_t &o = (K & 1) ? ob : oa;
+  if (K & 2) o = (o & ~0x00FF0000u) | ((w & 0xFFu) << 16);
+  else o = w & 0xFFu;
+#endif
+}
+// the four bytes of a word's bins in stream order: oa = (bin 0, -, bin 2, -), ob = (bin 1, -, bin 3, -)
+CABAC_HD uint32_t out_word(uint32_t oa, uint32_t ob) { return perm_b32(ob, oa, 0x06020400u); }
+
+// Bin K of a word (0..3) on the raw-byte entry, the picked successor byte written straight into the output pair:
+// subtract-with-borrow decides, three selects on the borrow.  13 VALU + 3 LDS operations per bin with the state address.
+// States: entry_raw(qb), store_at(at, x) (stores the low byte of x), store_at_hi(at, x) (stores byte 2 of x).
+// Needs sh >= the bin's own shift; four context bins after a top-up to 23 never run short (they shift <= 22 bits in
+// total: tests/lane_harness.cpp lane_max_shift_sum), so the kernels' plain words carry no guard.
+template <int K, class States, class Addr>
+CABAC_HD void dec_bin_out(DecCore &d, Addr at, uint32_t qb, States &st, uint32_t &oa, uint32_t &ob) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lps = lps_of((uint32_t)ent, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  uint32_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t &o = (K & 1) ? ob : oa;
+  uint32_t diff;
+  // bins 0 and 1 of a word start their output register (the other bytes read 0), bins 2 and 3 add byte 2 to it
+#define ISSCABAC_DEC_OUT(SEL, UNUSED, OC)                                                                              \
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"                                                                           \
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"   \
+      "v_cndmask_b32_e32 %2, %6, %7, vcc\n\t"                                                                          \
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"                                                                              \
+      : "=&v"(diff), OC(o), "=&v"(r)                                                                                   \
+      : "v"(d.v), "v"(scaled), "v"((uint32_t)(ent >> 32)), "v"(lps), "v"(rmps)                                         \
+      : "vcc")
+  if (K & 2) {
+    ISSCABAC_DEC_OUT("BYTE_2", "UNUSED_PRESERVE", "+v");
+    st.store_at_hi(at, o);
+  } else {
+    ISSCABAC_DEC_OUT("BYTE_0", "UNUSED_PAD", "=&v");
+    st.store_at(at, o);
+  }
+#undef ISSCABAC_DEC_OUT
+  d.v = diff;
+#else
+  const bool mps_path = d.v < scaled;
+  const uint32_t nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  put_out_byte<K>(oa, ob, nx);
+  st.store_at(at, nx);
+  r = mps_path ? rmps : lps;
+  d.v = mps_path ? d.v : d.v - scaled;
+#endif
+  const uint32_t n = clz32(r) - 23u;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+}
+// The same step handing the picked byte back in a register of its own (clean: successor | bin): for the paths that
+// forward it (latency-oriented instance) or run under a lane's own exec mask (general path).  One instruction more.
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_nx(DecCore &d, Addr at, uint32_t qb, States &st) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lps = lps_of((uint32_t)ent, d.range);
+  const uint32_t rmps = d.range - lps;
+  const uint32_t scaled = rmps << d.sh;
+  uint32_t r, nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t diff;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %7, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(d.v), "v"(scaled), "v"((uint32_t)(ent >> 32)), "v"(lps), "v"(rmps)
+      : "vcc");
+  d.v = diff;
+#else
+  const bool mps_path = d.v < scaled;
+  nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  r = mps_path ? rmps : lps;
+  d.v = mps_path ? d.v : d.v - scaled;
+#endif
+  st.store_at(at, nx);
+  const uint32_t n = clz32(r) - 23u;
+  d.range = r << n;
+  d.sh -= (int32_t)n;
+  return nx;
+}
+// ... and for words that mix context-coded and bypass bins (see dec_bin_mixed below; mb = ~0 for a bypass bin): a bypass
+// lane decides against the whole range one bit further down, picks its bin out of the constant 0x0001 (byte 0: not below
+// = 1, byte 1: below = 0) instead of the entry and writes its state byte back unchanged.  Returns the picked byte.
+template <class States, class Addr>
+CABAC_HD uint32_t dec_bin_mixed_nx(DecCore &d, uint32_t mb, Addr at, uint32_t qb, States &st) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lps = lps_of((uint32_t)ent, d.range);
+  const uint32_t rmps = d.range - lps;
+  const int32_t sh = d.sh + (int32_t)mb;  // mb = -1: the bypass bin's bit
+  const uint32_t scaled = select_mask(mb, d.range, rmps) << sh;
+  const uint32_t hi = select_mask(mb, 0x0001u, (uint32_t)(ent >> 32));
+  const uint32_t rl = select_mask(mb, d.range, lps), rm = select_mask(mb, d.range, rmps);
+  uint32_t r, nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t diff;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %7, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(d.v), "v"(scaled), "v"(hi), "v"(rl), "v"(rm)
+      : "vcc");
+  d.v = diff;
+#else
+  const bool below = d.v < scaled;
+  nx = (hi >> (below ? 8 : 0)) & 0xFFu;
+  r = below ? rm : rl;
+  d.v = below ? d.v : d.v - scaled;
+#endif
+  st.store_at(at, select_mask(mb, qb, nx));
+  const uint32_t n = clz32(r) - 23u;  // 0 for a bypass bin: its range is normalised
+  d.range = r << n;
+  d.sh = sh - (int32_t)n;
+  return nx;
+}
+
 // The decoder's select-based step for chunks that mix context-coded and bypass bins (see enc_bin_mixed_acc): a bypass
 // bin compares the value with the whole range one bit further down (ref: CABAC_ArithmeticDecoder.cpp:288-331) and leaves
 // range and state alone.  Returns the (mps, path) pair of dec_bin_at_mem; a bypass bin reports mps 0, which makes
@@ -1054,9 +1199,11 @@ struct WindowSrc {
     cend = (bpos & ~7u) + 64u;
   }
   // make the piece in flight the piece in use (waits for its load)
-  CABAC_HD void adopt() {
-    ph = __builtin_bswap64(nlo);
-    uint64_t pl = __builtin_bswap64(nhi);
+  CABAC_HD void adopt() { adopt_from(__builtin_bswap64(nlo), __builtin_bswap64(nhi)); }
+  // ... from the piece's two halves as big-endian numbers (the decode kernel converts them as it takes them out of the
+  // registers the load landed in)
+  CABAC_HD void adopt_from(uint64_t h, uint64_t pl) {
+    ph = h;
     if (CABAC_WAVE_ANY(npos + 16u > len)) {  // only near the stream's end
       const uint32_t k = len > npos ? len - npos : 0u;  // real bytes in the piece
       if (k < 16u) {

@@ -52,6 +52,12 @@ struct HostStates {
     const uint32_t b0 = by_path ? next_path_mem(q) : next_mem(q), b1 = by_path ? next_path_mem(q + 1u) : next_mem(q | 1u);
     return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(by_path ? (b0 | b1 << 8) : enc_entry_hi(q >> 1, b0, b1)) << 32;
   }
+  // the decoder's entry by RAW state byte (LdsStates::entry_raw): bit 0 of the byte is a stale bin
+  uint64_t entry_raw(uint32_t qb) const {
+    const uint32_t q = qb & ~1u;
+    return (uint64_t)kLpsRow[q >> 2] | (uint64_t)dec_entry_hi_out(q >> 1, next_path_mem(q), next_path_mem(q + 1u)) << 32;
+  }
+  void store_at_hi(uint32_t a, uint32_t x) { cm[a] = (uint8_t)(x >> 16); }
   uint32_t next_path_mem(uint32_t q_plus_path) const {  // path 1 = MPS
     return (next_state_entry16(q_plus_path >> 1, kTransLps[q_plus_path >> 2]) >> (8 * (1u - (q_plus_path & 1u)))) & 0xFFu;
   }
@@ -113,6 +119,30 @@ uint32_t lane_max_shift_sum(int k) {
   for (int step = 0; step < k; step++, cur ^= 1) {
     for (uint32_t r = 256; r <= 510; r++) {
       uint32_t b = 0;
+      for (uint32_t state = 0; state <= 62; state++) {
+        const uint32_t lps = (kLpsRow[state] >> (8 * ((r >> 6) & 3u))) & 0xFFu, rmps = r - lps;
+        const uint32_t nl = clz32(lps) - 23u, nm = clz32(rmps) - 23u;
+        const uint32_t vl = nl + best[cur][lps << nl], vm = nm + best[cur][rmps << nm];
+        b = vl > b ? vl : b;
+        b = vm > b ? vm : b;
+      }
+      best[cur ^ 1][r] = b;
+    }
+  }
+  uint32_t m = 0;
+  for (uint32_t r = 256; r <= 510; r++) m = best[cur][r] > m ? best[cur][r] : m;
+  return m;
+}
+
+// ... the same with bypass bins allowed anywhere in the run (one bit each, the range stays): the bound behind the decode
+// kernel's unguarded mixed words
+uint32_t lane_max_shift_sum_ep(int k) {
+  static uint32_t best[2][511];
+  for (uint32_t r = 256; r <= 510; r++) best[0][r] = 0;
+  int cur = 0;
+  for (int step = 0; step < k; step++, cur ^= 1) {
+    for (uint32_t r = 256; r <= 510; r++) {
+      uint32_t b = 1 + best[cur][r];  // a bypass bin
       for (uint32_t state = 0; state <= 62; state++) {
         const uint32_t lps = (kLpsRow[state] >> (8 * ((r >> 6) & 3u))) & 0xFFu, rmps = r - lps;
         const uint32_t nl = clz32(lps) - 23u, nm = clz32(rmps) - 23u;
@@ -333,6 +363,125 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
   return status;
 }
 
+
+// The decode kernel's chunk structure (cabac_kernels.hip: k_decode) on one stream: 16-bin chunks classified like the
+// kernel does -- plain (16 context bins: dec_bin_out, no guard), mixed (context + bypass bins: dec_bin_mixed_nx, no guard),
+// general (anything else: per-bin branches, the fourth bin of a word guarded) --, state bytes with the stale bin in bit 0,
+// output bytes masked with 1 at the end like store_out.  lat: the latency-oriented instance's order (state one bin ahead,
+// successor forwarded for a repeated context).  Returns the status word, or 0xDEADxxxx if an unguarded bin ran short.
+uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx,
+                                uint32_t n, const uint8_t *ctx_init, int nctx, int lat, uint8_t *bins_out,
+                                uint8_t *ctx_final, uint32_t *path_counts /* [plain, mixed, general] chunks */) {
+  const int cm = nctx <= 64 ? 1 : nctx <= 128 ? 3 : 2;
+  auto is_ctx = [&](uint32_t c) { return cm == 1 ? c < 64u : cm == 3 ? c < 128u : c != 0xFFu; };
+  auto is_prob = [&](uint32_t c) { return cm != 2 && is_prob_byte(c); };
+  HostStates st;
+  st.init(ctx_init, nctx);
+  const uint64_t abase = start & ~3ull;
+  const uint32_t skew = (uint32_t)(start - abase);
+  WindowSrc<HostMem> src;
+  src.mem = HostMem{buf + abase, total - abase, nullptr, nullptr};
+  src.len = skew + len;
+  src.start(skew);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  uint32_t bad = 0;
+  for (uint32_t i0 = 0; i0 < n; i0 += 16) {
+    src.boundary();
+    uint8_t cb[16];
+    for (uint32_t k = 0; k < 16; k++) cb[k] = i0 + k < n ? ctx[i0 + k] : 0;  // (the kernel reads whatever the row holds)
+    const bool full = i0 + 16 <= n;
+    bool hi = false, odd = false;
+    for (uint32_t k = 0; k < 16; k++) {
+      hi |= (cb[k] & (cm == 1 ? 0xC0u : 0x80u)) != 0;
+      odd |= (cb[k] & 0x80u) && cb[k] != 0xFFu;
+    }
+    uint32_t ow[4] = {0, 0, 0, 0}, oa = 0, ob = 0;
+    if (full && !hi) {
+      if (path_counts) path_counts[0]++;
+      uint32_t at = cb[0], at_prev = 0, nx_prev = 0, qld = lat ? st.load_at(at) : 0;
+      for (int g = 0; g < 4; g++) {
+        if (g == 2) src.ensure(47);
+        if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
+        dec_topup_nocheck(d, src);
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * g + k;
+          if (lat) {
+            const uint32_t q = (i > 0 && at == at_prev) ? nx_prev : qld;
+            uint32_t at_next = 0;
+            if (i < 15) {
+              at_next = cb[i + 1];
+              qld = st.load_at(at_next);
+            }
+            nx_prev = dec_bin_nx(d, at, q, st);
+            if (k == 0) put_out_byte<0>(oa, ob, nx_prev);
+            else if (k == 1) put_out_byte<1>(oa, ob, nx_prev);
+            else if (k == 2) put_out_byte<2>(oa, ob, nx_prev);
+            else put_out_byte<3>(oa, ob, nx_prev);
+            at_prev = at;
+            at = at_next;
+          } else {
+            const uint32_t a = cb[i];
+            if (k == 0) dec_bin_out<0>(d, a, st.load_at(a), st, oa, ob);
+            else if (k == 1) dec_bin_out<1>(d, a, st.load_at(a), st, oa, ob);
+            else if (k == 2) dec_bin_out<2>(d, a, st.load_at(a), st, oa, ob);
+            else dec_bin_out<3>(d, a, st.load_at(a), st, oa, ob);
+          }
+          if (d.sh < 0) bad = 0xDEAD0000u | (i0 + i);
+        }
+        ow[g] = out_word(oa, ob);
+      }
+    } else if (cm != 2 && full && !odd) {
+      if (path_counts) path_counts[1]++;
+      const uint32_t in = cm == 1 ? 0x3Fu : 0x7Fu;
+      for (int g = 0; g < 4; g++) {
+        if (g == 2) src.ensure(47);
+        if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
+        dec_topup_nocheck(d, src);
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = cb[4 * g + k], a = c & in;
+          const uint32_t nx = dec_bin_mixed_nx(d, (c & 0x80u) ? ~0u : 0u, a, st.load_at(a), st);
+          if (k == 0) put_out_byte<0>(oa, ob, nx);
+          else if (k == 1) put_out_byte<1>(oa, ob, nx);
+          else if (k == 2) put_out_byte<2>(oa, ob, nx);
+          else put_out_byte<3>(oa, ob, nx);
+          if (d.sh < 0) bad = 0xDEAD0000u | (i0 + 4 * g + k);
+        }
+        ow[g] = out_word(oa, ob);
+      }
+    } else {
+      if (path_counts) path_counts[2]++;
+      for (int g = 0; g < 4; g++) {
+        if (g == 2) src.ensure(47);
+        if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
+        dec_topup_nocheck(d, src);
+        for (int k = 0; k < 4; k++) {
+          if (k == 3) dec_guard(d, src, 8);
+          uint32_t w = 0;
+          if (i0 + 4 * g + k < n) {
+            const uint32_t c = cb[4 * g + k];
+            if (is_ctx(c)) w = dec_bin_nx(d, c, st.load_at(c), st);
+            else if (c == kBypass || c == kProbBase + 50u) w = dec_bin_ep(d);
+            else if (is_prob(c) && prob_valid(c - kProbBase)) w = dec_bin_prob(d, c - kProbBase, kProbRow[prob_row_index(c - kProbBase)]);
+            if (d.sh < 0) bad = 0xDEAD0000u | (i0 + 4 * g + k);
+          }
+          if (k == 0) put_out_byte<0>(oa, ob, w);
+          else if (k == 1) put_out_byte<1>(oa, ob, w);
+          else if (k == 2) put_out_byte<2>(oa, ob, w);
+          else put_out_byte<3>(oa, ob, w);
+        }
+        ow[g] = out_word(oa, ob);
+      }
+    }
+    for (uint32_t k = 0; k < 16 && i0 + k < n; k++) bins_out[i0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 1u);
+  }
+  if (bad) return bad;
+  const uint8_t *p = buf + start;
+  const uint32_t status = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
+  if (ctx_final) st.final_packed(ctx_final, nctx);
+  return status;
+}
 
 // one stream through the reference-formulation decoder (RefDec): what the engine uses for streams starting with 0xFF
 uint32_t lane_decode_stream_ref(const uint8_t *payload, uint32_t len, const uint8_t *ctx, uint32_t n, const uint8_t *ctx_init,

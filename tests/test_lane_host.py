@@ -29,6 +29,11 @@ def lane():
     L.lane_decode_stream.restype = C.c_uint32
     L.lane_decode_stream.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
                                      C.c_int, u8p, u8p, C.POINTER(C.c_uint32)]
+    L.lane_decode_stream_out.restype = C.c_uint32
+    L.lane_decode_stream_out.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
+                                         u8p, u8p, C.POINTER(C.c_uint32)]
+    L.lane_max_shift_sum_ep.restype = C.c_uint32
+    L.lane_max_shift_sum_ep.argtypes = [C.c_int]
     L.lane_word_shift_max.restype = C.c_uint32
     L.lane_max_shift_sum.restype = C.c_uint32
     L.lane_max_shift_sum.argtypes = [C.c_int]
@@ -72,6 +77,20 @@ def lane_decode(L, payload, ctx, init, chunk=16, group=4, pad_front=0, pad_back=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
+def lane_decode_out(L, payload, ctx, init, lat=0, pad_front=0, pad_back=0, fill=0xA5):
+    """the decode kernel's own chunk structure (lane_harness.cpp: lane_decode_stream_out)"""
+    payload = np.ascontiguousarray(payload, np.uint8)
+    buf = np.concatenate([np.full(pad_front, fill, np.uint8), payload, np.full(pad_back, fill, np.uint8)])
+    ctx = np.ascontiguousarray(ctx, np.uint8)
+    init = np.ascontiguousarray(init, np.uint8)
+    bins = np.full(max(1, ctx.size), 7, np.uint8)
+    fin = np.zeros(max(1, init.size), np.uint8)
+    cnt = (C.c_uint32 * 3)()
+    st = L.lane_decode_stream_out(_p(buf), buf.size, pad_front, payload.size, _p(ctx), ctx.size, _p(init), init.size,
+                                  lat, _p(bins), _p(fin), cnt)
+    return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
+
+
 @pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 16, 17, 18, 19, 20])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
@@ -89,6 +108,70 @@ def test_decode_golden(lane, golden, pads):
         assert st == 0, s["name"]
         assert (bins == s["bins_a"]).all(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
+
+
+@pytest.mark.parametrize("pads", [(0, 0, 0), (3, 0, 1), (1, 40, 0), (2, 5, 1), (7, 3, 0)])
+def test_decode_out_golden(lane, golden, pads):
+    """the kernel's chunk structure with the bin riding in bit 0 of the state byte (dec_bin_out / _nx / _mixed_nx)"""
+    for s in golden["streams"]:
+        bins, st, fin, _ = lane_decode_out(lane, s["payload_a"], s["ctx_a"], s["ctx_init_a"], lat=pads[2],
+                                           pad_front=pads[0], pad_back=pads[1])
+        assert st == 0, s["name"]
+        assert (bins == s["bins_a"]).all(), s["name"]
+        assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
+
+
+def test_decode_out_fuzz_and_corrupt(lane, oracle):
+    """... fuzzed against the oracle: plain, mixed and general chunks, fixed-probability bins, corrupted payloads (bins and
+    status words must be the oracle's), and no unguarded bin ever short of bits (0xDEAD.. would come back)."""
+    assert [lane.lane_max_shift_sum_ep(k) for k in (1, 2, 3, 4)] == [6, 11, 17, 22]
+    rng = np.random.default_rng(2024)
+    paths = np.zeros(3, np.int64)
+    flagged = 0
+    for it in range(600):
+        n = int(rng.integers(0, 2500))
+        Cn = int(rng.choice([1, 3, 4, 23, 64, 100, 128, 200, 255]))
+        init = rng.integers(0, 126, Cn).astype(np.uint8)
+        ctx = rng.integers(0, Cn, n).astype(np.uint8)
+        kind = it % 5
+        if kind == 1:
+            ctx[rng.random(n) < 0.5] = 0xFF
+        elif kind == 2 and Cn <= 128:  # fixed-probability bins and bypass bins among the context bins
+            m = rng.random(n)
+            pp = rng.integers(1, 100, n)
+            pp[(pp >= 46) & (pp <= 54)] = 50
+            ctx = np.where(m < 0.2, 155 + pp, np.where(m < 0.3, 0xFF, ctx)).astype(np.uint8)
+        elif kind == 3:  # the worst words: states 58..62, LPS runs
+            init = (2 * rng.integers(58, 63, Cn) + rng.integers(0, 2, Cn)).astype(np.uint8)
+        bins = rng.integers(0, 2, n).astype(np.uint8)
+        if kind == 3:
+            bins = np.where(rng.random(n) < 0.85, 1 - (init & 1)[np.minimum(ctx, Cn - 1)], bins).astype(np.uint8)
+        elif kind != 4:
+            skew = rng.random(256) ** (1 + it % 4)
+            bins = (rng.random(n) < skew[ctx]).astype(np.uint8)
+        want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
+        for lat in (0, 1):
+            dec, st, dfin, cnt = lane_decode_out(lane, want, ctx, init, lat=lat, pad_front=int(rng.integers(0, 9)),
+                                                 pad_back=int(rng.integers(0, 20)))
+            assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes(), (it, lat, hex(st))
+        paths += cnt
+        if n >= 8 and it % 2:
+            bad = want.copy()
+            mode = it % 3
+            if mode == 0:
+                bad[rng.integers(0, bad.size)] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                bad = bad[:max(1, bad.size - int(rng.integers(1, 4)))]
+            else:
+                bad = np.concatenate([bad, rng.integers(0, 256, 3).astype(np.uint8)])
+            if bad[0] == 0xFF:
+                continue  # the engine sends these to the reference-formulation decoder (RefDec)
+            wdec, wst = oracle.decode_stream(bad, ctx, init)
+            got, st, _, _ = lane_decode_out(lane, bad, ctx, init, lat=it % 2, pad_front=2, pad_back=int(rng.integers(0, 30)))
+            assert st == wst and (got == wdec).all(), (it, hex(st), hex(wst))
+            flagged += st != 0
+    assert (paths > 50).all(), paths  # plain, mixed and general chunks were all exercised
+    assert flagged > 50
 
 
 def test_fuzz_vs_oracle(lane, oracle):
