@@ -48,6 +48,9 @@
 #ifndef ISSCABAC_ENC_ROLLED
 #define ISSCABAC_ENC_ROLLED 0
 #endif
+#ifndef ISSCABAC_EXP_INPLACE
+#define ISSCABAC_EXP_INPLACE 0
+#endif
 #ifndef ISSCABAC_EXP_CLK  // stall accounting of the decode kernel into the status words (tools/dec_stalls.py)
 #define ISSCABAC_EXP_CLK 0
 #endif
@@ -166,29 +169,6 @@ struct TileT {
       const uint32_t voff = row * pitch + boff;
       if (NT) r[k] = boff < pitch ? nt_load16(rows + voff) : make_uint4(0, 0, 0, 0);
       else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(rows + voff) : make_uint4(0, 0, 0, 0);
-    }
-  }
-  // The same when the whole round lies inside the rows (off + T <= pitch): exactly NLD load instructions, no
-  // predicate -- the decode kernel counts on that (WindowDev::boundary_async)
-  template <bool NT = false>
-  __device__ static __forceinline__ void load_full(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch,
-                                                   uint32_t off, int lane) {
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const uint32_t row = min(row_of(k, lane), nrows - 1u);
-      const uint32_t voff = row * pitch + off + ch_of(lane) * 16;
-      if (NT) r[k] = nt_load16(rows + voff);
-      else r[k] = *reinterpret_cast<const uint4 *>(rows + voff);
-    }
-  }
-  template <bool NT = false>
-  __device__ static __forceinline__ void load_rows_full(uint4 (&r)[NLD], const uint8_t *base, const uint32_t (&rid)[NLD], uint32_t pitch,
-                                                        uint32_t off, int lane) {
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const uint8_t *p = base + ((uint64_t)rid[k] * pitch + off + ch_of(lane) * 16);
-      if (NT) r[k] = nt_load16(p);
-      else r[k] = *reinterpret_cast<const uint4 *>(p);
     }
   }
   // The same for a wave whose 64 streams are NOT neighbours in the array (length-bucketed launches, cabac_order.hip):
@@ -797,99 +777,6 @@ struct DevMem {
   }
 };
 
-// The decode kernel's bit source: WindowSrc with the payload piece fetched and awaited BY HAND.
-// Every chunk boundary waits for the piece requested one boundary earlier.  vmcnt counts loads and stores alike and
-// completes in order, and the compiler's wait in front of the piece's first use is vmcnt(0) (the requests sit in
-// branches), so the ctx loads and the output stores issued right behind a boundary had one chunk -- 16 bins -- to
-// complete before the wave stalled on them: measured, 1.0 ms of a 3.5 ms launch (bench.py with the loads / stores taken out
-// one at a time).  Here the request is inline assembly under an exec mask (always exactly one instruction, no branch), the
-// piece in flight (X) is named by nothing but the wait in front of adopt, and that wait allows the K operations issued
-// behind the request -- 8 output stores or 4 ctx loads, counted exactly by the kernel -- to stay in flight: they get two
-// chunks.  tools/check_inflight_regs.py checks in the compiled code that nothing touches X between request and wait.
-struct WindowDev : WindowSrc<DevMem> {
-  // The piece in flight -- bytes [npos, npos + 16) as loaded -- lives in v[124:127] and is no C++ value at all: a value
-  // the register allocator knows of gets copied (measured: out of the load's destination right behind the request, and
-  // back in front of the wait), and a copy reads registers whose data has not arrived.  Only the assembly below names
-  // these four registers -- they are in its clobber lists, so the compiler keeps nothing in them across it -- and
-  // tools/check_inflight_regs.py fails the build's test if any other instruction of a decode kernel does.
-  __device__ __forceinline__ void request() {
-    const uint32_t np = byte_pos() & ~3u;
-    const bool want = bpos - pbit >= ISSCABAC_PREFETCH_BITS;
-    const bool fast = want && (int32_t)np <= mem.lim;
-    const uint64_t mask = __builtin_amdgcn_ballot_w64(fast);
-    const uint8_t *addr = mem.payload + (mem.abase + np);
-    uint64_t sv;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\t"
-                 "global_load_dwordx4 v[124:127], %2, off\n\t"
-                 "s_mov_b64 exec, %0"
-                 : "=&s"(sv)
-                 : "s"(mask), "v"(addr)
-                 : "memory", "v124", "v125", "v126", "v127");
-    if (want) npos = np;
-    if (wave_any(want && !fast)) {
-      // the last 16 bytes of the whole payload buffer (one wave per launch at most): everything lands first, then the
-      // lanes concerned read byte by byte
-      asm volatile("s_waitcnt vmcnt(0)" : : : "memory", "v124", "v125", "v126", "v127");
-      if (want && !fast) {
-        const DevMem::Pair r = DevMem::load16_tail(mem.payload, mem.total, mem.abase + np);
-        asm volatile("v_mov_b32 v124, %0\n\t"
-                     "v_mov_b32 v125, %1\n\t"
-                     "v_mov_b32 v126, %2\n\t"
-                     "v_mov_b32 v127, %3"
-                     :
-                     : "v"((uint32_t)r.lo), "v"((uint32_t)(r.lo >> 32)), "v"((uint32_t)r.hi), "v"((uint32_t)(r.hi >> 32))
-                     : "v124", "v125", "v126", "v127");
-      }
-    }
-  }
-  // waits for the piece and takes it out byte-swapped (what adopt() starts with).  K: vector memory operations issued
-  // behind the most recent request() that may stay in flight
-  template <int K>
-  __device__ __forceinline__ void await_adopt() {
-    uint32_t hh, hl, lh, ll;
-    asm volatile("s_waitcnt vmcnt(%4)\n\t"
-                 "v_perm_b32 %0, 0, v124, %5\n\t"
-                 "v_perm_b32 %1, 0, v125, %5\n\t"
-                 "v_perm_b32 %2, 0, v126, %5\n\t"
-                 "v_perm_b32 %3, 0, v127, %5"
-                 : "=&v"(hh), "=&v"(hl), "=&v"(lh), "=&v"(ll)
-                 : "n"(K), "s"(0x00010203u)
-                 : "memory", "v124", "v125", "v126", "v127");
-    adopt_from((uint64_t)hh << 32 | hl, (uint64_t)lh << 32 | ll);
-  }
-  __device__ __forceinline__ void start_async(uint32_t first_byte) {
-    bpos = 8u * first_byte;
-    cend = bpos;
-    cur = 0;
-    ph = pl1 = 0;
-    asm volatile("v_mov_b32 v124, 0\n\t"
-                 "v_mov_b32 v125, 0\n\t"
-                 "v_mov_b32 v126, 0\n\t"
-                 "v_mov_b32 v127, 0"
-                 :
-                 :
-                 : "v124", "v125", "v126", "v127");
-    pbit = bpos - ISSCABAC_PREFETCH_BITS;  // (so that request() wants a piece)
-    request();
-    pbit = 8u * npos;
-  }
-#if ISSCABAC_EXP_CLK
-  uint64_t clk_await = 0;
-#endif
-  template <int K>
-  __device__ __forceinline__ void boundary_async() {
-#if ISSCABAC_EXP_CLK
-    const uint64_t c0 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(K) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-    clk_await += __builtin_amdgcn_s_memtime() - c0;
-#endif
-    await_adopt<K>();
-    rebase();
-    request();
-  }
-};
-
 struct DecArgs {
   const uint8_t *payload, *ctx;
   const uint64_t *offsets;
@@ -912,15 +799,26 @@ struct DecArgs {
 #ifndef ISSCABAC_DEC_NOSTORE
 #define ISSCABAC_DEC_NOSTORE 0
 #endif
-constexpr bool kDecNT = ISSCABAC_DEC_NT != 0;  // decode kernel: ctx loads and bin stores are streaming
+#ifndef ISSCABAC_DEC_NT_ST
+#define ISSCABAC_DEC_NT_ST ISSCABAC_DEC_NT
+#endif
+constexpr bool kDecNT = ISSCABAC_DEC_NT != 0;  // decode kernel: ctx loads are streaming
+constexpr bool kDecNTst = ISSCABAC_DEC_NT_ST != 0;  // ... and the bin stores
 
 // LDS of the decode kernel: the raw-byte entries (256 x 8 bytes, cabac_lane.h: dec_bin_out) at 0, then per wave the
 // context states, the round tile and (bucketed launches) the wave's stream ids
 constexpr int kDecTabBytes = 2048;
+#ifndef ISSCABAC_DEC_LPR
+#define ISSCABAC_DEC_LPR 8
+#endif
+// the decode kernel's input tile (its one input array: ctx): 128-byte row segments where the registers allow it -- the
+// plain instances; the latency-oriented and the bucketed instances keep 64-byte segments (16 registers instead of 32)
+template <bool LAT, bool PERM>
+using DecTile = TileT<(LAT || PERM) ? 4 : ISSCABAC_DEC_LPR>;
 template <int CM, bool PERM>
 struct DecLds {
   static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
-  static constexpr uint32_t TILE = Tile::H * 64;  // the ctx half tile
+  static constexpr uint32_t TILE = 32 * 64;  // the ctx half tile (TileT::H bytes per stream)
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
   static constexpr uint32_t BYTES = SB + TILE + OutBuf::BYTES + IDS;
 };
@@ -950,6 +848,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   if (s0 >= a.S) return;
 
   using DL = DecLds<CM, PERM>;
+  using DTile = DecTile<LAT, PERM>;
+  static_assert(DTile::H * 64 == DL::TILE, "half tile");
   uint8_t *wbase = smem + kDecTabBytes + wib * DL::BYTES;
   uint8_t *tile_c = wbase + DL::SB;
   uint32_t *obuf = reinterpret_cast<uint32_t *>(tile_c + DL::TILE);
@@ -958,12 +858,12 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream decoded here
-  uint32_t rid[Tile::NLD] = {0, 0, 0, 0};
+  uint32_t rid[DTile::NLD] = {};
   if (PERM) {
     const_cast<uint32_t *>(wids)[lane] = (uint32_t)s;
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < Tile::NLD; k++) rid[k] = wids[Tile::row_of(k, lane)];
+    for (int k = 0; k < DTile::NLD; k++) rid[k] = wids[DTile::row_of(k, lane)];
   }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
@@ -987,14 +887,14 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
   const uint64_t abase = start & ~3ull;
   const uint32_t skew = (uint32_t)(start - abase);
-  WindowDev src;
+  WindowSrc<DevMem> src;
   src.mem.payload = a.payload;
   src.mem.total = a.payload_bytes;
   src.mem.abase = abase;
   src.mem.lim = a.payload_bytes >= abase + 16 ? (int32_t)min(a.payload_bytes - 16 - abase, (uint64_t)0x7FFFFFFF) : -1;
   src.len = skew + len;
-  src.start_async(skew);
-  src.template boundary_async<0>();
+  src.start(skew);
+  src.boundary();
   DecCore d;
   dec_start(d, src);
   // v now holds the stream's first four bytes.  A first byte of 0xFF (corrupt input only) makes the reference's value
@@ -1003,16 +903,21 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
+#if ISSCABAC_EXP_INPLACE  // (timing experiment: the output over the ctx rows -- same pages, same lines)
+  uint8_t *out_w = const_cast<uint8_t *>(a.ctx) + s0 * a.pitch;
+#else
   uint8_t *out_w = a.bins_out + s0 * a.pitch;
+#endif
   // 128 bins of every stream leave the staging buffer as full 128-byte row segments: lane l of pass k takes chunk l % 8 of
   // row 8 k + l / 8.  Ordinarily -- all 64 rows exist, the block lies inside the row -- the eight stores are issued by
   // hand: one wave-uniform base per pass (SGPRs) + one 32-bit lane offset for all of them (the compiler hoists eight 64-bit
-  // lane addresses out of the bin loop otherwise: 16 registers), no per-store exec masks, and the compiler's wait-count
-  // pass, which does not look inside, keeps counting loads only (with stores pending beside loads it waits for vmcnt(0)).
-  const uint32_t st_voff = (uint32_t)(lane >> 3) * a.pitch + (uint32_t)(lane & 7) * 16;
-  const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(lane & 7, lane >> 3);
-  auto store_out = [&](uint32_t off) -> bool {  // true: exactly eight stores went out, issued by hand
+  // lane addresses out of the bin loop otherwise: 16 registers) and no per-store exec masks.
+  auto store_out = [&](uint32_t off) {
     if (!PERM && nrows == 64 && off + 128 <= a.pitch) {
+      // (formed here, behind an opaque lane id, so that they are not kept in registers across the bin loop)
+      const uint32_t ln = opaque((uint32_t)lane);
+      const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
+      const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         // idx(c, 8 k + i) = idx(c, i) ^ 8 k
@@ -1022,10 +927,13 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #if ISSCABAC_DEC_NOSTORE  // timing experiment only
         if (v.x == 0x12345678u)
 #endif
-        if (kDecNT) asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        // (s_nop 1: a store of more than 64 bits must not be followed within two wait states by a VALU write of its data -- the
+        // compiler keeps that wait state for its own stores, it cannot see this one)
+        if (ISSCABAC_DEC_NT_ST == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        else if (kDecNTst) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
       }
-      return true;
+      return;
     }
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
@@ -1039,37 +947,29 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         else *reinterpret_cast<uint4 *>(p) = v;
       }
     }
-    return false;
   };
 
-  const uint32_t nrounds = (a.nbins + Tile::T - 1) / Tile::T;
-  uint4 pc[Tile::NLD];
-  auto fetch = [&](uint32_t off) -> bool {  // true: exactly four loads went out
-    if (off + Tile::T <= a.pitch) {
-      if (PERM) Tile::load_rows_full<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
-      else Tile::load_full<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
-      return true;
-    }
-    if (PERM) Tile::load_rows<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
-    else Tile::load<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
-    return false;
+  const uint32_t nrounds = (a.nbins + DTile::T - 1) / DTile::T;
+  uint4 pc[DTile::NLD];
+  auto fetch = [&](uint32_t off) {
+    if (PERM) DTile::template load_rows<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
+    else DTile::template load<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
   };
   if (nrounds) fetch(0);
   wave_lds_sync();
 #if ISSCABAC_EXP_CLK
-  uint64_t clk_ctx = 0;
+  uint64_t clk_ctx = 0, clk_body = 0, clk_st = 0, clk_ld = 0;
   const uint64_t clk_start = __builtin_amdgcn_s_memtime();
 #endif
   bool have_out = false;
   uint32_t out_off = 0;
-  uint32_t kw = 0;  // vector memory operations issued behind the most recent payload request (wave-uniform)
   for (uint32_t t = 0; t < nrounds; t++) {
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #else
 #pragma unroll
 #endif
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < DTile::NP; h++) {
 #if ISSCABAC_EXP_CLK
       if (h == 0) {
         const uint64_t c0 = __builtin_amdgcn_s_memtime();
@@ -1078,37 +978,49 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         clk_ctx += __builtin_amdgcn_s_memtime() - c0;
       }
 #endif
-      Tile::half_to_lds(tile_c, pc, h, lane);
+      DTile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
 #if ISSCABAC_DEC_ROLLED
 #pragma unroll 1
 #endif
       for (int j = 0; j < 2; j++) {
-        const uint32_t i0 = t * Tile::T + h * Tile::H + j * 16;
-        const uint32_t cidx = (t & 1u) * 4 + h * 2 + j;  // chunk inside the 128-bin output block
-        uint4 ov = make_uint4(0, 0, 0, 0);
+        const uint32_t i0 = t * DTile::T + h * DTile::H + j * 16;
+        const uint32_t cidx = (i0 >> 4) & 7u;  // chunk inside the 128-bin output block
+        uint32_t od = 0;  // the chunk's 16 bins packed as they come (OutBuf: bit g of byte b = bin 4 g + b)
         const bool live = i0 < nmax;  // past the longest stream of the wave: zeros
-        if (live) {
-          if (kw == 8) src.template boundary_async<8>();
-          else if (kw == 4) src.template boundary_async<4>();
-          else src.template boundary_async<0>();
-          kw = 0;
-        }
+        if (live) src.boundary();
         if (j == 0) {
-          // global stores and loads go out right BEHIND the boundary's payload request: the next boundary's wait for the
-          // piece lets them stay in flight (WindowDev), the one after that is the first to wait for them
+          // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
+          // anything issued just before the boundary's wait for the payload piece would be waited for as well
           if (have_out) {
-            kw = store_out(out_off) ? 8 : 0;
+#if ISSCABAC_EXP_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            const uint64_t cs0 = __builtin_amdgcn_s_memtime();
+#endif
+            store_out(out_off);
             wave_lds_sync();  // the staging buffer is rewritten from here on
+#if ISSCABAC_EXP_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            clk_st += __builtin_amdgcn_s_memtime() - cs0;
+#endif
             have_out = false;
           }
 #if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's ctx bytes again and again)
-          if (h == 1 && t + 1 < nrounds && (t + 1) * Tile::T < nmax)  // nothing to decode past the wave's longest stream
-            kw = fetch((t + 1) * Tile::T) ? 4 : 0;
+          if (h == DTile::NP - 1 && t + 1 < nrounds && (t + 1) * DTile::T < nmax) {  // nothing to decode past the wave's longest stream
+#if ISSCABAC_EXP_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            const uint64_t cf0 = __builtin_amdgcn_s_memtime();
+#endif
+            fetch((t + 1) * DTile::T);
+#if ISSCABAC_EXP_CLK
+            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            clk_ld += __builtin_amdgcn_s_memtime() - cf0;
+#endif
+          }
 #endif
         }
         if (live) {
-        const uint4 wc = Tile::row_chunk(tile_c, lane, j);
+        const uint4 wc = DTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         // One bit-granular top-up per four bins (sh = 23 afterwards).  Four context or bypass bins shift at most 22 bits
@@ -1117,6 +1029,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         // top-up can take.  oa / ob collect the bins of a word as bytes (cabac_lane.h: dec_bin_out).
         uint32_t oa = 0, ob = 0;
         if (full && !hi) {
+#if ISSCABAC_EXP_CLK
+          asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+          const uint64_t cb0 = __builtin_amdgcn_s_memtime();
+#endif
           // every lane decodes 16 context bins
           // latency-oriented instance: the state of the next bin is loaded one bin ahead, the successor forwarded in a
           // register for a repeated context
@@ -1158,8 +1074,12 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               dec_bin_out<2>(d, a2, stx.load_at(a2), stx, oa, ob);
               dec_bin_out<3>(d, a3, stx.load_at(a3), stx, oa, ob);
             }
-            set_word(ov, g, out_word(oa, ob));
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
+#if ISSCABAC_EXP_CLK
+          asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+          clk_body += __builtin_amdgcn_s_memtime() - cb0;
+#endif
         } else if (CM != 2 && full &&
                    !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
           // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed_nx), see k_encode
@@ -1179,7 +1099,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               else if (k == 2) put_out_byte<2>(oa, ob, nx);
               else put_out_byte<3>(oa, ob, nx);
             }
-            set_word(ov, g, out_word(oa, ob));
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
         } else {
           // fixed-probability bins, contexts >= 128 beside bypass bins, or streams that end inside this chunk: every lane
@@ -1212,19 +1132,19 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               else if (k == 2) put_out_byte<2>(oa, ob, w);
               else put_out_byte<3>(oa, ob, w);
             }
-            set_word(ov, g, out_word(oa, ob));
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
         }
         }
-        obuf[OutBuf::idx(cidx, lane)] = OutBuf::pack(ov);
+        obuf[OutBuf::idx(cidx, lane)] = od;
       }
       wave_lds_sync();
     }
-    if ((t & 1u) == 1u || t + 1 == nrounds) {  // a 128-bin output block is complete (or the stream ends)
+    if (((t + 1) * DTile::T) % 128 == 0 || t + 1 == nrounds) {  // a 128-bin output block is complete (or the stream ends)
       have_out = true;
-      out_off = (t & ~1u) * Tile::T;
-      if (t + 1 == nrounds && (t & 1u) == 0) {
-        // odd number of rounds: the upper half of the last block was never written
+      out_off = (t * DTile::T) & ~127u;
+      if (((t + 1) * DTile::T) % 128 != 0) {
+        // the stream ends inside the block: its upper half was never written
         for (uint32_t c = 4; c < 8; c++) obuf[OutBuf::idx(c, lane)] = 0;
         wave_lds_sync();
       }
@@ -1239,9 +1159,11 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
 #if ISSCABAC_EXP_CLK
     const uint64_t tot = __builtin_amdgcn_s_memtime() - clk_start;
-    if (lane == 0) a.status[s] = (uint32_t)src.clk_await;
     if (lane == 1) a.status[s] = (uint32_t)clk_ctx;
     if (lane == 2) a.status[s] = (uint32_t)tot;
+    if (lane == 3) a.status[s] = (uint32_t)clk_body;
+    if (lane == 4) a.status[s] = (uint32_t)clk_st;
+    if (lane == 5) a.status[s] = (uint32_t)clk_ld;
 #endif
   }
 }
@@ -1487,7 +1409,10 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
-  const size_t lds = kDecTabBytes + waves_per_block(CM) * DecLds<CM, PERM>::BYTES;
+#ifndef ISSCABAC_DEC_LDS_PAD  // (occupancy experiments: bytes of unused LDS per workgroup)
+#define ISSCABAC_DEC_LDS_PAD 0
+#endif
+  const size_t lds = kDecTabBytes + waves_per_block(CM) * DecLds<CM, PERM>::BYTES + ISSCABAC_DEC_LDS_PAD;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;

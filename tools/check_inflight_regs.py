@@ -67,52 +67,6 @@ def check(text):
     return bad, counts
 
 
-def check_vmem(text):
-    """The decode kernel requests its payload piece in inline assembly into fixed registers (cabac_kernels.hip: WindowDev) and
-    waits for it by hand one chunk later; in between the registers are no C++ value, so the compiler must not use them for
-    anything: in every kernel, the destination registers of an inline-assembly global load may be named by inline assembly
-    only.  Returns (violations, requests checked per kernel)."""
-    bad, counts = [], {}
-    kernels, cur = {}, None
-    for line in text.splitlines():
-        m = re.match(r"^(_Z\w+):", line.strip())
-        if m:
-            cur = kernels.setdefault(m.group(1), [])
-            continue
-        if cur is not None:
-            cur.append(line)
-    for name, lines in kernels.items():
-        ins, in_asm = [], False
-        for raw in lines:
-            t = raw.strip()
-            if t.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if t.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
-                continue
-            ins.append((t.split(";")[0].strip(), in_asm))
-        reserved, nreq = set(), 0
-        for t, a in ins:
-            if a and t.startswith("global_load_dwordx4"):
-                reserved |= regs_of(operands(t)[1][0])
-                nreq += 1
-        if not reserved:
-            continue
-        counts[name] = nreq
-        for t, a in ins:
-            if a:
-                continue
-            used = set()
-            for tok in operands(t)[1]:
-                used |= regs_of(tok)
-            if used & reserved:
-                bad.append("%s: `%s` names v%s, reserved for the payload piece in flight" % (name, t, sorted(used & reserved)))
-    return bad, counts
-
-
 def main():
     if len(sys.argv) > 1:
         text = open(sys.argv[1]).read()
@@ -128,10 +82,6 @@ def main():
     bad, counts = check(text)
     for k, n in sorted(counts.items()):
         print("%6d LDS reads checked  %s" % (n, k))
-    bad2, counts2 = check_vmem(text)
-    for k, n in sorted(counts2.items()):
-        print("%6d payload requests checked  %s" % (n, k))
-    bad += bad2
     for b in bad:
         print("VIOLATION", b)
     return 1 if bad else 0
