@@ -82,6 +82,10 @@ __device__ __forceinline__ uint4 nt_load16(const uint8_t *p) {
   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) {  // (through the plain vector type: HIP's uint4 keeps the tile arrays in scratch here)
+  const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
   u32x4 w = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
@@ -159,16 +163,19 @@ struct TileT {
   // the row addresses cost one VGPR each instead of hoisted 64-bit pointers
   // NT: non-temporal (streaming) loads -- the decode kernel's ctx stream then stops evicting the payload lines its
   // lanes come back to (FETCH_SIZE 11.2 -> 8.9 GB per launch, 2% faster); in the encode kernel they only cost time
+  // A piece that would start past the row's end (off + 16 * piece >= pitch: the last round of a row whose pitch is no
+  // multiple of T) is clamped to the row's last 16 bytes instead of predicated away: no lane reads what it gets -- those
+  // bins lie past every stream's end -- and the loads stay unconditional (a predicate costs a zero fill of the registers,
+  // exec-mask code around every instruction and, in front of the fill, a wait for everything in flight)
   template <bool NT = false>
   __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch,
                                               uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
       const uint32_t row = min(row_of(k, lane), nrows - 1u);
-      const uint32_t boff = off + ch_of(lane) * 16;
       const uint32_t voff = row * pitch + boff;
-      if (NT) r[k] = boff < pitch ? nt_load16(rows + voff) : make_uint4(0, 0, 0, 0);
-      else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(rows + voff) : make_uint4(0, 0, 0, 0);
+      r[k] = NT ? nt_load16(rows + voff) : ld16(rows + voff);
     }
   }
   // The same for a wave whose 64 streams are NOT neighbours in the array (length-bucketed launches, cabac_order.hip):
@@ -176,12 +183,11 @@ struct TileT {
   template <bool NT = false>
   __device__ static __forceinline__ void load_rows(uint4 (&r)[NLD], const uint8_t *base, const uint32_t (&rid)[NLD], uint32_t pitch,
                                                    uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
 #pragma unroll
     for (int k = 0; k < NLD; k++) {
-      const uint32_t boff = off + ch_of(lane) * 16;
       const uint8_t *p = base + ((uint64_t)rid[k] * pitch + boff);
-      if (NT) r[k] = boff < pitch ? nt_load16(p) : make_uint4(0, 0, 0, 0);
-      else r[k] = boff < pitch ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0, 0, 0, 0);
+      r[k] = NT ? nt_load16(p) : ld16(p);
     }
   }
   // part h (bytes 32 h .. 32 h + 31 of the round) of the registers -> LDS
@@ -199,10 +205,23 @@ struct TileT {
   }
 };
 typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
-#ifndef ISSCABAC_ENC_LPR
-#define ISSCABAC_ENC_LPR 4
+// the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
+// both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
+#ifndef ISSCABAC_ENC_LPR_B
+#define ISSCABAC_ENC_LPR_B 4
 #endif
-typedef TileT<ISSCABAC_ENC_LPR> ETile;  // the encode kernel's
+#ifndef ISSCABAC_ENC_LPR_C
+#define ISSCABAC_ENC_LPR_C 4
+#endif
+#ifndef ISSCABAC_ENC_NT
+#define ISSCABAC_ENC_NT 0
+#endif
+constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
+                                                // half of every 128-byte line is an L2 hit one round later only if the first allocated it
+template <bool PERM>
+using EncTileB = TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+template <bool PERM>
+using EncTileC = TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>;
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
@@ -553,13 +572,17 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
-  uint32_t rid[ETile::NLD] = {};
+  using BTile = EncTileB<PERM>;
+  using CTile = EncTileC<PERM>;
+  uint32_t ridb[BTile::NLD] = {}, ridc[CTile::NLD] = {};
   if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
     uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);
     wids[lane] = (uint32_t)s;
     wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < ETile::NLD; k++) rid[k] = wids[ETile::row_of(k, lane)];
+    for (int k = 0; k < BTile::NLD; k++) ridb[k] = wids[BTile::row_of(k, lane)];
+#pragma unroll
+    for (int k = 0; k < CTile::NLD; k++) ridc[k] = wids[CTile::row_of(k, lane)];
   }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
@@ -587,20 +610,25 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   sink.pos = 0;
   sink.on = valid;
 
-  const uint32_t nrounds = (nmax + ETile::T - 1) / ETile::T;
+  // The two arrays may come in rounds of different length (TileT<LPR>): the loop runs over the longer one's rounds in
+  // 32-byte parts, and an array's next round is requested when its last part has gone to LDS
+  constexpr int TM = BTile::T > CTile::T ? BTile::T : CTile::T, NPM = TM / 32;
+  const uint32_t nrounds = (nmax + TM - 1) / TM;
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
-  uint4 pb[ETile::NLD], pc[ETile::NLD];
-  auto fetch = [&](uint32_t off) {
-    if (PERM) {
-      ETile::load_rows(pb, a.bins, rid, a.pitch, off, lane);
-      ETile::load_rows(pc, a.ctx, rid, a.pitch, off, lane);
-    } else {
-      ETile::load(pb, bins_w, nrows, a.pitch, off, lane);
-      ETile::load(pc, ctx_w, nrows, a.pitch, off, lane);
-    }
+  uint4 pb[BTile::NLD], pc[CTile::NLD];
+  auto fetch_b = [&](uint32_t off) {
+    if (PERM) BTile::template load_rows<kEncNT>(pb, a.bins, ridb, a.pitch, off, lane);
+    else BTile::template load<kEncNT>(pb, bins_w, nrows, a.pitch, off, lane);
   };
-  if (nrounds) fetch(0);
+  auto fetch_c = [&](uint32_t off) {
+    if (PERM) CTile::template load_rows<kEncNT>(pc, a.ctx, ridc, a.pitch, off, lane);
+    else CTile::template load<kEncNT>(pc, ctx_w, nrows, a.pitch, off, lane);
+  };
+  if (nrounds) {
+    fetch_b(0);
+    fetch_c(0);
+  }
   wave_lds_sync();
   for (uint32_t t = 0; t < nrounds; t++) {
 #if ISSCABAC_ENC_ROLLED
@@ -608,22 +636,25 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #else
 #pragma unroll
 #endif
-    for (int h = 0; h < ETile::NP; h++) {
-      if (t * ETile::T + h * ETile::H >= nmax) break;
-      ETile::half_to_lds(tile_b, pb, h, lane);
-      ETile::half_to_lds(tile_c, pc, h, lane);
+    for (int h = 0; h < NPM; h++) {
+      const uint32_t pos = t * TM + h * 32;
+      if (pos >= nmax) break;
+      BTile::half_to_lds(tile_b, pb, h % BTile::NP, lane);
+      CTile::half_to_lds(tile_c, pc, h % CTile::NP, lane);
       wave_lds_sync();
 #if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's bytes again and again)
-      if (h == ETile::NP - 1 && t + 1 < nrounds) fetch((t + 1) * ETile::T);  // registers are free again: the next round, behind 32 bins of work
+      // registers are free again: the next round, behind 32 bins of work
+      if (h % BTile::NP == BTile::NP - 1 && pos + 32 < nmax) fetch_b(pos + 32);
+      if (h % CTile::NP == CTile::NP - 1 && pos + 32 < nmax) fetch_c(pos + 32);
 #endif
 #if ISSCABAC_ENC_ROLLED
 #pragma unroll 1
 #endif
       for (int j = 0; j < 2; j++) {
-        const uint32_t i0 = t * ETile::T + h * ETile::H + j * 16;
+        const uint32_t i0 = pos + j * 16;
         if (i0 >= nmax) break;
-        const uint4 wb = ETile::row_chunk(tile_b, lane, j);
-        const uint4 wc = ETile::row_chunk(tile_c, lane, j);
+        const uint4 wb = BTile::row_chunk(tile_b, lane, j);
+        const uint4 wc = CTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
         const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
         if (LAT && full && !hi) {
