@@ -216,6 +216,9 @@ typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input a
 #ifndef ISSCABAC_ENC_NT
 #define ISSCABAC_ENC_NT 0
 #endif
+#ifndef ISSCABAC_ENC_DEPTH2
+#define ISSCABAC_ENC_DEPTH2 0
+#endif
 constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
                                                 // half of every 128-byte line is an L2 hit one round later only if the first allocated it
 template <bool PERM>
@@ -375,6 +378,9 @@ struct LdsStates {
 // byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
 // (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
 // ------------------------------------------------------------------------------------------------
+#ifndef ISSCABAC_ENC_NOSTORE  // timing experiment only
+#define ISSCABAC_ENC_NOSTORE 0
+#endif
 struct SlotSink {
   uint8_t *stage;   // LDS, this lane's 16 bytes
   uint8_t *slots;   // HBM, the wave's first slot (wave-uniform, 16-byte aligned)
@@ -386,7 +392,7 @@ struct SlotSink {
     pos++;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
     }
   }
   // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
@@ -395,7 +401,7 @@ struct SlotSink {
     pos += 2;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
     }
   }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
@@ -616,21 +622,30 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const uint32_t nrounds = (nmax + TM - 1) / TM;
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
-  uint4 pb[BTile::NLD], pc[CTile::NLD];
-  auto fetch_b = [&](uint32_t off) {
-    if (PERM) BTile::template load_rows<kEncNT>(pb, a.bins, ridb, a.pitch, off, lane);
-    else BTile::template load<kEncNT>(pb, bins_w, nrows, a.pitch, off, lane);
+  // Two sets of staging registers, taking turns: a round's loads are issued when the OTHER set's round is half coded --
+  // a round and a half (96 bins) before they are needed instead of half a round (ISSCABAC_ENC_DEPTH2 = 0: one set)
+  uint4 pb0[BTile::NLD], pc0[CTile::NLD];
+#if ISSCABAC_ENC_DEPTH2
+  static_assert(BTile::T == CTile::T, "the two-set rotation assumes equal rounds");
+  uint4 pb1[BTile::NLD], pc1[CTile::NLD];
+#endif
+  auto fetch_into = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t off, bool both, bool cc) {
+    if (both || !cc) {
+      if (PERM) BTile::template load_rows<kEncNT>(pb, a.bins, ridb, a.pitch, off, lane);
+      else BTile::template load<kEncNT>(pb, bins_w, nrows, a.pitch, off, lane);
+    }
+    if (both || cc) {
+      if (PERM) CTile::template load_rows<kEncNT>(pc, a.ctx, ridc, a.pitch, off, lane);
+      else CTile::template load<kEncNT>(pc, ctx_w, nrows, a.pitch, off, lane);
+    }
   };
-  auto fetch_c = [&](uint32_t off) {
-    if (PERM) CTile::template load_rows<kEncNT>(pc, a.ctx, ridc, a.pitch, off, lane);
-    else CTile::template load<kEncNT>(pc, ctx_w, nrows, a.pitch, off, lane);
-  };
-  if (nrounds) {
-    fetch_b(0);
-    fetch_c(0);
-  }
+  if (nrounds) fetch_into(pb0, pc0, 0, true, false);
+#if ISSCABAC_ENC_DEPTH2
+  if (TM < nmax) fetch_into(pb1, pc1, TM, true, false);
+#endif
   wave_lds_sync();
-  for (uint32_t t = 0; t < nrounds; t++) {
+  // one round of the longer array out of the register set (pb, pc); `ahead` = rounds between a set's request and its use
+  auto round = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t t, uint32_t ahead) {
 #if ISSCABAC_ENC_ROLLED
 #pragma unroll 1
 #else
@@ -638,14 +653,14 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #endif
     for (int h = 0; h < NPM; h++) {
       const uint32_t pos = t * TM + h * 32;
-      if (pos >= nmax) break;
+      if (pos >= nmax) return;
       BTile::half_to_lds(tile_b, pb, h % BTile::NP, lane);
       CTile::half_to_lds(tile_c, pc, h % CTile::NP, lane);
       wave_lds_sync();
 #if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's bytes again and again)
-      // registers are free again: the next round, behind 32 bins of work
-      if (h % BTile::NP == BTile::NP - 1 && pos + 32 < nmax) fetch_b(pos + 32);
-      if (h % CTile::NP == CTile::NP - 1 && pos + 32 < nmax) fetch_c(pos + 32);
+      // registers are free again: the set's next round
+      if (h % BTile::NP == BTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, false);
+      if (h % CTile::NP == CTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
 #endif
 #if ISSCABAC_ENC_ROLLED
 #pragma unroll 1
@@ -762,7 +777,15 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
       }
       wave_lds_sync();
     }
+  };
+#if ISSCABAC_ENC_DEPTH2
+  for (uint32_t t = 0; t < nrounds; t += 2) {
+    round(pb0, pc0, t, 2);
+    if (t + 1 < nrounds) round(pb1, pc1, t + 1, 2);
   }
+#else
+  for (uint32_t t = 0; t < nrounds; t++) round(pb0, pc0, t, 1);
+#endif
   enc_flush16(e, sink);
   enc_finish16(e, sink);
   sink.close();
