@@ -228,6 +228,7 @@ def main():
     fence()
     eng.sync()
     eng.kernel_ms_mean()  # forget the warm-up launches
+    eng.kernel_ms_samples()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -235,8 +236,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     eng.sync()  # raises if a payload buffer was too small (reports the most recent encode; the others are checked below)
+    ksamples = eng.kernel_ms_samples()  # every launch of the timed steps (the same events the means below come from)
     kms, klaunches = eng.kernel_ms_mean()  # HIP events on the launch stream around every kernel of the timed steps
     assert klaunches["encode"] == args.steps * len(bufs) and klaunches["decode"] == args.steps * len(bufs)
+    # kernel time of every step (all launches of the step, all four kernels): min / median beside the mean, so that two
+    # builds can be compared from one run each (box-to-box spread is +- 3 %, within a run the steps agree to ~0.5 %)
+    nl = len(bufs)
+    step_ms = []
+    if all(len(ksamples[k]) == args.steps * nl for k in ("encode", "scan", "gather", "decode")):
+        for i in range(args.steps):
+            step_ms.append(sum(sum(ksamples[k][i * nl:(i + 1) * nl]) for k in ("encode", "scan", "gather", "decode")))
     totals = [int(b["offsets"][-1]) for b in bufs]
     for b, tot in zip(bufs, totals):
         assert tot <= b["cap"], "payload buffer too small"
@@ -336,6 +345,10 @@ def main():
                        "bits_per_bin": 8.0 * sum(totals) / (float(my_streams) * B)},
             "verified_bit_exact": verified,
             "kernels_ms": kms,
+            "kernels_ms_min": {k: (min(v) if v else None) for k, v in ksamples.items()},
+            "kernels_ms_median": {k: (sorted(v)[len(v) // 2] if v else None) for k, v in ksamples.items()},
+            "step_kernel_ms_min": min(step_ms) if step_ms else None,
+            "step_kernel_ms_median": sorted(step_ms)[len(step_ms) // 2] if step_ms else None,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": kbytes, "ms_per_launch": kms_avg},

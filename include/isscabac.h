@@ -395,6 +395,10 @@ int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]);
 /* mean kernel times (same four slots) over the batch calls since the previous call of this function, and how many
  * launches each mean covers; waits for the enqueued work first.  Up to 128 calls are kept between reads (a full ring is read out early, which waits for the stream). */
 int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4]);
+/* the individual launch times of one slot (0 encode kernel, 1 scan, 2 gather, 3 decode kernel) recorded since the
+ * previous complete read, oldest first (at most 4096 are kept): *count = how many there are; the first min(cap, *count)
+ * are copied to ms, and they are forgotten once cap covered them all.  Waits for the enqueued work first. */
+int isscabac_kernel_ms_samples(isscabac_engine *e, int slot, float *ms, uint32_t cap, uint32_t *count);
 
 /* synthetic workload generator of SURVEY.md section 8(d) (counter based, identical to
  * oracle/cabac_oracle.c:orc_synth_fill), filling device buffers for global streams s0 .. s0+S-1 */

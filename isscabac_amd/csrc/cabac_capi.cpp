@@ -216,12 +216,14 @@ static int prof_drain(isscabac_engine *e) {
         e->last_ms[k] = ms;
         e->sum_ms[k] += ms;
         e->sum_n[k]++;
+        if (e->samples[k].size() < isscabac_engine::kMaxSamples) e->samples[k].push_back(ms);
       }
     } else {
       HIP_TRY(e, hipEventElapsedTime(&ms, p.ev[0], p.ev[1]));
       e->last_ms[3] = ms;
       e->sum_ms[3] += ms;
       e->sum_n[3]++;
+      if (e->samples[3].size() < isscabac_engine::kMaxSamples) e->samples[3].push_back(ms);
     }
     e->prof_count--;
   }
@@ -604,6 +606,20 @@ int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4
     e->sum_ms[i] = 0;
     e->sum_n[i] = 0;
   }
+  return ISSCABAC_OK;
+}
+
+int isscabac_kernel_ms_samples(isscabac_engine *e, int slot, float *ms, uint32_t cap, uint32_t *count) {
+  if (!e || slot < 0 || slot > 3 || !count || (cap && !ms)) return ISSCABAC_ERR_ARG;
+  if (e->prof_count) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    const int rc = engine_sync(e);
+    if (rc) return rc;
+  }
+  std::vector<float> &v = e->samples[slot];
+  *count = (uint32_t)v.size();
+  for (uint32_t i = 0; i < cap && i < v.size(); i++) ms[i] = v[i];
+  if (cap >= v.size()) v.clear();  // a sizing call (cap too small) leaves them in place
   return ISSCABAC_OK;
 }
 

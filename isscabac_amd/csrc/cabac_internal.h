@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/isscabac.h"
 
@@ -57,6 +58,8 @@ struct isscabac_engine {
   float last_ms[4] = {0, 0, 0, 0};
   double sum_ms[4] = {0, 0, 0, 0};
   uint32_t sum_n[4] = {0, 0, 0, 0};
+  std::vector<float> samples[4];  // every launch's time since the last isscabac_kernel_ms_samples (bounded: kMaxSamples)
+  static constexpr size_t kMaxSamples = 4096;
 };
 
 

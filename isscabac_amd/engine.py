@@ -118,6 +118,7 @@ def _load():
     L.isscabac_decode_batch_dev_async.argtypes = L.isscabac_decode_batch_dev.argtypes
     L.isscabac_sync.argtypes = [_vp, _u64p]
     L.isscabac_kernel_ms_mean.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.isscabac_kernel_ms_samples.argtypes = [_vp, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     L.isscabac_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
                                         _u8p, C.c_uint64, _u64p, _u64p]
     L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
@@ -292,6 +293,18 @@ class Engine:
         self._check(self._L.isscabac_kernel_ms_mean(self._h, ms, n))
         keys = ("encode", "scan", "gather", "decode")
         return {k: ms[i] for i, k in enumerate(keys)}, {k: int(n[i]) for i, k in enumerate(keys)}
+
+    def kernel_ms_samples(self):
+        """Every launch's kernel time since the previous call (waits for the stream first): {'encode': [...], ...} in ms,
+        oldest first."""
+        out = {}
+        for i, k in enumerate(("encode", "scan", "gather", "decode")):
+            n = C.c_uint32(0)
+            self._check(self._L.isscabac_kernel_ms_samples(self._h, i, None, 0, C.byref(n)))
+            buf = (C.c_float * max(1, n.value))()
+            self._check(self._L.isscabac_kernel_ms_samples(self._h, i, buf, n.value, C.byref(n)))
+            out[k] = [float(buf[j]) for j in range(n.value)]
+        return out
 
     # ---- device-buffer hot path ------------------------------------------------------------------------
     def encode_dev_async(self, d_bins, d_ctx, S, nbins, pitch, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0):

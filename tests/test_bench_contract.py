@@ -42,6 +42,52 @@ def test_bench_json_line_contract():
     assert abs(d["value"] - bins_per_step / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
 
 
+def _run_dist_bench(extra_env, tag):
+    """bench.py under the launcher the driver uses for N > 1, with one rank: ISSCABAC_FORCE_DIST=1 takes the multi-rank
+    branch (RCCL process group, barriers, all_reduce of the elapsed time, the bitstream gather).  The launcher starts
+    before anything touches the GPU; nothing is re-executed afterwards."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, ISSCABAC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--streams", "8192", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    logdir = os.path.join(ROOT, "gpurun_out", "r03_dist")
+    try:  # kept as evidence (copied to profiles/r03/ by hand): the RCCL branch of bench.py ran on this build
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, tag + ".log"), "w") as f:
+            f.write("$ %s\n[exit %d]\n--- stdout\n%s\n--- stderr (tail)\n%s\n" % (" ".join(cmd), out.returncode, out.stdout, out.stderr[-3000:]))
+    except OSError:
+        pass
+    return out
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_branch_runs_with_one_rank():
+    out = _run_dist_bench({}, "force_dist_ok")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["gather_ok"] is True and d["gather_ms"] > 0 and d["gather_bytes"] == d["config"]["payload_bytes_per_gpu"]
+    assert d["n_gpus"] == 1 and d["verified_bit_exact"] is True and d["value"] > 0
+    assert d["step_kernel_ms_min"] <= d["step_kernel_ms_median"]
+
+
+@pytest.mark.gpu
+def test_bench_gather_deadline_fails_visibly_after_the_line():
+    out = _run_dist_bench({"ISSCABAC_GATHER_DEADLINE_S": "0"}, "force_dist_deadline")
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout  # the result line is out ...
+    d = json.loads(lines[0])
+    assert d["gather_ok"] is False and d["value"] > 0
+    assert out.returncode != 0  # ... and the run failed (the rank left with exit code 3; the launcher reports a failure)
+    assert "exitcode" in out.stderr.lower() or "exit code" in out.stderr.lower() or "3" in out.stderr
+
+
 def test_default_metric_string_is_baseline_json_verbatim():
     sys.path.insert(0, ROOT)
     import bench
