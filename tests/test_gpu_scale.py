@@ -1,0 +1,66 @@
+"""Scale checks of the batch path on one MI355X ("offsets must be 64-bit"; BASELINE config 5's
+per-GPU share at full size).  Device round trips over every stream plus sampled streams byte for byte against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _round_trip_and_sample(S, B, C, seed, ep, sample, cap_per_stream):
+    torch = _torch()
+    from isscabac_amd import Engine
+    from oracle.pyoracle import Oracle
+    dev = torch.device("cuda:0")
+    eng, orc = Engine(0), Oracle()
+    bins = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    ctx = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    eng.synth_dev(seed, 0, S, B, B, C, ep, bins.data_ptr(), ctx.data_ptr())
+    init = np.zeros(C, np.uint8)
+    cap = S * cap_per_stream
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    total = eng.encode_dev(bins.data_ptr(), ctx.data_ptr(), S, B, B, init, payload.data_ptr(), cap, offsets.data_ptr())
+    off = offsets.cpu().numpy().astype(np.uint64)
+    assert off[0] == 0 and off[-1] == total and (np.diff(off.astype(np.int64)) > 0).all()
+    out = torch.empty((S, B), dtype=torch.uint8, device=dev)
+    status = torch.empty((S,), dtype=torch.int32, device=dev)
+    eng.decode_dev(payload.data_ptr(), total, offsets.data_ptr(), ctx.data_ptr(), S, B, B, init, out.data_ptr(), status.data_ptr())
+    assert int(status.abs().sum()) == 0
+    assert torch.equal(out, bins)
+    del out, status
+    for s in sample:
+        hb, hc = orc.synth(seed, s, 1, B, C, ep)
+        want = orc.encode_stream(hb[0], hc[0], init)
+        got = payload[int(off[s]):int(off[s + 1])].cpu().numpy()
+        assert got.tobytes() == want.tobytes(), s
+    eng.close()
+    return total, off
+
+
+def test_config5_per_gpu_share_at_full_size():
+    """BASELINE.json config 5 on one of its 8 GPUs: 1 Mi streams x 8 Ki bins, 50 % bypass bins -- the mixed-chunk path of
+    both kernels at full occupancy.  Device round trip over all 8.6 G bins, 133 strided streams against the oracle."""
+    S = 1 << 20
+    sample = list(range(0, S, S // 128)) + [S - 1, S - 2, 63, 64, 65]
+    total, _off = _round_trip_and_sample(S, 8192, 64, 0xCABAC005, True, sample, 8192 // 8 + 8192 // 16 + 64)
+    assert 0.11 * S * 8192 < total < 0.14 * S * 8192  # ~1.0 bit per bin: half of them bypass bins
+
+
+def test_payload_beyond_4_gib_offsets_are_64_bit():
+    """5 Mi streams x 8 Ki bins with bypass bins: ~5.4 GB of payload, so streams start beyond 2^32 -- offsets, the scan,
+    the gather and the decoder's payload addressing all have to be 64-bit.  Needs ~175 GB of free HBM."""
+    torch = _torch()
+    free, _tot = torch.cuda.mem_get_info(0)
+    if free < 180e9:
+        pytest.skip("needs 180 GB of free HBM, %.0f GB are free" % (free / 1e9))
+    S = 5 << 20
+    # sampled: the batch's ends and 64 streams from the tail, which lies beyond the 4 GiB mark (checked below)
+    total, off = _round_trip_and_sample(S, 8192, 64, 0xCABAC005, True,
+                                        [0, 1, S // 2, S - 1] + list(range(S - 100_000, S - 100_000 + 64)), 1100)
+    assert total > (1 << 32)
+    assert int(off[S - 100_000]) > (1 << 32)  # the sampled run does start beyond 4 GiB
