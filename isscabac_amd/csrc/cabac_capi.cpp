@@ -485,8 +485,10 @@ int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t
   uint32_t *d_nb = nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr;
   uint8_t *d_payload = static_cast<uint8_t *>(e->stage[3]);
   uint64_t *d_offsets = static_cast<uint64_t *>(e->stage[4]);
-  // everything enqueued earlier on the engine's stream may still read the staging buffers
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // everything enqueued earlier on the engine's stream may still read the staging buffers -- and an asynchronous device
+  // encode still outstanding has its size word in e->h_total, which this call is about to reuse: settle it first (its
+  // capacity error, if any, is this call's result: the caller never synchronised it)
+  if ((rc = isscabac_sync(e, nullptr))) return rc;
   HostPipe up{e, 0, isscabac_engine::kPinSlots};
   if (d_nb && (rc = up.upload(d_nb, nbins_per_stream, S * sizeof(uint32_t)))) return rc;
   // groups of streams: group g is coded while group g + 1 is still crossing the link

@@ -4,7 +4,8 @@
 // opens the handle's file for writing, :288 for reading) and its callers size a result by `dir(fn).bytes * 8`
 // (ref: CABAC/cabacDemo.m:190-191, ISS/+coder/cabacEncode.m:100-101).  The engine keeps a batch as payload + offsets;
 // these calls convert between the two forms, so that files written here are read by the reference's decoder and the
-// other way round (tests/test_gpu_container.py does both with oracle/_ref).
+// other way round (tests/test_abi_symbols.py::test_stream_files_interoperate_with_the_reference_decoder and
+// tests/test_mex_gateway.py do both with oracle/_ref).
 // The second half is the side information ISS.m transmits next to its two CABAC streams (ref: ISS/ISS.m:197-201:
 // centroids cW, cH, the mixing matrix Q and, unless equalProb, the uint8 context initialisations xw, xh).  The reference
 // only measures its size through MATLAB's `save`; here it gets a concrete little-endian container, written and read back
@@ -30,6 +31,14 @@ struct File {
   ~File() {
     if (f) fclose(f);
   }
+  // for files written: flush and close now, and say whether everything reached the file (a full disk shows up here)
+  bool close_ok() {
+    if (!f) return false;
+    const bool ok = fflush(f) == 0 && !ferror(f);
+    const bool closed = fclose(f) == 0;
+    f = nullptr;
+    return ok && closed;
+  }
 };
 
 const char kMagic[8] = {'I', 'S', 'S', 'C', 'A', 'B', 'A', 'C'};
@@ -54,7 +63,7 @@ int isscabac_write_stream_files(const uint8_t *payload, const uint64_t *offsets,
   for (uint64_t s = 0; s < S; s++) {
     if (offsets[s + 1] < offsets[s]) return engine_fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_write_stream_files: offsets not monotone at stream %llu", (unsigned long long)s);
     File f(paths[s], "wb");
-    if (!f.f || !put(f.f, payload + offsets[s], (size_t)(offsets[s + 1] - offsets[s])))
+    if (!f.f || !put(f.f, payload + offsets[s], (size_t)(offsets[s + 1] - offsets[s])) || !f.close_ok())
       return engine_fail(nullptr, ISSCABAC_ERR_IO, "isscabac_write_stream_files: cannot write '%s'", paths[s] ? paths[s] : "(null)");
   }
   return ISSCABAC_OK;
@@ -64,14 +73,15 @@ int isscabac_read_stream_files(const char *const *paths, uint64_t S, uint8_t *pa
                                uint64_t *total_bytes) {
   if (!paths || !offsets) return engine_fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_read_stream_files: null argument");
   uint64_t off = 0;
-  bool fits = payload != nullptr;
+  bool fits = true;  // (a null payload is fine as long as no byte has to go there: S == 0, or nothing but empty files)
   for (uint64_t s = 0; s < S; s++) {
     File f(paths[s], "rb");
     if (!f.f || fseek(f.f, 0, SEEK_END) != 0) return engine_fail(nullptr, ISSCABAC_ERR_IO, "isscabac_read_stream_files: cannot read '%s'", paths[s] ? paths[s] : "(null)");
     const long len = ftell(f.f);
     if (len < 0 || fseek(f.f, 0, SEEK_SET) != 0) return engine_fail(nullptr, ISSCABAC_ERR_IO, "isscabac_read_stream_files: cannot read '%s'", paths[s]);
     offsets[s] = off;
-    if (fits && off + (uint64_t)len <= cap) {
+    if (len == 0) {
+    } else if (fits && payload && off + (uint64_t)len <= cap) {
       if (!get(f.f, payload + off, (size_t)len)) return engine_fail(nullptr, ISSCABAC_ERR_IO, "isscabac_read_stream_files: short read on '%s'", paths[s]);
     } else {
       fits = false;
@@ -98,7 +108,7 @@ int isscabac_iss_container_write(const char *path, const isscabac_iss_side_info 
   if (!f.f || !put(f.f, kMagic, 8) || !put(f.f, head, sizeof head) || !put(f.f, lens, sizeof lens) ||
       !put(f.f, si->cW, 8ull * si->ncW) || !put(f.f, si->cH, 8ull * si->ncH) ||
       !put(f.f, si->Q, 8ull * si->q_rows * si->q_cols) || !put(f.f, si->xw, si->nxw) || !put(f.f, si->xh, si->nxh) ||
-      !put(f.f, w_stream, (size_t)w_bytes) || !put(f.f, h_stream, (size_t)h_bytes))
+      !put(f.f, w_stream, (size_t)w_bytes) || !put(f.f, h_stream, (size_t)h_bytes) || !f.close_ok())
     return engine_fail(nullptr, ISSCABAC_ERR_IO, "isscabac_iss_container_write: cannot write '%s'", path);
   return ISSCABAC_OK;
 }

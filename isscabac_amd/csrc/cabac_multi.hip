@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +35,18 @@ __global__ void k_rebase_offsets(uint64_t *dst, const uint64_t *src, uint64_t n,
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] + base;
 }
+
+// the public entry points leave the caller's current HIP device as they found it (they, and the calling thread's share of
+// on_all(), switch devices: an FFI or torch caller would otherwise find later raw hipMalloc / launches on the wrong GPU)
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceGuard() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
 
 static void shard_of(uint64_t S, int g, int n, uint64_t *lo, uint64_t *hi) {  // sharding.shard_range
   const uint64_t base = S / n, rem = S % n;
@@ -84,6 +98,7 @@ int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out) {
     m->eng.push_back(e);
     m->dev.push_back(device_ids[g]);
   }
+  DeviceGuard restore;
   m->d_pay.assign(n, nullptr);
   m->pay_cap.assign(n, 0);
   m->d_off.assign(n, nullptr);
@@ -103,6 +118,7 @@ int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out) {
 
 void isscabac_destroy_multi(isscabac_multi *m) {
   if (!m) return;
+  DeviceGuard restore;
   for (size_t g = 0; g < m->eng.size(); g++) {
     (void)hipSetDevice(m->dev[g]);
     if (g < m->d_pay.size() && m->d_pay[g]) (void)hipFree(m->d_pay[g]);
@@ -130,17 +146,21 @@ int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const ui
   if (!bins || !ctx || !payload || !offsets || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_batch: null buffer");
   const int n = (int)m->eng.size();
   // every device codes its shard into a scratch of its own (sizes are not known before), then the pieces are placed
-  std::vector<std::vector<uint8_t>> part(n);
+  std::vector<std::unique_ptr<uint8_t[]>> part(n);  // (new uint8_t[k]: not zeroed -- a value-initialised vector would touch
+  std::vector<uint64_t> part_cap(n, 0);             //  every page of ~3 GiB per Mi streams before the engine writes them)
   std::vector<std::vector<uint64_t>> poff(n);
+  DeviceGuard restore;
   std::vector<uint64_t> tot(n, 0);
   int rc = on_all(m, [&](int g) -> int {
     uint64_t lo, hi;
     shard_of(S, g, n, &lo, &hi);
     if (hi == lo) return ISSCABAC_OK;
-    part[g].resize((hi - lo) * isscabac_stream_bound(nbins));
+    part_cap[g] = (hi - lo) * isscabac_stream_bound(nbins);
+    part[g].reset(new (std::nothrow) uint8_t[part_cap[g]]);
+    if (!part[g]) return engine_fail(m->eng[g], ISSCABAC_ERR_NOMEM, "isscabac_multi_encode_batch: no host memory for %llu scratch bytes", (unsigned long long)part_cap[g]);
     poff[g].resize(hi - lo + 1);
     return isscabac_encode_batch(m->eng[g], bins + lo * pitch, ctx + lo * pitch, nbins_per_stream ? nbins_per_stream + lo : nullptr,
-                                 hi - lo, nbins, pitch, ctx_init, nctx, part[g].data(), part[g].size(), poff[g].data(), &tot[g]);
+                                 hi - lo, nbins, pitch, ctx_init, nctx, part[g].get(), part_cap[g], poff[g].data(), &tot[g]);
   });
   if (rc) return rc;
   uint64_t total = 0;
@@ -151,7 +171,7 @@ int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const ui
   for (int g = 0; g < n; g++) {
     uint64_t lo, hi;
     shard_of(S, g, n, &lo, &hi);
-    if (tot[g]) memcpy(payload + base, part[g].data(), tot[g]);
+    if (tot[g]) memcpy(payload + base, part[g].get(), tot[g]);
     for (uint64_t s = lo; s < hi; s++) offsets[s] = poff[g][s - lo] + base;
     base += tot[g];
   }
@@ -165,15 +185,21 @@ int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const
   if (!m) return ISSCABAC_ERR_ARG;
   if (!payload || !offsets || !ctx || !bins_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: null buffer");
   const int n = (int)m->eng.size();
+  // the whole array once, before any shard touches the payload: the device threads run at the same time, and a shard whose
+  // own slice looks fine would otherwise upload payload[offsets[lo], offsets[hi]) from the caller's buffer although a
+  // later entry shows the array to be malformed (e.g. [0, 1000000, 5]) -- a host read out of bounds.  After this check
+  // every shard's slice lies inside [0, offsets[S]), which is what the caller vouches for.
+  for (uint64_t s = 0; s < S; s++) {
+    if (offsets[s + 1] < offsets[s]) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: offsets not monotone at stream " + std::to_string(s));
+    if (offsets[s + 1] - offsets[s] > 0xFFFFFFFFull) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: stream " + std::to_string(s) + " longer than 4 GiB");
+  }
+  DeviceGuard restore;
   return on_all(m, [&](int g) -> int {
     uint64_t lo, hi;
     shard_of(S, g, n, &lo, &hi);
     if (hi == lo) return ISSCABAC_OK;
     std::vector<uint64_t> off(hi - lo + 1);
-    for (uint64_t s = lo; s <= hi; s++) {
-      if (offsets[s] < offsets[lo]) return engine_fail(m->eng[g], ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: offsets not monotone");
-      off[s - lo] = offsets[s] - offsets[lo];
-    }
+    for (uint64_t s = lo; s <= hi; s++) off[s - lo] = offsets[s] - offsets[lo];
     return isscabac_decode_batch(m->eng[g], payload + offsets[lo], off.data(), ctx + lo * pitch,
                                  nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins, pitch, ctx_init, nctx,
                                  bins_out + lo * pitch, status ? status + lo : nullptr);
@@ -189,6 +215,7 @@ int isscabac_multi_encode_batch_dev(isscabac_multi *m, const uint8_t *const *d_b
   if (!d_bins || !d_ctx || !d_payload_root || !d_offsets_root || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_batch_dev: null buffer");
   const int n = (int)m->eng.size();
   std::vector<uint64_t> tot(n, 0);
+  DeviceGuard restore;
   // 1. every device codes its shard into its own buffers (capacity = the provable bound, so that this cannot fail late)
   int rc = on_all(m, [&](int g) -> int {
     uint64_t lo, hi;

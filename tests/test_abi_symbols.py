@@ -72,6 +72,18 @@ def test_stream_file_container_round_trip(oracle, tmp_path):
     eng.write_stream_files(payload[:9], o3, paths[:3])
     p4, o4 = eng.read_stream_files(paths[:3])
     assert p4.tobytes() == payload[:9].tobytes() and (o4 == o3).all()
+    # nothing but empty files, and no files at all: a NULL payload buffer is fine when no byte has to go there (what a
+    # MEX caller's 0x1 matrix hands over)
+    import ctypes as C
+    L = eng._load()
+    for k in (2, 0):
+        for q in paths[:k]:
+            open(q, "wb").close()
+        arr = (C.c_char_p * max(1, k))(*[q.encode() for q in paths[:k]])
+        off = (C.c_uint64 * (k + 1))(*([7] * (k + 1)))
+        tot = C.c_uint64(99)
+        assert L.isscabac_read_stream_files(arr, k, None, 0, off, C.byref(tot)) == 0
+        assert list(off) == [0] * (k + 1) and tot.value == 0
 
 
 def test_stream_files_interoperate_with_the_reference_decoder(oracle, reference, tmp_path):

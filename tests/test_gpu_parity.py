@@ -405,6 +405,20 @@ def test_iss_context_init_statistics_and_full_iss_flow(engine, oracle):
         assert status[0] == 0 and (sym.reshape(cols, rows).T == G).all()
 
 
+def test_iss_context_init_against_the_independent_fixture(engine):
+    """... and the device histogram against the fixture of the independent restatement (tests/golden/make_f1_fixture.py)"""
+    import json
+    import os
+    from isscabac_amd import SymbolParams
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(root, "tests", "golden", "iss_ctx_init_fixture.json")))
+    for c in fx["cases"]:
+        G = np.array(c["G"], np.uint8)
+        params = SymbolParams.iss(c["nq"], c["method"], c["k"], c["types"], c["nlbp"])
+        p0, _b = engine.iss_init_context_model(G.T.copy(), params)
+        assert p0.tolist() == c["p0"], (G.shape, c["method"], c["types"])
+
+
 def test_c_abi_argument_errors_do_not_crash(engine):
     """bad arguments come back as error codes with a message (the reference would assert or read out of bounds)"""
     import isscabac_amd

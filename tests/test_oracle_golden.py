@@ -157,3 +157,18 @@ def test_p0_map_engine_oracle_and_independent_fixture_agree(oracle):
     assert rc == 0 and (got == want).all()
     # the shape SURVEY 8(a)-9 quotes from its probe of the real code
     assert want[0] == (62 << 1 | 1) and want[127] == (0 << 1 | 1) and want[128] == 0 and want[255] == 62 << 1
+
+
+def test_iss_context_init_against_the_independent_restatement(oracle):
+    """cabacInitContextModel.m is MATLAB (no run of the reference possible here), so the oracle's C
+    restatement is pinned by a second one written apart from it -- Python lists for the cell arrays, straight from the .m
+    text (tests/golden/make_f1_fixture.py): every probability must agree to the last bit."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(root, "tests", "golden", "iss_ctx_init_fixture.json")))
+    assert len(fx["cases"]) >= 8
+    for c in fx["cases"]:
+        G = np.array(c["G"])
+        p0, _b = oracle.iss_init_context_model(G, c["nq"], c["method"], c["k"], c["types"], c["nlbp"])
+        assert p0.tolist() == c["p0"], (G.shape, c["method"], c["types"])
