@@ -168,6 +168,20 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
                           uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
                           uint8_t *bins_out, uint32_t *status);
 
+/* The same two calls with the bins as BITS on the caller's side -- an additive form for host callers, whose cost is the
+ * PCIe link (ref: the bins the reference's callers pass are one value per bin, CABAC/SimpleCABACMex.cpp:210-247, 301-335):
+ * row s of bins_bits / bins_bits_out is pitch / 8 bytes long and holds bin i of stream s at bit i % 8 of byte i / 8
+ * (numpy.packbits(..., bitorder="little")).  ctx stays one byte per bin.  An eighth of the bins' bytes crosses the link;
+ * they are spread to / gathered from bytes on the device.  Results are those of the byte forms. */
+int isscabac_encode_batch_packed(isscabac_engine *e, const uint8_t *bins_bits, const uint8_t *ctx,
+                                 const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins,
+                                 uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                                 uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes);
+int isscabac_decode_batch_packed(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets,
+                                 const uint8_t *ctx, const uint32_t *nbins_per_stream, uint64_t S,
+                                 uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                 uint8_t *bins_bits_out, uint32_t *status);
+
 /* ---- symbol-level batch coding: binariser + context selector fused into the coder kernels -----------------------
  * A stream is a column of integer symbols 0..nq-1 (uint8, stream-major [S][pitch] like the bin arrays).  The kernel
  * binarises (TU: ref CABAC/cabacBinarizer.m:30-37; EGk: :56-69), picks the context of every bin

@@ -461,9 +461,11 @@ uint64_t group_streams(uint64_t S, uint32_t pitch) {
 
 }  // namespace
 
-int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
-                          uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
-                          uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+// packed: `bins` holds one BIT per bin (bin i of a stream at bit i % 8 of byte i / 8 of its row of pitch / 8 bytes): an
+// eighth of the bins' bytes crosses the link and is spread to bytes on the device (k_unpack_bits) in front of the coder
+static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                       uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                       uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, bool packed) {
   BatchShape sh;
   int rc = check_shape(e, "isscabac_encode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
@@ -478,6 +480,7 @@ int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t
   if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
   if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  if (packed && (rc = grow(e, &e->stage[6], &e->stage_bytes[6], in_bytes / 8))) return rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
@@ -495,12 +498,16 @@ int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t
   const uint64_t G = group_streams(S, pitch);
   for (uint64_t s0 = 0; s0 < S; s0 += G) {
     const uint64_t n = std::min(G, S - s0);
-    if ((rc = up.upload(d_bins + s0 * pitch, bins + s0 * pitch, n * pitch))) return rc;
+    uint8_t *d_bits = static_cast<uint8_t *>(e->stage[6]);
+    if (packed) rc = up.upload(d_bits + s0 * (pitch / 8), bins + s0 * (pitch / 8), n * (pitch / 8));
+    else rc = up.upload(d_bins + s0 * pitch, bins + s0 * pitch, n * pitch);
+    if (rc) return rc;
     if ((rc = up.upload(d_ctx + s0 * pitch, ctx + s0 * pitch, n * pitch))) return rc;
     HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
     BatchShape g = sh;
     g.S = n;
+    if (packed) HIP_TRY(e, launch_unpack_bits(d_bits + s0 * (pitch / 8), d_bins + s0 * pitch, n, pitch, e->stream));
     HIP_TRY(e, launch_encode(g, d_bins + s0 * pitch, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, e->slots + s0 * stride, stride,
                              e->lens + s0, e->stream));
   }
@@ -520,9 +527,21 @@ int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t
   return down.drain();
 }
 
-int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
-                          const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
-                          const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status) {
+int isscabac_encode_batch(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                          uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                          uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+  return encode_host(e, bins, ctx, nbins_per_stream, S, nbins, pitch, ctx_init, nctx, payload, payload_cap, offsets, total_bytes, false);
+}
+int isscabac_encode_batch_packed(isscabac_engine *e, const uint8_t *bins_bits, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                                 uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                                 uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+  return encode_host(e, bins_bits, ctx, nbins_per_stream, S, nbins, pitch, ctx_init, nctx, payload, payload_cap, offsets, total_bytes, true);
+}
+
+// packed: the decoded bins come back one BIT per bin (rows of pitch / 8 bytes, see encode_host)
+static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                       const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                       const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status, bool packed) {
   BatchShape sh;
   int rc = check_shape(e, "isscabac_decode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
@@ -539,6 +558,7 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
   if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
   if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
+  if (packed && (rc = grow(e, &e->stage[6], &e->stage_bytes[6], in_bytes / 8))) return rc;
   if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
   uint8_t *d_out = static_cast<uint8_t *>(e->stage[0]), *d_ctx = static_cast<uint8_t *>(e->stage[1]);
   uint32_t *d_nb = nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr;
@@ -567,14 +587,29 @@ int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint
     // streams that start with 0xFF (corrupt input): redone in the reference's own formulation, see isscabac_decode_batch_dev
     HIP_TRY(e, launch_decode_exact(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr,
                                    d_out + s0 * pitch, d_status + s0, e->flag, e->stream));
+    uint8_t *d_bits = static_cast<uint8_t *>(e->stage[6]);
+    if (packed) HIP_TRY(e, launch_pack_bits(d_out + s0 * pitch, d_bits + s0 * (pitch / 8), n, pitch, e->stream));
     HIP_TRY(e, hipEventRecord(e->pipe_ev[1], e->stream));
     HIP_TRY(e, hipStreamWaitEvent(e->d2h_stream, e->pipe_ev[1], 0));
-    if ((rc = down.download(bins_out + s0 * pitch, d_out + s0 * pitch, n * pitch))) return rc;
+    if (packed) rc = down.download(bins_out + s0 * (pitch / 8), d_bits + s0 * (pitch / 8), n * (pitch / 8));
+    else rc = down.download(bins_out + s0 * pitch, d_out + s0 * pitch, n * pitch);
+    if (rc) return rc;
   }
   if (status && (rc = down.download(status, d_status, S * sizeof(uint32_t)))) return rc;
   if ((rc = down.drain())) return rc;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                          const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                          const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status) {
+  return decode_host(e, payload, offsets, ctx, nbins_per_stream, S, nbins, pitch, ctx_init, nctx, bins_out, status, false);
+}
+int isscabac_decode_batch_packed(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                                 const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                 const uint8_t *ctx_init, int nctx, uint8_t *bins_bits_out, uint32_t *status) {
+  return decode_host(e, payload, offsets, ctx, nbins_per_stream, S, nbins, pitch, ctx_init, nctx, bins_bits_out, status, true);
 }
 
 // ---- measurement hooks, utilities -----------------------------------------------------------------------

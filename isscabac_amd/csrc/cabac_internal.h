@@ -32,8 +32,8 @@ struct isscabac_engine {
   uint64_t order_tmp_cap = 0;
   uint32_t *flag = nullptr;  // one word: "some stream needs the reference-formulation decoder" (see launch_decode_exact)
   // staging for the host-buffer entry points
-  void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  uint64_t stage_bytes[6] = {0, 0, 0, 0, 0, 0};
+  void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ([6]: bins as bits, packed forms)
+  uint64_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
   // pinned staging ring of the host-buffer entry points (see HostPipe in cabac_capi.cpp): kPinSlots blocks of kPinBytes,
   // one event each, and two copy streams (H2D and D2H run full duplex beside the compute stream)
   static constexpr int kPinSlots = 6;
@@ -114,6 +114,9 @@ hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, u
 uint64_t order_tmp_bytes(uint64_t S);
 hipError_t launch_order(const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t *d_order, void *d_tmp, uint64_t tmp_bytes,
                         hipStream_t stream);
+// bins as bits <-> bins as bytes (rows of pitch / 8 and pitch bytes), for the packed host-buffer entry points
+hipError_t launch_unpack_bits(const uint8_t *d_packed, uint8_t *d_bins, uint64_t S, uint32_t pitch, hipStream_t stream);
+hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S, uint32_t pitch, hipStream_t stream);
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);

@@ -1552,6 +1552,52 @@ hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_
   ISSCABAC_DISPATCH(run_decode, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bins as bits on the PCIe link (isscabac_encode_batch_packed / isscabac_decode_batch_packed): row s of the packed array
+// holds bin i of stream s at bit i % 8 of byte i / 8 (pitch / 8 bytes per row); one thread moves 16 bins
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unpack_bits(const uint8_t *packed, uint8_t *bins, uint64_t S, uint32_t pitch) {
+  const uint32_t cpr = pitch / 16;  // 16-bin pieces per row
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t r = gid / cpr;
+  const uint32_t c = (uint32_t)(gid % cpr);
+  if (r >= S) return;
+  const uint32_t w = *reinterpret_cast<const uint16_t *>(packed + r * (pitch / 8) + 2 * c);
+  uint32_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t nib = (w >> (4 * k)) & 0xFu;  // bins 4k .. 4k+3 at bits 0..3 -> one byte each
+    o[k] = (nib | nib << 7 | nib << 14 | nib << 21) & 0x01010101u;
+  }
+  *reinterpret_cast<uint4 *>(bins + r * pitch + 16 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ void __launch_bounds__(256) k_pack_bits(const uint8_t *bins, uint8_t *packed, uint64_t S, uint32_t pitch) {
+  const uint32_t cpr = pitch / 16;
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t r = gid / cpr;
+  const uint32_t c = (uint32_t)(gid % cpr);
+  if (r >= S) return;
+  const uint4 v = *reinterpret_cast<const uint4 *>(bins + r * pitch + 16 * c);
+  const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+  uint32_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = in[k] & 0x01010101u;  // bytes of 0 / 1 -> a nibble
+    w |= ((x | x >> 7 | x >> 14 | x >> 21) & 0xFu) << (4 * k);
+  }
+  *reinterpret_cast<uint16_t *>(packed + r * (pitch / 8) + 2 * c) = (uint16_t)w;
+}
+hipError_t launch_unpack_bits(const uint8_t *d_packed, uint8_t *d_bins, uint64_t S, uint32_t pitch, hipStream_t stream) {
+  const uint64_t total = S * (pitch / 16);
+  hipLaunchKernelGGL(k_unpack_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_packed, d_bins, S, pitch);
+  return hipGetLastError();
+}
+hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S, uint32_t pitch, hipStream_t stream) {
+  const uint64_t total = S * (pitch / 16);
+  hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, d_bins, d_packed, S, pitch);
+  return hipGetLastError();
+}
+
 uint64_t scan_tmp_bytes(uint64_t S) { return ((S + kScanBlock - 1) / kScanBlock + 1) * sizeof(uint64_t); }
 
 hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream) {

@@ -121,7 +121,11 @@ def _load():
     L.isscabac_kernel_ms_samples.argtypes = [_vp, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     L.isscabac_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
                                         _u8p, C.c_uint64, _u64p, _u64p]
+    L.isscabac_encode_batch_packed.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                        _u8p, C.c_uint64, _u64p, _u64p]
     L.isscabac_decode_batch.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
+                                        C.c_int, _u8p, _u32p]
+    L.isscabac_decode_batch_packed.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
                                         C.c_int, _u8p, _u32p]
     L.isscabac_symbol_max_bins.argtypes = [C.POINTER(SymbolParams)]
     L.isscabac_symbol_max_bins.restype = C.c_uint32
@@ -407,6 +411,51 @@ class Engine:
                                                   _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
                                                   _ptr(bins, _u8p), _ptr(status, _u32p)))
         return (bins if pitch == B else bins[:, :B].copy()), status
+
+    # ---- the same with the bins as bits on the host side (an eighth of their bytes over the PCIe link) --------------
+    def encode_packed(self, bins_bits, ctx, ctx_init, nbins=None, out=None):
+        """bins_bits: [S, pitch / 8] uint8, bin i of a stream at bit i % 8 of byte i / 8 (numpy.packbits(bins, axis=1,
+        bitorder="little") of rows padded to pitch); ctx: [S, B] uint8.  Otherwise like encode()."""
+        ctx = _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        bits = _np(bins_bits, np.uint8)
+        assert bits.shape == (S, pitch // 8), (bits.shape, (S, pitch // 8))
+        ctxp = self._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        if out is not None:
+            payload, offsets = out
+            cap = payload.size
+        else:
+            cap = S * stream_bound(B)
+            payload, offsets = np.empty(cap, np.uint8), np.zeros(S + 1, np.uint64)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_batch_packed(self._h, _ptr(bits, _u8p), _ptr(ctxp, _u8p), _ptr(nb, _u32p), S, B,
+                                                         pitch, _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
+                                                         _ptr(offsets, _u64p), C.byref(total)))
+        if out is not None:
+            return payload[:int(total.value)], offsets[:S + 1]
+        return payload[:int(total.value)].copy(), offsets
+
+    def decode_packed(self, payload, offsets, ctx, ctx_init, nbins=None, out=None):
+        """Returns (bins as bits uint8[S, pitch / 8], status uint32[S]); numpy.unpackbits(bits, axis=1, bitorder="little")
+        [:, :B] gives the bins.  out: optional (bits buffer, status buffer)."""
+        payload, offsets, ctx = _np(payload, np.uint8), _np(offsets, np.uint64), _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        ctxp = self._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        if out is not None:
+            bits, status = out
+            assert bits.shape == (S, pitch // 8) and bits.dtype == np.uint8 and bits.flags["C_CONTIGUOUS"]
+        else:
+            bits, status = np.empty((S, pitch // 8), np.uint8), np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_decode_batch_packed(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ctxp, _u8p),
+                                                         _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
+                                                         _ptr(bits, _u8p), _ptr(status, _u32p)))
+        return bits, status
 
     # ---- symbol-level batch calls (binariser + context selector fused on the device) --------------------
     def encode_symbols(self, sym, params, ctx_init, nsym=None):

@@ -419,6 +419,33 @@ def test_iss_context_init_against_the_independent_fixture(engine):
         assert p0.tolist() == c["p0"], (G.shape, c["method"], c["types"])
 
 
+def test_packed_host_path_is_byte_exact_against_the_byte_path(engine, oracle):
+    """isscabac_encode_batch_packed / isscabac_decode_batch_packed (bins as bits on the PCIe link): payload, offsets, bins and
+    status words must be those of the byte forms -- several shapes, ragged lengths, bypass bins, a corrupted payload."""
+    rng = np.random.default_rng(77)
+    for S, B, Cn, ragged in [(300, 1000, 64, False), (65, 40, 4, True), (1, 16, 1, False), (2048, 4096, 64, True), (130, 500, 128, True)]:
+        ctx = rng.integers(0, Cn, (S, B)).astype(np.uint8)
+        if Cn <= 128:
+            ctx[rng.random((S, B)) < 0.2] = 0xFF
+        bins = rng.integers(0, 2, (S, B)).astype(np.uint8)
+        init = rng.integers(0, 126, Cn).astype(np.uint8)
+        nb = rng.integers(0, B + 1, S).astype(np.uint32) if ragged else None
+        pitch = max(16, (B + 15) // 16 * 16)
+        padded = np.zeros((S, pitch), np.uint8)
+        padded[:, :B] = bins
+        bits = np.packbits(padded, axis=1, bitorder="little")
+        payload, offsets = engine.encode(bins, ctx, init, nb)
+        p2, o2 = engine.encode_packed(bits, ctx, init, nb)
+        assert p2.tobytes() == payload.tobytes() and (o2 == offsets).all(), (S, B)
+        if payload.size > 40:
+            payload = payload.copy()
+            payload[payload.size // 2] ^= 0x10  # same garbage, same flags, either way
+        dec, status = engine.decode(payload, offsets, ctx, init, nb)
+        dbits, st2 = engine.decode_packed(payload, offsets, ctx, init, nb)
+        got = np.unpackbits(dbits, axis=1, bitorder="little")[:, :B]
+        assert (got == dec).all() and (st2 == status).all(), (S, B)
+
+
 def test_c_abi_argument_errors_do_not_crash(engine):
     """bad arguments come back as error codes with a message (the reference would assert or read out of bounds)"""
     import isscabac_amd

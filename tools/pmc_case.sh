@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() { # name, counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-verify $BARGS > "$OUT/$name.log" 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-verify $BARGS > "$OUT/$name.log" 2>&1
   echo "$OUT $name rc=$?"
 }
 BARGS="$*"
