@@ -12,6 +12,8 @@
 //   SimpleCABACMex('encodeBinProb', h, bin, p) / bin = ('decodeBinProb', h, p)       fixed probability p % of a 1 (ref: encodeBinProb)
 //   [payload, offsets] = ('encodeBatch', h, bins, ctx [, nbins])      bins/ctx: B x S uint8, one stream per column,
 //   [bins, status]     = ('decodeBatch', h, payload, offsets, ctx [, nbins])                        ctx 255 = bypass
+//   [payload, offsets] = ('encodeBatchPacked', h, bits, ctx [, nbins])   bits: (ceil(B/16)*2) x S uint8, bin i of a column at
+//   [bits, status]     = ('decodeBatchPacked', h, payload, offsets, ctx [, nbins])      bit i % 8 of byte i / 8
 //   [payload, offsets, nbins]                         = ('encodeSymbols', h, sym, params [, nsym])   sym: R x S uint8 symbols,
 //   [payload, offsets, nbins, ctxHist, ctxCost, symBits] = ('encodeSymbolsStats', h, sym, params [, nsym])   one stream per column;
 //   [sym, status]                                     = ('decodeSymbols', h, payload, offsets, R, params [, nsym])
@@ -368,6 +370,53 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     plhs[0] = mxCreateNumericMatrix(B, S, mxUINT8_CLASS, mxREAL);
     uint8_t *out = (uint8_t *)mxGetData(plhs[0]);
     for (size_t s = 0; s < S; s++) memcpy(out + s * B, bins + s * pitch, B);
+    if (nlhs > 1) plhs[1] = doubles_of_u32(status, S, 1);
+  } else if (c == "encodeBatchPacked") {
+    // bins as BITS: a (pitch / 8) x S uint8 matrix, bin i of a stream at bit i % 8 of byte i / 8 of its column
+    // (pitch = B rounded up to 16; B = rows of ctx) -- an eighth of the bins' bytes crosses the PCIe link
+    Handle *h = get_handle(nrhs, prhs);
+    if (nrhs < 4 || nrhs > 5) mexErrMsgTxt("Error: encodeBatchPacked needs the handle, the bins as bits, ctx and optionally nbins\n");
+    if (g_multi) mexErrMsgTxt("Error: the packed batch commands run on one device (call setDevices with a single id)\n");
+    const uint8_t *bits = u8_arg(prhs[2], "Error: the packed bins must be a uint8 matrix (one stream per column)\n");
+    const uint8_t *ctx = u8_arg(prhs[3], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const size_t B = mxGetM(prhs[3]), S = mxGetN(prhs[3]);
+    const uint32_t pitch = (uint32_t)((B + 15) / 16 * 16);
+    if (B == 0 || S == 0 || mxGetM(prhs[2]) != pitch / 8 || mxGetN(prhs[2]) != S)
+      mexErrMsgTxt("Error: the packed bins must have ceil(rows(ctx) / 16) * 2 rows and one column per stream\n");
+    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
+    const uint32_t *nb = u32_per_stream(nrhs == 5, nrhs == 5 ? prhs[4] : NULL, S, "Error: nbins must be uint32 with one entry per stream\n");
+    ctx = padded(ctx, B, S, pitch);
+    const uint64_t cap = S * isscabac_stream_bound((uint32_t)B);
+    uint8_t *payload = scratch(cap);
+    uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
+    uint64_t total = 0;
+    engine();
+    check(isscabac_encode_batch_packed(g_engine, bits, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(), (int)h->ctx_init.size(), payload,
+                                       cap, offsets, &total), "encodeBatchPacked");
+    plhs[0] = mxCreateNumericMatrix(total, 1, mxUINT8_CLASS, mxREAL);
+    memcpy(mxGetData(plhs[0]), payload, total);
+    if (nlhs > 1) plhs[1] = doubles_of_u64(offsets, S + 1);
+  } else if (c == "decodeBatchPacked") {
+    Handle *h = get_handle(nrhs, prhs);
+    if (nrhs < 5 || nrhs > 6) mexErrMsgTxt("Error: decodeBatchPacked needs the handle, payload, offsets, ctx and optionally nbins\n");
+    if (g_multi) mexErrMsgTxt("Error: the packed batch commands run on one device (call setDevices with a single id)\n");
+    const uint8_t *payload = u8_arg(prhs[2], "Error: payload must be uint8\n");
+    if (!mxIsClass(prhs[3], "double")) mexErrMsgTxt("Error: offsets must be double\n");
+    const uint8_t *ctx = u8_arg(prhs[4], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const size_t B = mxGetM(prhs[4]), S = mxGetN(prhs[4]);
+    if (mxGetNumberOfElements(prhs[3]) != S + 1 || B == 0 || S == 0) mexErrMsgTxt("Error: offsets must have one entry per stream plus one\n");
+    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
+    uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
+    for (size_t s = 0; s <= S; s++) offsets[s] = (uint64_t)mxGetPr(prhs[3])[s];
+    if (offsets[S] > mxGetNumberOfElements(prhs[2])) mexErrMsgTxt("Error: offsets exceed the payload\n");
+    const uint32_t *nb = u32_per_stream(nrhs == 6, nrhs == 6 ? prhs[5] : NULL, S, "Error: nbins must be uint32 with one entry per stream\n");
+    const uint32_t pitch = (uint32_t)((B + 15) / 16 * 16);
+    ctx = padded(ctx, B, S, pitch);
+    uint32_t *status = (uint32_t *)scratch(S * sizeof(uint32_t));
+    plhs[0] = mxCreateNumericMatrix(pitch / 8, S, mxUINT8_CLASS, mxREAL);  // the bits, straight into the result
+    engine();
+    check(isscabac_decode_batch_packed(g_engine, payload, offsets, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(),
+                                       (int)h->ctx_init.size(), (uint8_t *)mxGetData(plhs[0]), status), "decodeBatchPacked");
     if (nlhs > 1) plhs[1] = doubles_of_u32(status, S, 1);
   } else if (c == "encodeSymbols" || c == "encodeSymbolsStats") {
     // one call per matrix instead of one per bin: binarisation, context selection and coding run on the GPU

@@ -37,6 +37,27 @@ def test_compiles_and_rejects_like_the_reference(gw):
 
 
 @pytest.mark.gpu
+def test_packed_batch_commands_match_the_byte_commands(gw, oracle, tmp_path):
+    """'encodeBatchPacked' / 'decodeBatchPacked': the bins as bits across the gateway, same payload and bins as the byte commands"""
+    rng = np.random.default_rng(3)
+    B, S = 200, 37
+    ctx = rng.integers(0, 3, (B, S)).astype(np.uint8)
+    bins = rng.integers(0, 2, (B, S)).astype(np.uint8)
+    (h,) = gw.call("initByProb", str(tmp_path / "p.bin"), np.array([0.5, 0.3, 0.8]), nlhs=1)
+    payload, offsets = gw.call("encodeBatch", h, bins, ctx, nlhs=2)
+    pitch = (B + 15) // 16 * 16
+    padded = np.zeros((pitch, S), np.uint8)
+    padded[:B] = bins
+    bits = np.packbits(padded, axis=0, bitorder="little")
+    p2, o2 = gw.call("encodeBatchPacked", h, bits, ctx, nlhs=2)
+    assert p2.tobytes() == payload.tobytes() and (o2 == offsets).all()
+    dbits, status = gw.call("decodeBatchPacked", h, p2, o2, ctx, nlhs=2)
+    assert dbits.shape == (pitch // 8, S) and (status == 0).all()
+    assert (np.unpackbits(dbits, axis=0, bitorder="little")[:B] == bins).all()
+    with pytest.raises(MexError, match="packed bins must have"):
+        gw.call("encodeBatchPacked", h, bits[:-1], ctx, nlhs=2)
+
+
 def test_per_bin_commands_round_trip_and_numbits(gw, oracle, golden, tmp_path):
     s = {x["name"]: x for x in golden["streams"]}["lcg200_3ctx"]
     fn = str(tmp_path / "mex.bin")
