@@ -1,11 +1,11 @@
 # usage (GPU box, repo root): bash tools/evidence_run.sh <outdir>
 # bench line, rocprof kernel stats, PMC passes, the stream-count sweep and the other-shape rates of the current build into
-# <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r02
+# <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r03
 set -u
-O=${1:-gpurun_out/r02h}; mkdir -p $O
+O=${1:-gpurun_out/r03h}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify > $O/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify > $O/stats.log 2>&1
 PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config3 > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_config3 > $O/pmc_summary.json
 python3 tools/pmc_case_table.py $O/pmc_config3 1048576 4096 > $O/pmc_table.txt
@@ -22,5 +22,6 @@ echo "== tools/ctx_rates.py"; python tools/ctx_rates.py
 echo "== tools/ragged_rate.py"; python tools/ragged_rate.py
 echo "== tools/symbol_rate.py"; python tools/symbol_rate.py
 echo "== tools/host_api_rate.py"; python tools/host_api_rate.py
+echo "== tools/per_bin_rate.py"; python tools/per_bin_rate.py
 } > $O/other_shapes.txt 2>&1
 tail -3 $O/other_shapes.txt
