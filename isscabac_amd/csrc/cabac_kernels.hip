@@ -190,6 +190,17 @@ struct TileT {
       r[k] = NT ? nt_load16(p) : ld16(p);
     }
   }
+  // ... with the ids read from LDS (ids[row]) when the loads are issued instead of kept in NLD registers
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows_ids(uint4 (&r)[NLD], const uint8_t *base, const uint32_t *ids, uint32_t pitch,
+                                                       uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint8_t *p = base + ((uint64_t)ids[row_of(k, lane)] * pitch + boff);
+      r[k] = NT ? nt_load16(p) : ld16(p);
+    }
+  }
   // part h (bytes 32 h .. 32 h + 31 of the round) of the registers -> LDS
   __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
     if ((int)(ch_of(lane) >> 1) == h) {
@@ -867,8 +878,11 @@ constexpr int kDecTabBytes = 2048;
 #endif
 // the decode kernel's input tile (its one input array: ctx): 128-byte row segments where the registers allow it -- the
 // plain instances; the latency-oriented and the bucketed instances keep 64-byte segments (16 registers instead of 32)
+#ifndef ISSCABAC_DEC_LPR_PERM
+#define ISSCABAC_DEC_LPR_PERM ISSCABAC_DEC_LPR
+#endif
 template <bool LAT, bool PERM>
-using DecTile = TileT<(LAT || PERM) ? 4 : ISSCABAC_DEC_LPR>;
+using DecTile = TileT<LAT ? 4 : PERM ? ISSCABAC_DEC_LPR_PERM : ISSCABAC_DEC_LPR>;
 template <int CM, bool PERM>
 struct DecLds {
   static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
@@ -912,12 +926,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream decoded here
-  uint32_t rid[DTile::NLD] = {};
   if (PERM) {
     const_cast<uint32_t *>(wids)[lane] = (uint32_t)s;
     wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < DTile::NLD; k++) rid[k] = wids[DTile::row_of(k, lane)];
   }
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
@@ -1006,7 +1017,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t nrounds = (a.nbins + DTile::T - 1) / DTile::T;
   uint4 pc[DTile::NLD];
   auto fetch = [&](uint32_t off) {
-    if (PERM) DTile::template load_rows<kDecNT>(pc, a.ctx, rid, a.pitch, off, lane);
+    if (PERM) DTile::template load_rows_ids<kDecNT>(pc, a.ctx, wids, a.pitch, off, lane);
     else DTile::template load<kDecNT>(pc, ctx_w, nrows, a.pitch, off, lane);
   };
   if (nrounds) fetch(0);
