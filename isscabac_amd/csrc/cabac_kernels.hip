@@ -97,9 +97,10 @@ __device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
 // neighbours' are not affected).
 template <int CM>
 constexpr uint32_t not_plain_mask() { return CM == 1 ? 0xC0C0C0C0u : 0x80808080u; }
+// CM 2 (> 128 contexts): the state image is as large as the batch's context count asks for (a multiple of four contexts),
+// `lim` = min(contexts of the image, 255): bytes from lim on are bypass bins (0xFF) or invalid (skipped, like everywhere)
 template <int CM>
-__device__ __forceinline__ bool is_ctx_byte(uint32_t c) { return CM == 1 ? c < 64u : CM == 3 ? c < 128u : c != 0xFFu; }
-// fixed-probability bins exist in batches of at most 128 contexts (with more, bytes 129..254 are context indices)
+__device__ __forceinline__ bool is_ctx_byte(uint32_t c, uint32_t lim) { return CM == 1 ? c < 64u : CM == 3 ? c < 128u : c < lim; }
 template <int CM>
 __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 && is_prob_byte(c); }
 
@@ -123,6 +124,15 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+// some byte of the chunk's 16 ctx bytes names no context of the image (wave-uniform answer).  CM 2: byte >= lim, lim in
+// 129..255, as a carry into bit 7 of the low seven bits (kadd = (256 - lim) in every byte, no carry between bytes)
+template <int CM>
+__device__ __forceinline__ bool chunk_not_plain(const uint4 &wc, uint32_t kadd) {
+  if (CM != 2) return wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
+  auto f = [&](uint32_t x) { return ((x & 0x7F7F7F7Fu) + kadd) & x; };
+  return wave_any(((f(wc.x) | f(wc.y) | f(wc.z) | f(wc.w)) & 0x80808080u) != 0);
+}
+// fixed-probability bins exist in batches of at most 128 contexts (with more, bytes 129..254 are context indices)
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -536,6 +546,7 @@ struct EncArgs {
   uint32_t *lens;
   uint64_t S, slot_stride;
   uint32_t nbins, pitch, nctx;
+  uint32_t img_bytes;  // CM 2: bytes of a wave's state image, 256 per four contexts
   uint32_t ctx_init[64];
 };
 
@@ -583,8 +594,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   if (s0 >= a.S) return;
 
   using WL = WaveLds<CM, PERM>;
-  uint8_t *wbase = smem + kTabBytes + wib * WL::BYTES;
-  uint8_t *tile_b = wbase + WL::SB, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
+  const uint32_t sbytes = CM == 2 ? a.img_bytes : WL::SB;  // the wave's state image
+  const uint32_t ctx_lim = min(sbytes >> 6, 255u), ctx_kadd = (256u - ctx_lim) * 0x01010101u;
+  uint8_t *wbase = smem + kTabBytes + wib * (WL::BYTES - WL::SB + sbytes);
+  uint8_t *tile_b = wbase + sbytes, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
 
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
@@ -613,7 +626,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     // is_ctx_byte() and must find the reference's default ContextModel() (mps 1, state 0: the C ABI pads ctx_init
     // with it), never a stale LDS byte -- a stale 0xFC..0xFF would be state 63, whose LPS of 2 shifts 7 bits per bin
     // and overruns the slot bound of 6
-    constexpr uint32_t ngrp = WL::SB / 256;
+    const uint32_t ngrp = sbytes / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   LdsStates stx{wbase + lane * 4};
@@ -682,7 +695,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const uint4 wb = BTile::row_chunk(tile_b, lane, j);
         const uint4 wc = CTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
-        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
+        const bool hi = chunk_not_plain<CM>(wc, ctx_kadd);
         if (LAT && full && !hi) {
           // every lane codes 16 context bins, the state pass issued by hand (EncLatPipe): the lookup of bin j goes out as
           // soon as the successor of bin j - 1 is back, and the range / low arithmetic of bin j - 1 runs behind it
@@ -771,7 +784,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
             if (full || i0 + k < n) {
               const uint32_t cb = byte_of(wc, k);
-              if (is_ctx_byte<CM>(cb)) {
+              if (is_ctx_byte<CM>(cb, ctx_lim)) {
                 if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1, 0u}, stx.addr_of(z, 0), stx);
                 else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1, 0u}, stx.addr_of(z, 1), stx);
                 else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1, 0u}, stx.addr_of(z, 2), stx);
@@ -852,6 +865,7 @@ struct DecArgs {
   uint32_t *exact_flag;  // set when a stream of this launch needs k_decode_exact
   uint64_t S, payload_bytes;
   uint32_t nbins, pitch, nctx;
+  uint32_t img_bytes;  // as in EncArgs
   uint32_t ctx_init[64];
 };
 
@@ -918,8 +932,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   using DL = DecLds<CM, PERM>;
   using DTile = DecTile<LAT, PERM>;
   static_assert(DTile::H * 64 == DL::TILE, "half tile");
-  uint8_t *wbase = smem + kDecTabBytes + wib * DL::BYTES;
-  uint8_t *tile_c = wbase + DL::SB;
+  const uint32_t sbytes = CM == 2 ? a.img_bytes : DL::SB;  // the wave's state image
+  const uint32_t ctx_lim = min(sbytes >> 6, 255u), ctx_kadd = (256u - ctx_lim) * 0x01010101u;
+  uint8_t *wbase = smem + kDecTabBytes + wib * (DL::BYTES - DL::SB + sbytes);
+  uint8_t *tile_c = wbase + sbytes;
   uint32_t *obuf = reinterpret_cast<uint32_t *>(tile_c + DL::TILE);
   const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_c + DL::TILE + OutBuf::BYTES);  // PERM: the wave's stream ids
 
@@ -942,7 +958,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     // is_ctx_byte() and must find the reference's default ContextModel() (mps 1, state 0: the C ABI pads ctx_init
     // with it), never a stale LDS byte -- a stale 0xFC..0xFF would be state 63, whose LPS of 2 shifts 7 bits per bin
     // and overruns the slot bound of 6
-    constexpr uint32_t ngrp = DL::SB / 256;
+    const uint32_t ngrp = sbytes / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   LdsStates stx{wbase + lane * 4};
@@ -1087,7 +1103,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         if (live) {
         const uint4 wc = DTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
-        const bool hi = wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
+        const bool hi = chunk_not_plain<CM>(wc, ctx_kadd);
         // One bit-granular top-up per four bins (sh = 23 afterwards).  Four context or bypass bins shift at most 22 bits
         // (tests/lane_harness.cpp: lane_max_shift_sum), so the plain and mixed words never run short and carry no guard;
         // the window is re-based at the chunk boundary and, wave-uniformly, whenever a lane has fewer than the 24 bits a
@@ -1183,7 +1199,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
               uint32_t w = 0;
               if (full || i0 + 4 * g + k < n) {
                 const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
-                if (is_ctx_byte<CM>(cb)) {
+                if (is_ctx_byte<CM>(cb, ctx_lim)) {
                   const uint32_t ak = stx.addr32_of(z, k);
                   w = dec_bin_nx(d, ak, stx.load_at(ak), stx);
                 } else if (cb == kBypass || cb == kProbBase + 50u) {
@@ -1448,15 +1464,17 @@ uint64_t slot_stride_for(uint32_t nbins) {
 }
 
 template <int CM, bool PERM>
-static size_t coder_lds_bytes() {
-  return kTabBytes + waves_per_block(CM) * WaveLds<CM, PERM>::BYTES;
+static size_t coder_lds_bytes(uint32_t img_bytes) {
+  return kTabBytes + waves_per_block(CM) * (WaveLds<CM, PERM>::BYTES - WaveLds<CM, PERM>::SB + (CM == 2 ? img_bytes : WaveLds<CM, PERM>::SB));
 }
+// CM 2: a wave's state image covers the batch's contexts in whole groups of four (a.nctx > 128 there)
+static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<CM, PERM>();
+  const size_t lds = coder_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)coder_lds_bytes<CM, PERM>(16384));
   if (err != hipSuccess) return err;
   // LdsStates<.., NEXT16> addresses its table by absolute LDS address: the dynamic LDS must start at 0
   static int static_lds = -1;
@@ -1477,9 +1495,11 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
 #ifndef ISSCABAC_DEC_LDS_PAD  // (occupancy experiments: bytes of unused LDS per workgroup)
 #define ISSCABAC_DEC_LDS_PAD 0
 #endif
-  const size_t lds = kDecTabBytes + waves_per_block(CM) * DecLds<CM, PERM>::BYTES + ISSCABAC_DEC_LDS_PAD;
+  using DL = DecLds<CM, PERM>;
+  const size_t lds_max = kDecTabBytes + waves_per_block(CM) * DL::BYTES + ISSCABAC_DEC_LDS_PAD;
+  const size_t lds = CM == 2 ? lds_max - DL::SB + a.img_bytes : lds_max;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
   if (err != hipSuccess) return err;
   static int static_lds = -1;  // absolute LDS addresses, as in run_encode
   if (static_lds < 0) {
@@ -1522,6 +1542,7 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
   a.nbins = sh.nbins;
   a.pitch = sh.pitch;
   a.nctx = sh.nctx;
+  a.img_bytes = image_bytes_for(sh.nctx);
   std::memcpy(a.ctx_init, sh.ctx_init, 256);
   ISSCABAC_DISPATCH(run_encode, a);
 }
@@ -1542,6 +1563,7 @@ static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_pay
   a.nbins = sh.nbins;
   a.pitch = sh.pitch;
   a.nctx = sh.nctx;
+  a.img_bytes = image_bytes_for(sh.nctx);
   std::memcpy(a.ctx_init, sh.ctx_init, 256);
 }
 

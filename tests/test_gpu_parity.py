@@ -68,6 +68,10 @@ def test_golden_streams_as_one_ragged_batch(engine, golden, oracle):
     (1024, 8192, 64, 0xCABAC005, True),         # config 5 shape, 50% bypass
     (300, 1000, 255, 0x1234, False),            # 255 contexts -> big LDS state variant, B % 16 != 0
     (333, 2000, 100, 0x4321, False),            # 65..128 contexts -> the 8 KiB state variant
+    (200, 1500, 190, 0x190, False),             # > 128 contexts: state image sized by the context count (12 KiB)
+    (200, 1500, 190, 0x191, True),              # ... with bypass bins (0xFF lies beyond the image's last context)
+    (130, 700, 129, 0x129, True),               # the smallest such image
+    (130, 700, 253, 0x253, True),               # the largest (16 KiB: only 0xFF is no context)
     (130, 500, 128, 0x99, True),
     (65, 40, 4, 0x77, False),
     (1, 16, 1, 0x5, False),
@@ -82,6 +86,31 @@ def test_synthetic_shapes_vs_oracle(engine, oracle, S, B, C, seed, ep):
     dec, status = engine.decode(payload, offsets, ctx, init)
     assert (status == 0).all()
     assert (dec == bins).all()
+
+
+def test_ctx_bytes_beyond_the_state_image_leave_other_streams_alone(engine, oracle):
+    """include/isscabac.h: a ctx byte that is neither a context index nor 0xFF leaves that stream's result unspecified and
+    the other streams of the batch untouched.  With more than 128 contexts the state image ends at the batch's last group
+    of four contexts: bytes behind it must not reach LDS."""
+    rng = np.random.default_rng(190)
+    S, B, C = 192, 640, 150
+    ctx = rng.integers(0, C, (S, B)).astype(np.uint8)
+    ctx[rng.random((S, B)) < 0.05] = 0xFF
+    bins = rng.integers(0, 2, (S, B)).astype(np.uint8)
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    want_payload, want_off = oracle.encode_batch(bins, ctx, init)
+    dirty = ctx.copy()
+    bad_rows = [3, 64, 130, 191]
+    for s in bad_rows:
+        dirty[s, rng.integers(0, B, 40)] = rng.integers(152, 255, 40)  # behind the image of 152 contexts
+    payload, offsets = engine.encode(bins, dirty, init)
+    dec, status = engine.decode(payload, offsets, dirty, init)
+    for s in range(S):
+        if s in bad_rows:
+            continue
+        assert payload[int(offsets[s]):int(offsets[s + 1])].tobytes() == \
+            want_payload[int(want_off[s]):int(want_off[s + 1])].tobytes(), s
+        assert status[s] == 0 and (dec[s] == bins[s]).all(), s
 
 
 def test_golden_synthetic_payloads(engine, golden, oracle):

@@ -58,6 +58,7 @@ def test_packed_batch_commands_match_the_byte_commands(gw, oracle, tmp_path):
         gw.call("encodeBatchPacked", h, bits[:-1], ctx, nlhs=2)
 
 
+@pytest.mark.gpu
 def test_per_bin_commands_round_trip_and_numbits(gw, oracle, golden, tmp_path):
     s = {x["name"]: x for x in golden["streams"]}["lcg200_3ctx"]
     fn = str(tmp_path / "mex.bin")
