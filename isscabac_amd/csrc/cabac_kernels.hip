@@ -981,6 +981,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   // v now holds the stream's first four bytes.  A first byte of 0xFF (corrupt input only) makes the reference's value
   // register overflow: those streams are decoded again, in the reference's formulation, by k_decode_exact
   if (valid && needs_ref_decoder(d.v >> 24) && a.exact_flag) *a.exact_flag = 1u;
+  // the loop's core is the absolute form (cabac_lane.h: DecAbs, R = range << sh); the general path converts for its chunk
+  DecAbs da = dec_to_abs(d);
 
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
@@ -1128,7 +1130,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check
             // then covers words 2 and 3
             if (g == 2) src.ensure(47);
-            dec_topup_nocheck(d, src);
+            dec_topup_abs(da, src);
             if (LAT) {
 #pragma unroll
               for (int k = 0; k < 4; k++) {
@@ -1139,7 +1141,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   at_next = stx.addr32_of(zl, (k + 1) & 3);
                   qld = stx.load_at(at_next);
                 }
-                nx_prev = dec_bin_nx(d, at, q, stx);
+                nx_prev = k == 0 ? dec_bin_nx_abs<true>(da, at, q, stx) : dec_bin_nx_abs<false>(da, at, q, stx);
                 if (k == 0) put_out_byte<0>(oa, ob, nx_prev);
                 else if (k == 1) put_out_byte<1>(oa, ob, nx_prev);
                 else if (k == 2) put_out_byte<2>(oa, ob, nx_prev);
@@ -1150,10 +1152,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             } else {
               const CtxQuad z = stx.prep4(word_of(wc, g));
               const uint32_t a0 = stx.addr32_of(z, 0), a1 = stx.addr32_of(z, 1), a2 = stx.addr32_of(z, 2), a3 = stx.addr32_of(z, 3);
-              dec_bin_out<0>(d, a0, stx.load_at(a0), stx, oa, ob);
-              dec_bin_out<1>(d, a1, stx.load_at(a1), stx, oa, ob);
-              dec_bin_out<2>(d, a2, stx.load_at(a2), stx, oa, ob);
-              dec_bin_out<3>(d, a3, stx.load_at(a3), stx, oa, ob);
+              dec_bin_out_abs<0, true>(da, a0, stx.load_at(a0), stx, oa, ob);
+              dec_bin_out_abs<1, false>(da, a1, stx.load_at(a1), stx, oa, ob);
+              dec_bin_out_abs<2, false>(da, a2, stx.load_at(a2), stx, oa, ob);
+              dec_bin_out_abs<3, false>(da, a3, stx.load_at(a3), stx, oa, ob);
             }
             od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
@@ -1169,12 +1171,14 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           for (int g = 0; g < 4; g++) {
             if (g == 2) src.ensure(47);
             const uint32_t cw = word_of(wc, g);
-            dec_topup_nocheck(d, src);
+            dec_topup_abs(da, src);
             const CtxQuad zs = stx.prep4(cw & kIn);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const uint32_t ak = stx.addr32_of(zs, k);
-              const uint32_t nx = dec_bin_mixed_nx(d, byte_bit_mask(cw, k, 7), ak, stx.load_at(ak), stx);
+              const uint32_t mbk = byte_bit_mask(cw, k, 7);
+              const uint32_t nx = k == 0 ? dec_bin_mixed_nx_abs<true>(da, mbk, ak, stx.load_at(ak), stx)
+                                         : dec_bin_mixed_nx_abs<false>(da, mbk, ak, stx.load_at(ak), stx);
               if (k == 0) put_out_byte<0>(oa, ob, nx);
               else if (k == 1) put_out_byte<1>(oa, ob, nx);
               else if (k == 2) put_out_byte<2>(oa, ob, nx);
@@ -1187,6 +1191,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           // takes its own branch under the exec mask -- context bin, bypass bin, fixed-probability bin, or nothing (its
           // output reads 0) once its stream is over.  Three bins after a top-up cannot run short (<= 6 bits each); the
           // fourth is guarded, wave-uniformly.
+          dec_from_abs(d, da);
 #pragma unroll
           for (int g = 0; g < 4; g++) {
             if (g == 2) src.ensure(47);
@@ -1215,6 +1220,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             }
             od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
+          da = dec_to_abs(d);
         }
         }
         obuf[OutBuf::idx(cidx, lane)] = od;
@@ -1237,6 +1243,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     (void)clip_stream(first, first, a.payload_bytes);
     const uint32_t sk = (uint32_t)first & 3u;
     const uint8_t *p = a.payload + first;
+    dec_from_abs(d, da);
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
 #if ISSCABAC_EXP_CLK
     const uint64_t tot = __builtin_amdgcn_s_memtime() - clk_start;

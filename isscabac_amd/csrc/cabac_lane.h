@@ -901,6 +901,147 @@ CABAC_HD uint32_t dec_bin_mixed_nx(DecCore &d, uint32_t mb, Addr at, uint32_t qb
   return nx;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The decode kernel's core in absolute form: R = range << sh in place of (range, sh).  v is compared with (range - LPS) << sh
+// anyway, so the kernel keeps the range at v's scale and never normalises it: a bin's renormalisation is no work at all
+// (R simply becomes the smaller number), the comparison point is read off R when it is needed (sh = 23 - clz(R): the
+// 9-bit range has its bit 8 set) and LPS << sh is the only shift left on the recurrence.  Against the step on (range, sh)
+// (dec_bin_out): ffbh, two subtractions, a right shift and one left shift instead of ffbh, two subtractions, a right
+// shift and two left shifts -- and the first bin after a top-up (R's bit 31 set: FIRST) knows both positions as
+// constants.  Same decisions, same values: R == d.range << d.sh at every bin (dec_to_abs / dec_from_abs convert).
+// ------------------------------------------------------------------------------------------------
+struct DecAbs {
+  uint32_t v;
+  uint32_t R;
+};
+CABAC_HD DecAbs dec_to_abs(const DecCore &d) {
+  DecAbs a;
+  a.v = d.v;
+  a.R = d.range << d.sh;
+  return a;
+}
+CABAC_HD void dec_from_abs(DecCore &d, const DecAbs &a) {
+  const uint32_t sh = 23u - clz32(a.R);
+  d.v = a.v;
+  d.sh = (int32_t)sh;
+  d.range = a.R >> sh;
+}
+// bit-granular top-up: R's leading one to bit 31 (sh = 23), v along with it (dec_topup_nocheck)
+template <class Src>
+CABAC_HD void dec_topup_abs(DecAbs &a, Src &src) {
+  const uint32_t c = clz32(a.R);
+  a.R <<= c;
+  a.v = src.feed_nocheck(a.v, c);
+}
+// rangeTabLps[state][column] out of the state's row, column + 4 given (4..7, zeros above: see lps_of)
+CABAC_HD uint32_t lps_col(uint32_t row, uint32_t col4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(row, 0u, col4);
+#else
+  return (row >> (8u * (col4 & 3u))) & 0xFFu;
+#endif
+}
+// LPS << sh for the range R stands for
+template <bool FIRST>
+CABAC_HD uint32_t abs_lps(uint32_t row, uint32_t R) {
+  if (FIRST) return lps_col(row, R >> 29) << 23;
+  const uint32_t t = 29u - clz32(R);  // sh + 6
+  return lps_col(row, R >> t) << (t - 6u);
+}
+// dec_bin_out in absolute form
+template <int K, bool FIRST, class States, class Addr>
+CABAC_HD void dec_bin_out_abs(DecAbs &a, Addr at, uint32_t qb, States &st, uint32_t &oa, uint32_t &ob) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lpss = abs_lps<FIRST>((uint32_t)ent, a.R);
+  const uint32_t rmps = a.R - lpss;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t &o = (K & 1) ? ob : oa;
+  uint32_t diff, r;
+#define ISSCABAC_DEC_OUT(SEL, UNUSED, OC)                                                                              \
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"                                                                           \
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:" SEL " dst_unused:" UNUSED " src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"   \
+      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"                                                                          \
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"                                                                              \
+      : "=&v"(diff), OC(o), "=&v"(r)                                                                                   \
+      : "v"(a.v), "v"(rmps), "v"((uint32_t)(ent >> 32)), "v"(lpss)                                                     \
+      : "vcc")
+  if (K & 2) {
+    ISSCABAC_DEC_OUT("BYTE_2", "UNUSED_PRESERVE", "+v");
+    st.store_at_hi(at, o);
+  } else {
+    ISSCABAC_DEC_OUT("BYTE_0", "UNUSED_PAD", "=&v");
+    st.store_at(at, o);
+  }
+#undef ISSCABAC_DEC_OUT
+  a.v = diff;
+  a.R = r;
+#else
+  const bool mps_path = a.v < rmps;
+  const uint32_t nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  put_out_byte<K>(oa, ob, nx);
+  st.store_at(at, nx);
+  a.R = mps_path ? rmps : lpss;
+  a.v = mps_path ? a.v : a.v - rmps;
+#endif
+}
+// dec_bin_nx in absolute form
+template <bool FIRST, class States, class Addr>
+CABAC_HD uint32_t dec_bin_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lpss = abs_lps<FIRST>((uint32_t)ent, a.R);
+  const uint32_t rmps = a.R - lpss;
+  uint32_t nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t diff, r;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(a.v), "v"(rmps), "v"((uint32_t)(ent >> 32)), "v"(lpss)
+      : "vcc");
+  a.v = diff;
+  a.R = r;
+#else
+  const bool mps_path = a.v < rmps;
+  nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  a.R = mps_path ? rmps : lpss;
+  a.v = mps_path ? a.v : a.v - rmps;
+#endif
+  st.store_at(at, nx);
+  return nx;
+}
+// dec_bin_mixed_nx in absolute form: a bypass lane (mb = ~0) decides against R >> 1, which is its new R either way
+template <bool FIRST, class States, class Addr>
+CABAC_HD uint32_t dec_bin_mixed_nx_abs(DecAbs &a, uint32_t mb, Addr at, uint32_t qb, States &st) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t lpss = abs_lps<FIRST>((uint32_t)ent, a.R);
+  const uint32_t half = a.R >> 1;
+  const uint32_t cmpv = select_mask(mb, half, a.R - lpss);
+  const uint32_t rl = select_mask(mb, half, lpss);
+  const uint32_t hi = select_mask(mb, 0x0001u, (uint32_t)(ent >> 32));
+  uint32_t nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t diff, r;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(a.v), "v"(cmpv), "v"(hi), "v"(rl)
+      : "vcc");
+  a.v = diff;
+  a.R = r;
+#else
+  const bool below = a.v < cmpv;
+  nx = (hi >> (below ? 8 : 0)) & 0xFFu;
+  a.R = below ? cmpv : rl;
+  a.v = below ? a.v : a.v - cmpv;
+#endif
+  st.store_at(at, select_mask(mb, qb, nx));
+  return nx;
+}
+
 // The decoder's select-based step for chunks that mix context-coded and bypass bins (see enc_bin_mixed_acc): a bypass
 // bin compares the value with the whole range one bit further down (ref: CABAC_ArithmeticDecoder.cpp:288-331) and leaves
 // range and state alone.  Returns the (mps, path) pair of dec_bin_at_mem; a bypass bin reports mps 0, which makes

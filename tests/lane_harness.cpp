@@ -5,6 +5,7 @@
 //
 //   g++ -O1 -g -shared -fPIC [-fsanitize=address,undefined] -I isscabac_amd/csrc tests/lane_harness.cpp
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -373,7 +374,8 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
                                 uint32_t n, const uint8_t *ctx_init, int nctx, int lat, uint8_t *bins_out,
                                 uint8_t *ctx_final, uint32_t *path_counts /* [plain, mixed, general] chunks */) {
   const int cm = nctx <= 64 ? 1 : nctx <= 128 ? 3 : 2;
-  auto is_ctx = [&](uint32_t c) { return cm == 1 ? c < 64u : cm == 3 ? c < 128u : c != 0xFFu; };
+  const uint32_t lim = std::min(4u * (((uint32_t)nctx + 3u) / 4u), 255u);  // cm 2: contexts of the state image (k_decode: ctx_lim)
+  auto is_ctx = [&](uint32_t c) { return cm == 1 ? c < 64u : cm == 3 ? c < 128u : c < lim; };
   auto is_prob = [&](uint32_t c) { return cm != 2 && is_prob_byte(c); };
   HostStates st;
   st.init(ctx_init, nctx);
@@ -386,6 +388,7 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
   src.boundary();
   DecCore d;
   dec_start(d, src);
+  DecAbs da = dec_to_abs(d);  // the kernel's loop-carried core: R = range << sh
   uint32_t bad = 0;
   for (uint32_t i0 = 0; i0 < n; i0 += 16) {
     src.boundary();
@@ -394,7 +397,7 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
     const bool full = i0 + 16 <= n;
     bool hi = false, odd = false;
     for (uint32_t k = 0; k < 16; k++) {
-      hi |= (cb[k] & (cm == 1 ? 0xC0u : 0x80u)) != 0;
+      hi |= cm == 2 ? cb[k] >= lim : (cb[k] & (cm == 1 ? 0xC0u : 0x80u)) != 0;
       odd |= (cb[k] & 0x80u) && cb[k] != 0xFFu;
     }
     uint32_t ow[4] = {0, 0, 0, 0}, oa = 0, ob = 0;
@@ -403,8 +406,8 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
       uint32_t at = cb[0], at_prev = 0, nx_prev = 0, qld = lat ? st.load_at(at) : 0;
       for (int g = 0; g < 4; g++) {
         if (g == 2) src.ensure(47);
-        if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
-        dec_topup_nocheck(d, src);
+        if (src.avail_bits() < (int32_t)clz32(da.R)) bad = 0xDEAD1000u;
+        dec_topup_abs(da, src);
         for (int k = 0; k < 4; k++) {
           const int i = 4 * g + k;
           if (lat) {
@@ -414,7 +417,7 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
               at_next = cb[i + 1];
               qld = st.load_at(at_next);
             }
-            nx_prev = dec_bin_nx(d, at, q, st);
+            nx_prev = k == 0 ? dec_bin_nx_abs<true>(da, at, q, st) : dec_bin_nx_abs<false>(da, at, q, st);
             if (k == 0) put_out_byte<0>(oa, ob, nx_prev);
             else if (k == 1) put_out_byte<1>(oa, ob, nx_prev);
             else if (k == 2) put_out_byte<2>(oa, ob, nx_prev);
@@ -423,12 +426,12 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
             at = at_next;
           } else {
             const uint32_t a = cb[i];
-            if (k == 0) dec_bin_out<0>(d, a, st.load_at(a), st, oa, ob);
-            else if (k == 1) dec_bin_out<1>(d, a, st.load_at(a), st, oa, ob);
-            else if (k == 2) dec_bin_out<2>(d, a, st.load_at(a), st, oa, ob);
-            else dec_bin_out<3>(d, a, st.load_at(a), st, oa, ob);
+            if (k == 0) dec_bin_out_abs<0, true>(da, a, st.load_at(a), st, oa, ob);
+            else if (k == 1) dec_bin_out_abs<1, false>(da, a, st.load_at(a), st, oa, ob);
+            else if (k == 2) dec_bin_out_abs<2, false>(da, a, st.load_at(a), st, oa, ob);
+            else dec_bin_out_abs<3, false>(da, a, st.load_at(a), st, oa, ob);
           }
-          if (d.sh < 0) bad = 0xDEAD0000u | (i0 + i);
+          if (da.R < 512u) bad = 0xDEAD0000u | (i0 + i);  // sh >= 1 (the range is 256..510): R >> 1 stays exact
         }
         ow[g] = out_word(oa, ob);
       }
@@ -437,21 +440,24 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
       const uint32_t in = cm == 1 ? 0x3Fu : 0x7Fu;
       for (int g = 0; g < 4; g++) {
         if (g == 2) src.ensure(47);
-        if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
-        dec_topup_nocheck(d, src);
+        if (src.avail_bits() < (int32_t)clz32(da.R)) bad = 0xDEAD1000u;
+        dec_topup_abs(da, src);
         for (int k = 0; k < 4; k++) {
           const uint32_t c = cb[4 * g + k], a = c & in;
-          const uint32_t nx = dec_bin_mixed_nx(d, (c & 0x80u) ? ~0u : 0u, a, st.load_at(a), st);
+          const uint32_t mbk = (c & 0x80u) ? ~0u : 0u;
+          const uint32_t nx = k == 0 ? dec_bin_mixed_nx_abs<true>(da, mbk, a, st.load_at(a), st)
+                                     : dec_bin_mixed_nx_abs<false>(da, mbk, a, st.load_at(a), st);
           if (k == 0) put_out_byte<0>(oa, ob, nx);
           else if (k == 1) put_out_byte<1>(oa, ob, nx);
           else if (k == 2) put_out_byte<2>(oa, ob, nx);
           else put_out_byte<3>(oa, ob, nx);
-          if (d.sh < 0) bad = 0xDEAD0000u | (i0 + 4 * g + k);
+          if (da.R < 256u) bad = 0xDEAD0000u | (i0 + 4 * g + k);
         }
         ow[g] = out_word(oa, ob);
       }
     } else {
       if (path_counts) path_counts[2]++;
+      dec_from_abs(d, da);
       for (int g = 0; g < 4; g++) {
         if (g == 2) src.ensure(47);
         if (src.avail_bits() < 23 - d.sh) bad = 0xDEAD1000u;
@@ -473,11 +479,13 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
         }
         ow[g] = out_word(oa, ob);
       }
+      da = dec_to_abs(d);
     }
     for (uint32_t k = 0; k < 16 && i0 + k < n; k++) bins_out[i0 + k] = (uint8_t)((ow[k >> 2] >> (8 * (k & 3))) & 1u);
   }
   if (bad) return bad;
   const uint8_t *p = buf + start;
+  dec_from_abs(d, da);
   const uint32_t status = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   if (ctx_final) st.final_packed(ctx_final, nctx);
   return status;
