@@ -106,7 +106,15 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 
 // waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
 // let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
-constexpr int waves_per_block(int cm) { return cm == 1 ? 4 : 1; }
+#ifndef ISSCABAC_ENC_WPB
+#define ISSCABAC_ENC_WPB 4
+#endif
+#ifndef ISSCABAC_DEC_WPB
+#define ISSCABAC_DEC_WPB 4
+#endif
+// waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
+constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
+constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
 constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
                                  // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
                                  // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
@@ -590,7 +598,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabRowOff / 4 + 2 * ps + 1] = enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
+  const uint64_t s0 = ((uint64_t)blockIdx.x * enc_waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
   using WL = WaveLds<CM, PERM>;
@@ -926,7 +934,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   }
 #endif
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * waves_per_block(CM) + wib) * 64;
+  const uint64_t s0 = ((uint64_t)blockIdx.x * dec_waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
 
   using DL = DecLds<CM, PERM>;
@@ -1472,7 +1480,7 @@ uint64_t slot_stride_for(uint32_t nbins) {
 
 template <int CM, bool PERM>
 static size_t coder_lds_bytes(uint32_t img_bytes) {
-  return kTabBytes + waves_per_block(CM) * (WaveLds<CM, PERM>::BYTES - WaveLds<CM, PERM>::SB + (CM == 2 ? img_bytes : WaveLds<CM, PERM>::SB));
+  return kTabBytes + enc_waves_per_block(CM) * (WaveLds<CM, PERM>::BYTES - WaveLds<CM, PERM>::SB + (CM == 2 ? img_bytes : WaveLds<CM, PERM>::SB));
 }
 // CM 2: a wave's state image covers the batch's contexts in whole groups of four (a.nctx > 128 there)
 static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
@@ -1492,8 +1500,8 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * enc_waves_per_block(CM) - 1) / (64 * enc_waves_per_block(CM));
+  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * enc_waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1503,7 +1511,7 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
 #define ISSCABAC_DEC_LDS_PAD 0
 #endif
   using DL = DecLds<CM, PERM>;
-  const size_t lds_max = kDecTabBytes + waves_per_block(CM) * DL::BYTES + ISSCABAC_DEC_LDS_PAD;
+  const size_t lds_max = kDecTabBytes + dec_waves_per_block(CM) * DL::BYTES + ISSCABAC_DEC_LDS_PAD;
   const size_t lds = CM == 2 ? lds_max - DL::SB + a.img_bytes : lds_max;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -1516,8 +1524,8 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * waves_per_block(CM) - 1) / (64 * waves_per_block(CM));
-  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * waves_per_block(CM)), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * dec_waves_per_block(CM) - 1) / (64 * dec_waves_per_block(CM));
+  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * dec_waves_per_block(CM)), lds, stream, a);
   return hipGetLastError();
 }
 

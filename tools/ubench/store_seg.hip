@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(256, 4) k(const uint8_t *in, uint8_t *out, uin
 
 // LSEG: bytes per row and load instruction group (64: 4 lanes per row, every round; 128: 8 lanes per row, every second round)
 // NIN: input arrays (1: ctx, decoder; 2: bins + ctx, encoder); STORE: 128-byte output segments every second round
-template <int LSEG, int NIN, bool STORE>
+// TOUCH: every TOUCH-th round lane l also reads one dword of each of the next TOUCH - 1 lines of row l (a plain load whose
+// result is dropped): the memory controller then sees TOUCH adjacent 128-byte lines of a row at a time, the demand loads of
+// the following rounds find theirs in L2 / the memory-side cache
+template <int LSEG, int NIN, bool STORE, int TOUCH = 0, bool NTLD = true>
 __global__ void __launch_bounds__(256, 4) k2(const uint8_t *in, const uint8_t *in2, uint8_t *out, uint32_t pitch, int sleeps, unsigned *sink) {
   extern __shared__ uint8_t smem[];
   const int lane = threadIdx.x & 63;
@@ -78,8 +81,14 @@ __global__ void __launch_bounds__(256, 4) k2(const uint8_t *in, const uint8_t *i
 #pragma unroll
       for (int k2i = 0; k2i < NI; k2i++) {
         const uint32_t row = k2i * RPI + lane / LPR;
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(inw + row * pitch + off + (lane % LPR) * 16));
+        const u32x4 *pp = reinterpret_cast<const u32x4 *>(inw + row * pitch + off + (lane % LPR) * 16);
+        const u32x4 v = NTLD ? __builtin_nontemporal_load(pp) : *pp;
         r[a][k2i] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      if (TOUCH > 1 && (off / LSEG) % TOUCH == 0) {
+#pragma unroll
+        for (int j = 1; j < TOUCH; j++)
+          if (off + j * LSEG < pitch) acc += *reinterpret_cast<const volatile uint32_t *>(inw + lane * pitch + off + j * LSEG) & 0x100u;
       }
     }
     for (int i = 0; i < sleeps * (LSEG / 64); i++) __builtin_amdgcn_s_sleep(127);
@@ -151,6 +160,16 @@ int main() {
     time2("decoder-like: 1 x 128 B loads + 128 B stores", k2<128, 1, true>, sleeps);
     time2("encoder-like: 2 x 64 B loads", k2<64, 2, false>, sleeps);
     time2("encoder-like: 2 x 128 B loads", k2<128, 2, false>, sleeps);
+    time2("decoder-like: 128 B loads nt + touch 1 ahead + stores", k2<128, 1, true, 2>, sleeps);
+    time2("decoder-like: 128 B loads plain + touch 1 ahead + stores", k2<128, 1, true, 2, false>, sleeps);
+    time2("decoder-like: 128 B loads nt + touch 3 ahead + stores", k2<128, 1, true, 4>, sleeps);
+    time2("decoder-like: 128 B loads plain + stores", k2<128, 1, true, 0, false>, sleeps);
+    time2("encoder-like: 2 x 64 B loads plain", k2<64, 2, false, 0, false>, sleeps);
+    time2("encoder-like: 2 x 64 B loads plain + touch 3 ahead (256 B)", k2<64, 2, false, 4, false>, sleeps);
+    time2("encoder-like: 2 x 64 B loads plain + touch 7 ahead (512 B)", k2<64, 2, false, 8, false>, sleeps);
+    time2("encoder-like: 2 x 128 B loads nt + touch 1 ahead", k2<128, 2, false, 2>, sleeps);
+    time2("1 x 128 B loads nt + touch 1 ahead", k2<128, 1, false, 2>, sleeps);
+    time2("1 x 128 B loads nt + touch 3 ahead", k2<128, 1, false, 4>, sleeps);
     time2("1 x 64 B loads", k2<64, 1, false>, sleeps);
     time2("1 x 128 B loads", k2<128, 1, false>, sleeps);
   }
