@@ -593,9 +593,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabBinOff / 4 + tid] = c_next.eb[tid];
   }
   for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by bin
-    tab[kTabRowOff / 4 + 2 * ps] = c_lps_rows[ps >> 1];
     const uint32_t sb = c_next.eb[ps >> 1] >> (16 * (ps & 1));
-    tab[kTabRowOff / 4 + 2 * ps + 1] = enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
+    // state 63 is no context's state: its entries are the all-zero ones bypass lanes look up (enc_bin_mixed_acc)
+    tab[kTabRowOff / 4 + 2 * ps] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
+    tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * enc_waves_per_block(CM) + wib) * 64;

@@ -341,22 +341,25 @@ CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
 // (rmps & m, shift, 0) and a bypass bin (0, 1, bin ? range : 0) -- low = 2 low + bin * range, ref:
 // CABAC_ArithmeticEncoder.cpp:250-270.  mb = ~0 for a bypass bin, 0 for a context bin; bmask = ~0 for a bypass bin of 1
 // (the caller forms it for a whole input word at once).
-// A bypass lane still reads some state (its address is made valid by the caller) and writes it back unchanged, and its
-// range passes through the renormalisation untouched (it is normalised: shift 0).  No lane branches.
+// A bypass lane still reads some state (its address is made valid by the caller) and writes it back unchanged; its table
+// lookup goes by kEncBypassQ -- state 63, which no context ever holds (refused at init, no successor of any state): the
+// tables carry an all-zero entry there, so the lane finds LPS = 0 and "the bin is the mps" and its range passes through the
+// step untouched (it is normalised: shift 0) with nothing added before the shift.  No lane branches.
 // The bounds of EncWordAcc hold: a bypass bin adds one bit and a term below 2^9 like a context bin with shift 1.
+constexpr uint32_t kEncBypassQ = 63u << 2;
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t mb, uint32_t bmask, Addr at,
                                 States &st) {
   const uint32_t q = st.load_at(at);
-  const uint64_t ent = st.entry_mem(q);  // one lookup: row + successors by bin + LPS flags, see enc_bin_row_acc
+  const uint64_t ent = st.entry_mem(select_mask(mb, kEncBypassQ, q));  // one lookup: row + successors by bin + LPS flags
   const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
   st.store_at(at, select_mask(mb, q, t));
-  const uint32_t m = bin.lps_mask(q, t) & ~mb;  // ~0: a context bin that is not its mps
+  const uint32_t m = bin.lps_mask(q, t);  // ~0: a context bin that is not its mps
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
-  const uint32_t r = select_mask(mb, e.range, select_mask(m, lps, rmps));
-  const uint32_t n = clz32(r) - 23u;  // 0 for a bypass bin
-  const uint32_t nt = n - mb;         // ... which moves low by one bit all the same
+  const uint32_t r = select_mask(m, lps, rmps);  // a bypass bin: the range itself
+  const uint32_t n = clz32(r) - 23u;             // ... 0
+  const uint32_t nt = n - mb;                    // ... which moves low by one bit all the same
   g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & bmask);
   g.S = (first ? 0u : g.S) + nt;
   e.range = r << n;
@@ -1015,10 +1018,9 @@ CABAC_HD uint32_t dec_bin_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
 template <bool FIRST, class States, class Addr>
 CABAC_HD uint32_t dec_bin_mixed_nx_abs(DecAbs &a, uint32_t mb, Addr at, uint32_t qb, States &st) {
   const uint64_t ent = st.entry_raw(qb);
-  const uint32_t lpss = abs_lps<FIRST>((uint32_t)ent, a.R);
-  const uint32_t half = a.R >> 1;
-  const uint32_t cmpv = select_mask(mb, half, a.R - lpss);
-  const uint32_t rl = select_mask(mb, half, lpss);
+  // (a bypass lane: "LPS << sh" = R / 2, so that both paths leave R / 2 -- R is even: sh >= 1 -- and R - R / 2 is the value compared)
+  const uint32_t rl = select_mask(mb, a.R >> 1, abs_lps<FIRST>((uint32_t)ent, a.R));
+  const uint32_t cmpv = a.R - rl;
   const uint32_t hi = select_mask(mb, 0x0001u, (uint32_t)(ent >> 32));
   uint32_t nx;
 #if defined(__HIP_DEVICE_COMPILE__)

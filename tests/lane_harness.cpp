@@ -50,6 +50,7 @@ struct HostStates {
   // ... and of the single-lookup steps (LdsStates::entry_mem): row | successors << 32, by bin (encoder) or by path (decoder)
   bool by_path = false;
   uint64_t entry_mem(uint32_t q) const {
+    if (!by_path && q >= kEncBypassQ) return 0;  // the encoder's all-zero entries of state 63 (k_encode's table)
     const uint32_t b0 = by_path ? next_path_mem(q) : next_mem(q), b1 = by_path ? next_path_mem(q + 1u) : next_mem(q | 1u);
     return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(by_path ? (b0 | b1 << 8) : enc_entry_hi(q >> 1, b0, b1)) << 32;
   }
