@@ -3,11 +3,13 @@
 # <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r03
 set -u
 O=${1:-gpurun_out/r03h}; mkdir -p $O
-python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify > $O/stats.log 2>&1
 PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config3 > /dev/null 2>&1
 python3 tools/pmc_summary.py $O/pmc_config3 > $O/pmc_summary.json
+# the bench line quotes this build's counter traffic: profiles/pmc_traffic.json first, then bench.py
+python3 tools/refresh_profiles.py --traffic-only $O/pmc_summary.json
+python bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/pmc_case_table.py $O/pmc_config3 1048576 4096 > $O/pmc_table.txt
 PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config5 --workload config5_per_gpu > /dev/null 2>&1
 python3 tools/pmc_case_table.py $O/pmc_config5 1048576 8192 >> $O/pmc_table.txt

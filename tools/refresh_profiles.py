@@ -2,6 +2,23 @@
 """Copy one evidence run (tools/evidence_run.sh, made on the GPU box under gpurun_out/<dir>) into profiles/<round>/final_*
 and update profiles/pmc_traffic.json.  usage: python tools/refresh_profiles.py gpurun_out/r02h r02"""
 import glob, json, os, shutil, sys
+
+
+def update_traffic(summary, note):
+    """FETCH_SIZE / WRITE_SIZE of the coder kernels (KiB per launch) -> profiles/pmc_traffic.json, which bench.py quotes"""
+    d = json.load(open(summary))
+    t = json.load(open("profiles/pmc_traffic.json"))
+    for k, x in d.items():
+        for name in ("k_decode", "k_encode"):
+            if k.startswith(name + "<") and "FETCH_SIZE" in x:
+                f, w = x["FETCH_SIZE"] * 1024, x["WRITE_SIZE"] * 1024
+                t.setdefault("config3", {}).setdefault(name, {}).update(fetch_bytes=f, write_bytes=w, hbm_bytes_per_launch=f + w, source=note)
+    json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
+
+
+if sys.argv[1] == "--traffic-only":  # on the GPU box, between the PMC passes and the bench line (tools/evidence_run.sh)
+    update_traffic(sys.argv[2], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, same evidence run (see profiles/README.md)")
+    sys.exit(0)
 src, rnd = sys.argv[1], sys.argv[2]
 dst = "profiles/%s/" % rnd
 os.makedirs(dst, exist_ok=True)
@@ -10,16 +27,9 @@ shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], dst + "final_kern
 for f in ("pmc_summary.json", "pmc_table.txt", "other_shapes.txt", "s_sweep.txt", "s_sweep.json"):
     if os.path.exists(src + "/" + f):
         shutil.copy(src + "/" + f, dst + "final_" + f)
-d = json.load(open(src + "/pmc_summary.json"))
-t = json.load(open("profiles/pmc_traffic.json"))
 note = ("profiles/%s/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE calibrated 1:1 "
         "on k_encode whose reads are exactly 2 B/bin)" % rnd)
-for k, x in d.items():
-    for name in ("k_decode", "k_encode"):
-        if k.startswith(name + "<") and "FETCH_SIZE" in x:
-            f, w = x["FETCH_SIZE"] * 1024, x["WRITE_SIZE"] * 1024
-            t.setdefault("config3", {}).setdefault(name, {}).update(fetch_bytes=f, write_bytes=w, hbm_bytes_per_launch=f + w, source=note)
-json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
+update_traffic(src + "/pmc_summary.json", note)
 b = json.load(open(src + "/bench.json"))
 print("value %.1f Gbin/s" % b["value"], b["kernels_ms"], "frac %.3f" % b["roofline"]["frac"], "cpu %.4f" % b["cpu_baseline"]["value"])
 print(open(dst + "final_kernel_stats.csv").read()[:700])
