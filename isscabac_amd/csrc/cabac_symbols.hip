@@ -11,6 +11,7 @@
 
 #include "cabac_internal.h"
 #include "cabac_lane.h"
+#include <mutex>
 #include "cabac_symbols.h"
 
 namespace isscabac {
@@ -40,9 +41,6 @@ constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
 // workgroups on a CU
 constexpr uint32_t kWalkStageBytes = 2048, kWalkRingBytes = 2048;
 __host__ __device__ constexpr uint32_t sym_walk_state_bytes(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
-__host__ __device__ constexpr uint32_t sym_walk_wave_bytes(uint32_t nctx, bool encoder) {
-  return sym_walk_state_bytes(nctx) + kWalkStageBytes + (encoder ? kWalkRingBytes : 0u);
-}
 // LDS of a workgroup: [0,256) rangeTabLps rows = [state][column] bytes, [256,512) next-state entries, [512,768) successor
 // bytes by (packed state, bin), [768,1024) by (packed state, path), then {bits, len | np << 8} per symbol value
 constexpr uint32_t kSymByBin = 512, kSymByPath = 768, kSymBinTab = 1024, kSymTab = 1024 + 256 * 8;
@@ -50,9 +48,8 @@ constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
 // LDS of a workgroup of the code-tree kernels (cabac_symbols.h: SymTrie), read by absolute address:
 //   [0, 1024)     the single-lookup step's 8-byte entries by packed state (cabac_lane.h: enc_bin_row_acc / dec_bin_row_q)
 //   [1024, 2048)  per symbol byte: its bin string << 3 (encoder: the bin in turn sits at bit 3, where it is 8 * bin)
-//   [2048, ...)   the walk table: one dword per (node, slot, symbol above) at node * stride + slot * 128 + up * 4; the
-//                 encoder's slot is the bin (stride 256), the decoder's the (mps, path) pair its bin step returns (stride
-//                 512: no instruction turns the pair into the bin) --
+//                 (decoder: [0, 2048) the 8-byte entries by RAW state byte, cabac_lane.h: dec_bin_out -- it has no bin strings)
+//   [2048, ...)   the walk table: one dword per (node, bin, symbol above) at node * 256 + bin * 128 + up * 4 --
 //                 bits 0..13  where the walk stands after this bin: (child node, same symbol above), or after a code word's
 //                             last bin (root, the symbol just finished above)
 //                 bit 14      no code word goes on here (corrupt stream: the general kernel decodes it again)
@@ -61,10 +58,19 @@ constexpr uint32_t kSymWaveBytes = kSymStateBytes + kSymStageBytes;
 //   so that per bin the walk, the context selection and the end-of-symbol test are one LDS read and a few bit operations.
 constexpr uint32_t kWalkBits = 1024, kWalkTab = 2048, kWalkSlot = 128, kWalkMaxNodes = 32;
 constexpr uint32_t kWalkNextMask = 0x3FFFu, kWalkBadBit = 14, kWalkLeafBit = 15, kWalkOffShift = 16, kWalkOffBits = 12, kWalkSymShift = 28;
-__host__ __device__ constexpr uint32_t walk_node_stride(bool encoder) { return encoder ? 2 * kWalkSlot : 4 * kWalkSlot; }
-__host__ __device__ constexpr uint32_t sym_walk_tab_bytes(uint32_t nodes, bool encoder) { return kWalkTab + nodes * walk_node_stride(encoder); }
+// (both kernels index the slot by the bin now: the decoder's step hands back `successor | bin`, cabac_lane.h: dec_bin_nx_abs)
+__host__ __device__ constexpr uint32_t walk_node_stride() { return 2 * kWalkSlot; }
+// the tables, rounded up to 2 KiB: behind them lie the waves' 2 KiB staging / ring regions (LaneBytes32), whose addresses are
+// formed by OR-ing into a 2 KiB-aligned base
+__host__ __device__ constexpr uint32_t sym_walk_tab_bytes(uint32_t nodes) { return (kWalkTab + nodes * walk_node_stride() + 2047u) & ~2047u; }
+// LDS of a code-tree workgroup: tables | staging of waves 0..3 | (encoder) symbol rings of waves 0..3 | state images
+__host__ __device__ constexpr uint32_t sym_walk_regions(bool encoder) { return kSymWaves * (kWalkStageBytes + (encoder ? kWalkRingBytes : 0u)); }
+__host__ __device__ constexpr uint32_t sym_walk_lds_bytes(uint32_t nodes, uint32_t nctx, bool encoder) {
+  return sym_walk_tab_bytes(nodes) + sym_walk_regions(encoder) + kSymWaves * sym_walk_state_bytes(nctx);
+}
 static_assert(kWalkSlot == (8u << 4) && kWalkSlot == (1u << 7) && kTrieUp * 4 <= kWalkSlot, "the shifts in the kernels");
-static_assert(kWalkMaxNodes * 4 * kWalkSlot <= kWalkNextMask + 1u, "walk positions are 14 bits");
+static_assert(kWalkMaxNodes * 2 * kWalkSlot <= kWalkNextMask + 1u, "walk positions are 14 bits");
+static_assert(kWalkStageBytes == 2048 && kWalkRingBytes == 2048, "LaneBytes32 regions are 2 KiB and 2 KiB-aligned");
 
 // states in LDS (same conflict-free layout as the bin kernels), tables in LDS memory (lanes finish at different times)
 struct SymStates {
@@ -346,14 +352,11 @@ struct SymTrieDecArgs {
 };
 __device__ __forceinline__ uint32_t walk_state_off(uint32_t c) { return ((c & ~3u) << 6) | (c & 3u); }
 // (all 256 threads; the caller's barrier follows)
-template <bool ENC>
 __device__ __forceinline__ void sym_walk_to_lds(uint8_t *smem, const SymTrie &T, int tid) {
   uint32_t *wt = reinterpret_cast<uint32_t *>(smem + kWalkTab);
-  constexpr uint32_t stride = walk_node_stride(ENC), per_node = stride / 4;
+  constexpr uint32_t stride = walk_node_stride(), per_node = stride / 4;
   for (uint32_t i = tid; i < T.nodes * per_node; i += 256) {
-    const uint32_t node = i / per_node, slot = (i / 32u) % (per_node / 32u), up = i & 31u;
-    // the decoder's slot is (mps << 1 | path): bin = mps on the MPS path, !mps on the LPS path
-    const uint32_t bin = ENC ? slot : ((slot >> 1) ^ (slot & 1u) ^ 1u);
+    const uint32_t node = i / per_node, bin = (i / 32u) % (per_node / 32u), up = i & 31u;
     uint32_t E = (1u << kWalkBadBit) | (node * stride + min(up, kTrieNoUp) * 4u);  // stays where it is
     const uint32_t nx = T.child[node * 2 + bin];
     if (up < kTrieUp && nx != kTrieNone) {
@@ -376,6 +379,8 @@ struct WalkStates {
   __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)a); }
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)a) = (uint8_t)q; }
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(q << 2)); }
+  // the decoder's entry by raw state byte (bit 0 = a stale bin): 256 entries at LDS 0
+  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(qb << 3)); }
 };
 // Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where it is the shift that picks the successor
 struct WalkBin {
@@ -389,9 +394,11 @@ struct WalkBin {
 // -- l * 32 + k -- puts sixteen lanes on every bank: the symbol ring read and the symbol store of every bin then cost the
 // LDS pipe sixteen passes each.)
 struct LaneBytes32 {
-  uint32_t base;  // LDS address of the region + lane * 4
-  __device__ __forceinline__ uint32_t addr(uint32_t k) const { return base + (((k << 6) & 0x700u) | (k & 3u)); }
-  __device__ __forceinline__ uint32_t get(uint32_t k) const { return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)addr(k)); }
+  uint32_t base;  // LDS address of the region (a multiple of 2048) + lane * 4
+  // m * 65 = m + (m << 6) for m = (k + d) % 32: bits 0..1 and 8..10 of it are m % 4 and m / 4 -- an and, a shift-add and an
+  // and-or (the base has zeros in those five bits) instead of shift, two ands and a three-way add
+  __device__ __forceinline__ uint32_t addr(uint32_t k, uint32_t d = 0) const { return (__umul24((k + d) & 31u, 65u) & 0x703u) | base; }
+  __device__ __forceinline__ uint32_t get(uint32_t k, uint32_t d = 0) const { return *reinterpret_cast<const sym_lds_u8 *>((uintptr_t)addr(k, d)); }
   __device__ __forceinline__ void put(uint32_t k, uint32_t b) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)addr(k)) = (uint8_t)b; }
   // bytes k, k + 1 (k even): they share a dword
   __device__ __forceinline__ void put16(uint32_t k, uint32_t x) const {
@@ -461,12 +468,12 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     }
     const BinString g = binarize(min((uint32_t)tid, a.P.nq - 1), a.P);  // (values >= nq cannot be coded: they go out as nq - 1)
     reinterpret_cast<uint32_t *>(smem + kWalkBits)[tid] = g.bits << 3;  // (at most 29 bins: sym_trie_build)
-    sym_walk_to_lds<true>(smem, ta.trie, tid);
+    sym_walk_to_lds(smem, ta.trie, tid);
   }
   __syncthreads();
-  const uint32_t sb = sym_walk_state_bytes(a.nctx);
-  uint8_t *wbase = smem + sym_walk_tab_bytes(ta.trie.nodes, true) + (tid >> 6) * sym_walk_wave_bytes(a.nctx, true);
-  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const uint32_t sb = sym_walk_state_bytes(a.nctx), tabs = sym_walk_tab_bytes(ta.trie.nodes), wv = (uint32_t)tid >> 6;
+  uint8_t *wbase = smem + tabs + sym_walk_regions(true) + wv * sb;  // this wave's state image
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + wv) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
@@ -477,8 +484,8 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
   const uint32_t sbase = (uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + lane * 4);  // this lane's states
   EncCore e;
   enc_start(e);
-  SymPhaseSink sink{LaneBytes32{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + lane * 4)}, a.slots + s * a.slot_stride, 0, 0};
-  const LaneBytes32 ring{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + kWalkStageBytes + lane * 4)};  // symbols [fill - 32, fill) of this column
+  SymPhaseSink sink{LaneBytes32{tabs + wv * kWalkStageBytes + lane * 4}, a.slots + s * a.slot_stride, 0, 0};
+  const LaneBytes32 ring{tabs + (kSymWaves + wv) * kWalkStageBytes + lane * 4};  // symbols [fill - 32, fill) of this column
   const uint32_t n_pad = (n_my + 15u) & ~15u;  // rows are padded to whole 16-byte pieces (pitch)
   uint32_t fill = 0;
   uint4 piece = make_uint4(0, 0, 0, 0);
@@ -497,7 +504,7 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
       nbins++;
     }
     // the next symbol's string: wanted if this bin ends the current one
-    const uint32_t nb8 = bt8[ring.get(idx + 1u)];
+    const uint32_t nb8 = bt8[ring.get(idx, 1u)];
     const uint32_t b8 = opaque(bits8 & 8u);                  // 8 * bin (opaque: stays one AND, shared by both uses)
     const uint32_t E = walk_entry(wa + (b8 << 4));           // (kWalkSlot = 8 << 4)
     enc_bin_row_acc(e, acc, false, WalkBin{b8}, sa, st);
@@ -556,16 +563,18 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   const int tid = threadIdx.x, lane = tid & 63;
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-    if (tid < 128) {  // packed state: its row, its successors by path
-      tab[2 * tid] = y_lps_rows[tid >> 1];
-      tab[2 * tid + 1] = (y_next.ep[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+    {  // raw state byte tid (bit 0: a stale bin): its row, `successor | bin` by path (cabac_lane.h: dec_entry_hi_out)
+      const uint32_t ps = (uint32_t)tid >> 1;
+      const uint32_t sp = y_next.ep[ps >> 1] >> (16 * (ps & 1));
+      tab[2 * tid] = y_lps_rows[ps >> 1];
+      tab[2 * tid + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
     }
-    sym_walk_to_lds<false>(smem, ta.trie, tid);
+    sym_walk_to_lds(smem, ta.trie, tid);
   }
   __syncthreads();
-  const uint32_t sb = sym_walk_state_bytes(a.nctx);
-  uint8_t *wbase = smem + sym_walk_tab_bytes(ta.trie.nodes, false) + (tid >> 6) * sym_walk_wave_bytes(a.nctx, false);
-  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + (tid >> 6)) * 64 + lane;
+  const uint32_t sb = sym_walk_state_bytes(a.nctx), tabs = sym_walk_tab_bytes(ta.trie.nodes), wv = (uint32_t)tid >> 6;
+  uint8_t *wbase = smem + tabs + sym_walk_regions(false) + wv * sb;  // this wave's state image
+  const uint64_t s = ((uint64_t)blockIdx.x * kSymWaves + wv) * 64 + lane;
   const bool valid = s < a.S;
   uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
   for (uint32_t g = 0; g < (a.nctx + 3) / 4; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
@@ -589,16 +598,17 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   // decoder, see RefDec) and bin strings that are no code word of the alphabet -- corrupt input both
   uint32_t bad = needs_ref_decoder(d.v >> 24) ? (1u << kWalkBadBit) : 0u;
   uint8_t *row_out = a.sym_out + s * a.pitch;
-  const LaneBytes32 stage{(uint32_t)(uintptr_t)(sym_lds_u8 *)(wbase + sb + lane * 4)};  // 32 bytes of output staging (see kSymPhase)
+  const LaneBytes32 stage{tabs + wv * kWalkStageBytes + lane * 4};  // 32 bytes of output staging (see kSymPhase)
   const uint32_t wa_top = kTrieNoUp * 4u;
   const uint32_t sa_top = sbase + walk_state_off(ta.trie.ctx[kTrieNoUp]);
   uint32_t idx = 0, wa = wa_top, sa = sa_top, row = 0, out = 0;  // out: symbols stored, a multiple of 16
+  // the bin loop's core is the absolute form (cabac_lane.h: DecAbs): the step hands back `successor | bin`
+  DecAbs da = dec_to_abs(d);
   auto live = [&]() { return idx < n_my && !(bad >> kWalkBadBit & 1u); };
-  auto one_bin = [&](auto guarded) {
+  auto one_bin = [&](auto guarded, auto first) {
     if (decltype(guarded)::value && !live()) return;
-    uint32_t nx;
-    const uint32_t pair = dec_bin_row_q(d, sa, st.load_at(sa), st, nx);  // bit 1 = mps, bit 0 = MPS path
-    const uint32_t E = walk_entry(wa + ((pair & 3u) << 7));               // (kWalkSlot = 1 << 7)
+    const uint32_t nx = dec_bin_nx_abs<decltype(first)::value>(da, sa, st.load_at(sa), st);
+    const uint32_t E = walk_entry(wa | ((nx & 1u) << 7));  // (kWalkSlot = 1 << 7; wa < 128 within its node)
     // the symbol of a code word that ends here -- anything else is overwritten when its code word does end
     stage.put(idx, E >> kWalkSymShift);
     bad |= E;
@@ -626,22 +636,21 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check then
-      // covers words 2 and 3.  One bit-granular top-up per four bins (sh = 23 afterwards): a bin takes at most 6 bits and
-      // needs sh >= 7, so three never run short and only the fourth is guarded
+      // covers words 2 and 3.  One bit-granular top-up per four bins (sh = 23 afterwards); four context bins shift at most
+      // 22 bits (tests/lane_harness.cpp: lane_max_shift_sum), so no bin runs short and none is guarded
       if (g == 2) src.ensure(47);
-      dec_topup_nocheck(d, src);
+      dec_topup_abs(da, src);
       if (!tail) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (k == 3) dec_guard(d, src, 7);
-          one_bin(std::false_type{});
-        }
+        one_bin(std::false_type{}, std::true_type{});
+        one_bin(std::false_type{}, std::false_type{});
+        one_bin(std::false_type{}, std::false_type{});
+        one_bin(std::false_type{}, std::false_type{});
       } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (k == 3) dec_guard(d, src, 7);
-          one_bin(std::true_type{});
-        }
+        // (a lane that sat out a bin has shifted less than the bound allows: never short either)
+        one_bin(std::true_type{}, std::true_type{});
+        one_bin(std::true_type{}, std::false_type{});
+        one_bin(std::true_type{}, std::false_type{});
+        one_bin(std::true_type{}, std::false_type{});
       }
     }
   }
@@ -657,6 +666,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
   for (uint32_t i = (n_my + 15u) & ~15u; i < a.nsym; i++) row_out[i] = 0;
   if (a.status) {
     const uint8_t *p = a.payload + start;
+    dec_from_abs(d, da);
     a.status[s] = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   }
 }
@@ -898,9 +908,20 @@ static bool sym_use_trie(const SymParams &P, SymTrie *T) {
 
 // the symbol kernels read their tables by absolute LDS address: their dynamic LDS must start at 0
 static int sym_check_no_static_lds(isscabac_engine *e, const void *fn) {
+  // asked once per kernel and process (a property of the code object): the query costs microseconds that a 0.1 ms call notices
+  static std::mutex mu;
+  static const void *seen[8];
+  static int nseen = 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < nseen; i++)
+      if (seen[i] == fn) return ISSCABAC_OK;
+  }
   hipFuncAttributes fa;
   HIP_TRY(e, hipFuncGetAttributes(&fa, fn));
   if (fa.sharedSizeBytes != 0) return engine_fail(e, ISSCABAC_ERR_HIP, "internal: symbol kernel has static LDS");
+  std::lock_guard<std::mutex> g(mu);
+  if (nseen < 8) seen[nseen++] = fn;
   return ISSCABAC_OK;
 }
 
@@ -949,7 +970,7 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   SymTrieEncArgs ta;
   if (!d_stats && sym_use_trie(a.P, &ta.trie)) {
     ta.a = a;
-    const size_t wlds = sym_walk_tab_bytes(ta.trie.nodes, true) + kSymWaves * sym_walk_wave_bytes(a.nctx, true);
+    const size_t wlds = sym_walk_lds_bytes(ta.trie.nodes, a.nctx, true);
     if (a.P.col_rows != 0 && a.P.selector != 0) {
       if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols_trie<true>)))) return rc;
       hipLaunchKernelGGL(k_encode_symbols_trie<true>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
@@ -964,9 +985,12 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
   HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
-  uint64_t total = 0;
-  HIP_TRY(e, hipMemcpyAsync(&total, d_offsets + S, sizeof total, hipMemcpyDeviceToHost, e->stream));
+  // the size word comes back through the engine's pinned words (word 1: word 0 may belong to an asynchronous batch encode
+  // that is still outstanding) -- a copy into pageable memory is staged by the runtime and costs tens of microseconds
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  HIP_TRY(e, hipMemcpyAsync(e->h_total + 1, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const uint64_t total = e->h_total[1];
   if (total_bytes) *total_bytes = total;
   if (total > payload_cap)
     return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols_dev: payload needs %llu bytes, capacity is %llu",
@@ -1010,7 +1034,7 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
     a.redo = e->lens;
     a.redo_any = e->flag;
     ta.a = a;
-    const size_t wlds = sym_walk_tab_bytes(ta.trie.nodes, false) + kSymWaves * sym_walk_wave_bytes(a.nctx, false);
+    const size_t wlds = sym_walk_lds_bytes(ta.trie.nodes, a.nctx, false);
     if (a.P.col_rows != 0 && a.P.selector != 0) {
       if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols_trie<true>)))) return rc;
       hipLaunchKernelGGL(k_decode_symbols_trie<true>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
