@@ -112,6 +112,9 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 #ifndef ISSCABAC_DEC_WPB
 #define ISSCABAC_DEC_WPB 4
 #endif
+#ifndef ISSCABAC_DEC_LAT_BARRIER
+#define ISSCABAC_DEC_LAT_BARRIER 1  // scheduling barriers around the latency-oriented decoder's per-bin tail
+#endif
 // waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
@@ -1126,13 +1129,24 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           const uint64_t cb0 = __builtin_amdgcn_s_memtime();
 #endif
           // every lane decodes 16 context bins
-          // latency-oriented instance: the state of the next bin is loaded one bin ahead, the successor forwarded in a
-          // register for a repeated context
-          uint32_t at = 0, at_prev = 0, nx_prev = 0, qld = 0;
-          CtxQuad zl = stx.prep4(wc.x);
+          // latency-oriented instance: a bin's entry is read right behind the decision of the bin before it (its state may
+          // be that bin's successor: forwarded in a register for a repeated context, else loaded two bins ahead), and the
+          // rest of that bin -- state store, next state load, output byte, the positions of the new range -- is issued in
+          // the read's shadow (the scheduling barriers keep the compiler from moving it in front of the read)
+          uint32_t at_cur = 0, at_nxt = 0, qld_nxt = 0;
+          // lane mask: the next bin names this bin's context -- compared in the shadow and kept in SGPRs (inline assembly: the
+          // compiler sinks a C++ comparison to its use, behind the decision)
+          uint64_t same_nxt = 0;
+          uint32_t psel = 0, psh = 0;  // the next bin's positions (abs_positions of the range this bin left)
+          uint64_t ent = 0;
+          CtxQuad zn = stx.prep4(wc.x);  // the quad of the word bin i + 2 lies in
           if (LAT) {
-            at = stx.addr32_of(zl, 0);
-            qld = stx.load_at(at);
+            at_cur = stx.addr32_of(zn, 0);
+            at_nxt = stx.addr32_of(zn, 1);
+            const uint32_t q0 = stx.load_at(at_cur);
+            qld_nxt = stx.load_at(at_nxt);
+            asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_nxt), "v"(at_cur));
+            ent = stx.entry_raw(q0);
           }
 #pragma unroll
           for (int g = 0; g < 4; g++) {
@@ -1143,20 +1157,39 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             if (LAT) {
 #pragma unroll
               for (int k = 0; k < 4; k++) {
-                const uint32_t q = (4 * g + k > 0 && at == at_prev) ? nx_prev : qld;
-                uint32_t at_next = 0;
-                if (4 * g + k < 15) {
-                  if (k == 3) zl = stx.prep4(word_of(wc, (g + 1) & 3));
-                  at_next = stx.addr32_of(zl, (k + 1) & 3);
-                  qld = stx.load_at(at_next);
+                const int i = 4 * g + k;
+                if (k == 0) {  // right behind the top-up: R's leading one is bit 31
+                  psel = da.R >> 29;
+                  psh = 23u;
                 }
-                nx_prev = k == 0 ? dec_bin_nx_abs<true>(da, at, q, stx) : dec_bin_nx_abs<false>(da, at, q, stx);
-                if (k == 0) put_out_byte<0>(oa, ob, nx_prev);
-                else if (k == 1) put_out_byte<1>(oa, ob, nx_prev);
-                else if (k == 2) put_out_byte<2>(oa, ob, nx_prev);
-                else put_out_byte<3>(oa, ob, nx_prev);
-                at_prev = at;
-                at = at_next;
+                const uint32_t nx = dec_bin_nx_abs_at(da, ent, psel, psh);
+                if (i < 15) {
+                  uint32_t qn;
+                  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
+                  ent = stx.entry_raw(qn);
+                }
+#if ISSCABAC_DEC_LAT_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                stx.store_at(at_cur, nx);
+                uint32_t at_n2 = 0, qld_n2 = 0;
+                if (i < 14) {
+                  if (((i + 2) & 3) == 0) zn = stx.prep4(word_of(wc, ((i + 2) >> 2) & 3));
+                  at_n2 = stx.addr32_of(zn, (i + 2) & 3);
+                  qld_n2 = stx.load_at(at_n2);
+                }
+                if (k == 0) put_out_byte<0>(oa, ob, nx);
+                else if (k == 1) put_out_byte<1>(oa, ob, nx);
+                else if (k == 2) put_out_byte<2>(oa, ob, nx);
+                else put_out_byte<3>(oa, ob, nx);
+                if (i < 14) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_n2), "v"(at_nxt));
+                if (k < 3) abs_positions(da.R, psel, psh);
+                at_cur = at_nxt;
+                at_nxt = at_n2;
+                qld_nxt = qld_n2;
+#if ISSCABAC_DEC_LAT_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
               }
             } else {
               const CtxQuad z = stx.prep4(word_of(wc, g));

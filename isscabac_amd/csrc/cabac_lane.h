@@ -987,11 +987,17 @@ CABAC_HD void dec_bin_out_abs(DecAbs &a, Addr at, uint32_t qb, States &st, uint3
   a.v = mps_path ? a.v : a.v - rmps;
 #endif
 }
-// dec_bin_nx in absolute form
-template <bool FIRST, class States, class Addr>
-CABAC_HD uint32_t dec_bin_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
-  const uint64_t ent = st.entry_raw(qb);
-  const uint32_t lpss = abs_lps<FIRST>((uint32_t)ent, a.R);
+// dec_bin_nx in absolute form, in two halves: the arithmetic on an entry already read (the latency-oriented instance issues
+// the read of the next bin's entry right behind this bin's decision and runs everything else in its shadow) ...
+// (sel = column + 4 of the LPS, sh = the comparison point: both follow from R alone -- abs_positions -- and are worked out
+// while the entry is on its way)
+CABAC_HD void abs_positions(uint32_t R, uint32_t &sel, uint32_t &sh) {
+  const uint32_t t = 29u - clz32(R);  // sh + 6
+  sel = R >> t;
+  sh = t - 6u;
+}
+CABAC_HD uint32_t dec_bin_nx_abs_at(DecAbs &a, uint64_t ent, uint32_t sel, uint32_t sh) {
+  const uint32_t lpss = lps_col((uint32_t)ent, sel) << sh;
   const uint32_t rmps = a.R - lpss;
   uint32_t nx;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1011,6 +1017,18 @@ CABAC_HD uint32_t dec_bin_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
   a.R = mps_path ? rmps : lpss;
   a.v = mps_path ? a.v : a.v - rmps;
 #endif
+  return nx;
+}
+template <bool FIRST>
+CABAC_HD uint32_t dec_bin_nx_abs_ent(DecAbs &a, uint64_t ent) {
+  uint32_t sel = a.R >> 29, sh = 23u;
+  if (!FIRST) abs_positions(a.R, sel, sh);
+  return dec_bin_nx_abs_at(a, ent, sel, sh);
+}
+// ... and whole: lookup by the raw state byte, step, store
+template <bool FIRST, class States, class Addr>
+CABAC_HD uint32_t dec_bin_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
+  const uint32_t nx = dec_bin_nx_abs_ent<FIRST>(a, st.entry_raw(qb));
   st.store_at(at, nx);
   return nx;
 }
