@@ -330,6 +330,23 @@ struct BinOfWord {
   }
 };
 
+// enc_pick (cabac_lane.h) for the kernel's bins: t = the entry's high word shifted by the bin, its byte 2 the flag "the bin
+// is not the state's mps" (enc_entry_hi) -- one SDWA compare into VCC, two selects
+#ifndef ISSCABAC_ENC_PICK_VCC
+#define ISSCABAC_ENC_PICK_VCC 1
+#endif
+#if ISSCABAC_ENC_PICK_VCC
+template <int K>
+__device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
+      "v_cndmask_b32_e32 %1, 0, %4, vcc"
+      : "=&v"(r), "=&v"(a)
+      : "v"(t), "v"(lps), "v"(rmps), "s"(0u)
+      : "vcc");
+}
+#endif
+
 // f(BinOfWord<k & 3>{w2, w1}) for a loop counter k that is a constant once the loop is unrolled
 template <class F>
 __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1, F &&f) {

@@ -316,18 +316,27 @@ constexpr uint32_t enc_entry_hi(uint32_t ps, uint32_t succ_bin0, uint32_t succ_b
 // tools/ubench/lds_tp.hip), two round trips behind each other instead of three, and none of them inside the
 // range -> LPS -> range recurrence: the LPS column is picked from the row in a register (lps_of).
 // Bin policy: next_of(hi) -> hi >> (8 * bin), lps_mask(q, t) -> ~0 if the bin is not q's mps (t = next_of(hi)).
+// The two things the LPS decision picks: r = the range the bin leaves (before renormalisation), a = what `low` gains.
+// Default: by the policy's mask; the encode kernel's policies overload it with a compare on the flag byte and two
+// selects on VCC (cheaper to issue than sign-extract + bit-select + and).
+template <class Bin>
+CABAC_HD void enc_pick(const Bin &bin, uint32_t q, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  const uint32_t m = bin.lps_mask(q, t);  // ~0: bin != mps
+  r = select_mask(m, lps, rmps);
+  a = rmps & m;
+}
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);
   const uint64_t ent = st.entry_mem(q);
   const uint32_t t = bin.next_of((uint32_t)(ent >> 32));  // low byte: the successor; bit 16: the bin is not q's mps
   st.store_at(at, t);
-  const uint32_t m = bin.lps_mask(q, t);  // ~0: bin != mps
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
-  const uint32_t r = select_mask(m, lps, rmps);
+  uint32_t r, a;
+  enc_pick(bin, q, t, lps, rmps, r, a);
   const uint32_t n = clz32(r) - 23u;
-  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
+  g.T = ((first ? 0u : g.T) + a) << n;
   g.S = (first ? 0u : g.S) + n;
   e.range = r << n;
 }

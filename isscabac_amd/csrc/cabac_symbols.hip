@@ -389,6 +389,16 @@ struct WalkBin {
   __device__ __forceinline__ uint32_t next_of(uint32_t hi) const { return hi >> b8; }
 };
 
+// enc_pick (cabac_lane.h) on the flag byte of the shifted entry: one SDWA compare into VCC, two selects (as in k_encode)
+__device__ __forceinline__ void enc_pick(const WalkBin &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
+      "v_cndmask_b32_e32 %1, 0, %4, vcc"
+      : "=&v"(r), "=&v"(a)
+      : "v"(t), "v"(lps), "v"(rmps), "s"(0u)
+      : "vcc");
+}
+
 // 32 bytes per lane in 2 KiB of a wave's LDS, laid out like the context states: byte k of lane l at
 // (k / 4) * 256 + l * 4 + k % 4, so that whatever k each of the 64 lanes is at, lane l only touches bank l % 32.  (Lane-major
 // -- l * 32 + k -- puts sixteen lanes on every bank: the symbol ring read and the symbol store of every bin then cost the
