@@ -147,8 +147,8 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)  # 0.3 s of timed region: box noise averages out better than over 20
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
     ap.add_argument("--streams", type=int, default=0, help="override the workload's stream count (global in strong "
