@@ -18,7 +18,8 @@ t0, rounds, bins_total, flagged = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     S = int(rng.choice([1, 3, 63, 64, 65, 200, 777, 2500]))
     B = int(rng.choice([1, 5, 16, 17, 100, 640, 1000, 4096, 5000]))
-    Cn = int(rng.choice([1, 3, 4, 5, 23, 64, 65, 128, 255]))
+    Cn = int(rng.choice([1, 3, 4, 5, 23, 64, 65, 128, 129, 150, 190, 253, 255]))
+    eng.set_tuning(str(rng.choice(["throughput", "latency"])))  # (auto would always pick the latency instance at these sizes)
     ep = float(rng.choice([0.0, 0.0, 0.05, 0.5, 1.0]))
     init = rng.integers(0, 126, Cn).astype(np.uint8)
     ctx = rng.integers(0, Cn, (S, B)).astype(np.uint8)
