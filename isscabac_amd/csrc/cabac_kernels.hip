@@ -1061,6 +1061,19 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     }
   };
 
+#ifndef ISSCABAC_EXP_SPREAD_ST
+#define ISSCABAC_EXP_SPREAD_ST 0  // timing experiment (wrong output): one store instruction behind every chunk instead of eight per
+                                  // block -- 3.01 ms against 2.95: the bursts are not what the stores cost
+#endif
+  auto store_one = [&](uint32_t off, int k) {
+    const uint32_t ln = opaque((uint32_t)lane);
+    const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
+    const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
+    const uint4 v = OutBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+  };
   const uint32_t nrounds = (a.nbins + DTile::T - 1) / DTile::T;
   uint4 pc[DTile::NLD];
   auto fetch = [&](uint32_t off) {
@@ -1104,7 +1117,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         if (j == 0) {
           // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
           // anything issued just before the boundary's wait for the payload piece would be waited for as well
-          if (have_out) {
+          if (have_out && !ISSCABAC_EXP_SPREAD_ST) {
 #if ISSCABAC_EXP_CLK
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
             const uint64_t cs0 = __builtin_amdgcn_s_memtime();
@@ -1283,6 +1296,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         }
         }
         obuf[OutBuf::idx(cidx, lane)] = od;
+#if ISSCABAC_EXP_SPREAD_ST
+        if (t > 0) store_one((t - 1) * DTile::T, (int)cidx);
+#endif
       }
       wave_lds_sync();
     }
