@@ -693,7 +693,7 @@ def test_length_bucketed_ragged_batches(engine, oracle):
     torch = _torch()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(91)
-    for S, B, C, ep in ((4096, 256, 64, False), (9000, 528, 100, True), (5003, 144, 200, False)):
+    for S, B, C, ep in ((4096, 256, 64, False), (9000, 528, 100, True), (5003, 144, 200, False), (4200, 208, 190, True)):
         bins, ctx = oracle.synth(0xCABAC005, 7, S, B, min(C, 64), ep)
         if C > 64:
             ctx = np.where(ctx == 0xFF, ctx, (ctx.astype(np.int64) * 3 % C)).astype(np.uint8)
