@@ -581,7 +581,10 @@ struct EncArgs {
 // LDS bytes of one wave: context states, two half tiles, (encoder) the output staging, (bucketed launches) the wave's stream ids
 template <int CM, bool PERM = false>
 struct WaveLds {
-  static constexpr uint32_t SB = CM == 1 ? 4096u : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
+#ifndef ISSCABAC_EXP_SB32
+#define ISSCABAC_EXP_SB32 0  // occupancy experiment: a 2 KiB state image (batches of <= 32 contexts only) -> five encoder waves per SIMD
+#endif
+  static constexpr uint32_t SB = CM == 1 ? (ISSCABAC_EXP_SB32 ? 2048u : 4096u) : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
