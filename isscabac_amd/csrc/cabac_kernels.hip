@@ -112,6 +112,16 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 #ifndef ISSCABAC_DEC_WPB
 #define ISSCABAC_DEC_WPB 4
 #endif
+// Issue priority of a wave while it codes a chunk's bins (s_setprio; 0 elsewhere: tile moves, loads, stores, window
+// boundaries).  A SIMD's four waves are in different phases; preferring the ones inside the serial bin arithmetic over the
+// ones that are about to wait for memory anyway measured, medians of six alternating runs on one box: k_encode 2.925 ->
+// 2.894 ms, k_decode 2.827 -> 2.798 ms, round trip 713 -> 722 Gbin/s (levels 1, 2 and 3 alike).
+#ifndef ISSCABAC_DEC_PRIO
+#define ISSCABAC_DEC_PRIO 1
+#endif
+#ifndef ISSCABAC_ENC_PRIO
+#define ISSCABAC_ENC_PRIO 1
+#endif
 #ifndef ISSCABAC_DEC_LAT_BARRIER
 #define ISSCABAC_DEC_LAT_BARRIER 1  // scheduling barriers around the latency-oriented decoder's per-bin tail
 #endif
@@ -728,6 +738,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
         const uint4 wc = CTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
         const bool hi = chunk_not_plain<CM>(wc, ctx_kadd);
+        if (ISSCABAC_ENC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_ENC_PRIO);
         if (LAT && full && !hi) {
           // every lane codes 16 context bins, the state pass issued by hand (EncLatPipe): the lookup of bin j goes out as
           // soon as the successor of bin j - 1 is back, and the range / low arithmetic of bin j - 1 runs behind it
@@ -830,6 +841,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
           }
         }
+        if (ISSCABAC_ENC_PRIO) __builtin_amdgcn_s_setprio(0);
       }
       wave_lds_sync();
     }
@@ -1064,6 +1076,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     }
   };
 
+#ifndef ISSCABAC_EXP_PRIO
+#define ISSCABAC_EXP_PRIO 0  // issue-priority experiment: 1 = the wave is preferred while it issues its loads / stores (no gain)
+#endif
 #ifndef ISSCABAC_EXP_SPREAD_ST
 #define ISSCABAC_EXP_SPREAD_ST 0  // timing experiment (wrong output): one store instruction behind every chunk instead of eight per
                                   // block -- 3.01 ms against 2.95: the bursts are not what the stores cost
@@ -1125,7 +1140,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
             const uint64_t cs0 = __builtin_amdgcn_s_memtime();
 #endif
+            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
             store_out(out_off);
+            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             wave_lds_sync();  // the staging buffer is rewritten from here on
 #if ISSCABAC_EXP_CLK
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
@@ -1139,7 +1156,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
             const uint64_t cf0 = __builtin_amdgcn_s_memtime();
 #endif
+            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
             fetch((t + 1) * DTile::T);
+            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
 #if ISSCABAC_EXP_CLK
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
             clk_ld += __builtin_amdgcn_s_memtime() - cf0;
@@ -1156,6 +1175,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         // the window is re-based at the chunk boundary and, wave-uniformly, whenever a lane has fewer than the 24 bits a
         // top-up can take.  oa / ob collect the bins of a word as bytes (cabac_lane.h: dec_bin_out).
         uint32_t oa = 0, ob = 0;
+        if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_DEC_PRIO);
         if (full && !hi) {
 #if ISSCABAC_EXP_CLK
           asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
@@ -1298,6 +1318,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           da = dec_to_abs(d);
         }
         }
+        if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
         obuf[OutBuf::idx(cidx, lane)] = od;
 #if ISSCABAC_EXP_SPREAD_ST
         if (t > 0) store_one((t - 1) * DTile::T, (int)cidx);
