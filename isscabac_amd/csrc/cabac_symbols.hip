@@ -34,6 +34,9 @@ struct SymNextTab {
 };
 __device__ const SymNextTab y_next{};
 
+#ifndef ISSCABAC_SYM_PRIO
+#define ISSCABAC_SYM_PRIO 1
+#endif
 constexpr int kSymWaves = 4;
 constexpr uint32_t kSymStateBytes = 4096, kSymStageBytes = 1024;
 // the code-tree kernels: 32 bytes of output staging and (encoder) a 32-byte ring of input symbols per lane (see kSymPhase),
@@ -545,6 +548,7 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
     sink.boundary();
     // while every lane has more symbols left than a phase can take, nobody needs a guard
     const bool tail = CABAC_WAVE_ANY(idx + kSymPhase > n_my);
+    if (ISSCABAC_SYM_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_SYM_PRIO);  // preferred while it codes bins (see cabac_kernels.hip)
 #pragma unroll
     for (uint32_t g = 0; g < kSymPhase / 4; g++) {
       EncWordAcc acc{0u, 0u};
@@ -559,6 +563,7 @@ __global__ void __launch_bounds__(256) k_encode_symbols_trie(SymTrieEncArgs ta) 
       enc_word_close(e, acc);
       if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush16_wave(e, sink);  // bytes are the same at any cadence
     }
+    if (ISSCABAC_SYM_PRIO) __builtin_amdgcn_s_setprio(0);
   }
   enc_finish16(e, sink);
   sink.close();
@@ -643,6 +648,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
     }
     // while every lane has more symbols left than a chunk can finish (and none has left the tree), nobody needs a guard
     const bool tail = CABAC_WAVE_ANY(idx + 16u > n_my || (bad >> kWalkBadBit & 1u));
+    if (ISSCABAC_SYM_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_SYM_PRIO);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       // boundary() has just re-based: its 64 bits cover the top-ups (<= 23 bits each) of words 0 and 1; one check then
@@ -663,6 +669,7 @@ __global__ void __launch_bounds__(256) k_decode_symbols_trie(SymTrieDecArgs ta) 
         one_bin(std::true_type{}, std::false_type{});
       }
     }
+    if (ISSCABAC_SYM_PRIO) __builtin_amdgcn_s_setprio(0);
   }
   const bool handed_over = (bad >> kWalkBadBit & 1u) != 0;
   a.redo[s] = handed_over ? 1u : 0u;
