@@ -175,8 +175,10 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   // of the SIMD and needs about three of them for that.  Measured on MI355X (tools/s_sweep.py, profiles/r02): with two
   // waves per SIMD (128 Ki streams) the latency-oriented instance is 5 % faster, with one 17 %; from 2.5 waves per SIMD
   // on the throughput instance wins by 3-5 %.  The switch sits at two waves per SIMD.
+  // More than 128 contexts: the state image (256 bytes per four contexts and wave) leaves at most 2.5 waves per SIMD
+  // whatever the batch's size, the latency instance's regime: 190 contexts 514 -> 542 Gbin/s, 253 contexts 434 -> 483.
   sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY ||
-                (e->tuning == ISSCABAC_TUNE_AUTO && S <= 2ull * (uint64_t)e->num_cus * 4 * 64);
+                (e->tuning == ISSCABAC_TUNE_AUTO && (nctx > 128 || S <= 2ull * (uint64_t)e->num_cus * 4 * 64));
   for (int c = 0; c < nctx; c++) {
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     sh->ctx_init[c] = ctx_init[c];
@@ -374,7 +376,9 @@ void parallel_copy(void *dst, const void *src, size_t n) {
     return;
   }
   std::vector<std::thread> th;
-  const size_t per = (n / nt + 63) & ~(size_t)63;
+  // (the share rounded UP before it is aligned: n / nt rounded down left the last n % nt bytes to nobody whenever it was
+  // a multiple of 64 already -- found by the soak as a payload whose last byte stayed behind)
+  const size_t per = ((n + nt - 1) / nt + 63) & ~(size_t)63;
   for (unsigned t = 1; t < nt; t++) {
     const size_t off = (size_t)t * per;
     if (off >= n) break;

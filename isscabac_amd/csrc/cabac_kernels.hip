@@ -1620,8 +1620,8 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// sh.latency selects the latency-oriented instance (<= 64 contexts only: the bigger state images run single-wave
-// workgroups whose occupancy is set by LDS, not by the number of streams)
+// sh.latency selects the latency-oriented instance (cabac_capi.cpp: small launches, and every launch of more than 128
+// contexts, whose occupancy the state image keeps at or below 2.5 waves per SIMD)
 #define ISSCABAC_DISPATCH(FN, ARGS)                                                                     \
   do {                                                                                                  \
     if (sh.d_order) { /* length-bucketed launch */                                                      \
@@ -1630,8 +1630,8 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
       return FN<2, false, true>(ARGS, stream);                                                          \
     }                                                                                                   \
     if (sh.nctx <= 64) return sh.latency ? FN<1, true, false>(ARGS, stream) : FN<1, false, false>(ARGS, stream); \
-    if (sh.nctx <= 128) return FN<3, false, false>(ARGS, stream);                                       \
-    return FN<2, false, false>(ARGS, stream);                                                           \
+    if (sh.nctx <= 128) return sh.latency ? FN<3, true, false>(ARGS, stream) : FN<3, false, false>(ARGS, stream); \
+    return sh.latency ? FN<2, true, false>(ARGS, stream) : FN<2, false, false>(ARGS, stream);            \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,

@@ -113,6 +113,47 @@ def test_ctx_bytes_beyond_the_state_image_leave_other_streams_alone(engine, orac
         assert status[s] == 0 and (dec[s] == bins[s]).all(), s
 
 
+def test_host_path_payload_of_every_size_class_arrives_whole(engine, oracle):
+    """The host-buffer path moves its results through pinned slots with a few copy threads (cabac_capi.cpp:
+    parallel_copy).  A payload above 1 MiB whose size is 1 modulo the threads' aligned shares used to lose its last byte
+    (found by tests/soak/gpu_fuzz.py): here the total is steered to such sizes with short filler streams."""
+    rng = np.random.default_rng(1675009)
+    S0, B = 3000, 4096
+    ctx = rng.integers(0, 64, (S0, B)).astype(np.uint8)
+    bins = rng.integers(0, 2, (S0, B)).astype(np.uint8)
+    init = np.zeros(64, np.uint8)
+    nb0 = np.full(S0, B, np.uint32)
+    _p, off = oracle.encode_batch(bins, ctx, init, nb0)
+    total0 = int(off[-1])
+    assert total0 > (1 << 20)
+    # filler streams of a few bins each: their lengths (1..7 bytes) steer the total
+    F = 400
+    fb = rng.integers(0, 2, (F, B)).astype(np.uint8)
+    fc = rng.integers(0, 64, (F, B)).astype(np.uint8)
+    fn = rng.integers(0, 48, F).astype(np.uint32)
+    _fp, foff = oracle.encode_batch(fb, fc, init, fn)
+    flen = np.diff(foff.astype(np.int64))
+    for want_mod, mod in ((1, 128), (2, 192), (1, 192), (127, 128)):
+        # choose fillers greedily until (total0 + sum) % mod == want_mod
+        pick, tot = [], total0
+        for i in range(F):
+            if tot % mod == want_mod:
+                break
+            pick.append(i)
+            tot += int(flen[i])
+        else:
+            continue
+        assert tot % mod == want_mod
+        bb = np.vstack([bins, fb[pick]]) if pick else bins
+        cc = np.vstack([ctx, fc[pick]]) if pick else ctx
+        nn = np.concatenate([nb0, fn[pick]]).astype(np.uint32)
+        want_p, want_o = oracle.encode_batch(bb, cc, init, nn)
+        assert want_p.size == tot
+        got_p, got_o = engine.encode(bb, cc, init, nn)
+        assert (got_o == want_o).all()
+        assert got_p.tobytes() == want_p.tobytes(), (tot, int(got_p[-1]), int(want_p[-1]))
+
+
 def test_golden_synthetic_payloads(engine, golden, oracle):
     for g in golden["synth"]:
         bins, ctx = oracle.synth(g["seed"], g["s0"], g["nS"], g["B"], g["C"], bool(g["ep_half"]))
