@@ -2,8 +2,8 @@
 """Randomised soak of the batch kernels against the oracle (test infrastructure; run by hand on a GPU box, not collected
 by pytest):   python tests/soak/gpu_fuzz.py [seconds=120] [seed=1]
 Every round draws a shape (streams, bins, contexts, bypass share, skew, ragged lengths, init states), encodes on the GPU
-through the host-buffer C ABI, compares every stream's bytes and the offsets with the oracle, decodes, compares bins and
-status; then corrupts the payload and compares the decoder's bins and status flags with the oracle's again."""
+through the host-buffer C ABI (a quarter of the rounds with the bins as bits), compares every stream's bytes and the
+offsets with the oracle, decodes, compares bins and status; then corrupts the payload and compares the decoder's bins and status flags with the oracle's again."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -32,10 +32,21 @@ while time.time() - t0 < budget:
     if rng.random() < 0.4:
         nb = rng.integers(0, B + 1, S).astype(np.uint32)
     want_p, want_o = orc.encode_batch(bins, ctx, init, nb)
-    got_p, got_o = eng.encode(bins, ctx, init, nb)
-    assert np.array_equal(got_o, want_o), ("offsets", S, B, Cn, ep)
-    assert got_p.tobytes() == want_p.tobytes(), ("payload", S, B, Cn, ep)
-    dec, st = eng.decode(got_p, got_o, ctx, init, nb)
+    packed = rng.random() < 0.25  # the bins-as-bits entry points of the host path
+    pitch = max(16, (B + 15) // 16 * 16)
+    if packed:
+        padded = np.zeros((S, pitch), np.uint8)
+        padded[:, :B] = bins
+        got_p, got_o = eng.encode_packed(np.packbits(padded, axis=1, bitorder="little"), ctx, init, nb)
+    else:
+        got_p, got_o = eng.encode(bins, ctx, init, nb)
+    assert np.array_equal(got_o, want_o), ("offsets", S, B, Cn, ep, packed)
+    assert got_p.tobytes() == want_p.tobytes(), ("payload", S, B, Cn, ep, packed)
+    if packed:
+        bits, st = eng.decode_packed(got_p, got_o, ctx, init, nb)
+        dec = np.unpackbits(bits, axis=1, bitorder="little")[:, :B]
+    else:
+        dec, st = eng.decode(got_p, got_o, ctx, init, nb)
     wdec, wst = orc.decode_batch(want_p, want_o, ctx, init, nb)
     assert np.array_equal(st, wst) and not st.any(), ("status", S, B, Cn, ep)
     for s in range(S):
