@@ -144,6 +144,25 @@ def cpu_baseline(seed, B, C, ep, budget_s, gpu_payload_of=None, nchk=4096):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILD processes of this one -- which
+    has not touched the GPU and never replaces itself -- under the same launcher the driver uses (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1), pass their output through (rank 0 prints the one JSON line) and return
+    the launcher's exit status."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.pop("ISSCABAC_SELF_LAUNCH", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +178,12 @@ def main():
                     help="kernel instance (isscabac_set_tuning); auto picks by launch size")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final bitstream gather (N > 1)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch check without a GPU: the ranks meet over gloo, reduce one number and rank 0 prints it")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("ISSCABAC_SELF_LAUNCH")):
+        sys.exit(launch_ranks(args.gpus))  # nothing in this process has touched the GPU (torch is not even imported)
 
     import numpy as np
     import torch
@@ -168,7 +192,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: the launcher's --nproc-per-node must equal --gpus" % (args.gpus, world)
+    if args.rendezvous_only:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "world": world, "max_rank_plus_1": t.item()}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ISSCABAC_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, reduction, gather) with one rank --

@@ -40,8 +40,9 @@ def build_lib(force=False, verbose=False):
 
 
 def build_variant(tag, defines):
-    """Same sources with extra -D flags -> lib/variant_<tag>.so (A/B experiments, see tools/ab_bench.py)."""
-    out = os.path.join(HERE, "lib", "variant_%s.so" % tag)
+    """Same sources with extra -D flags -> tools/ab/variant_<tag>.so (A/B experiments, see tools/ab_bench.py)."""
+    out = os.path.join(HERE, "..", "tools", "ab", "variant_%s.so" % tag)  # A/B builds live beside the tools, not beside the product library
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
           ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES]
     subprocess.check_call(cmd)

@@ -55,8 +55,8 @@ def _run_dist_bench(extra_env, tag):
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--streams", "8192", "--cpu-seconds", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
-    logdir = os.path.join(ROOT, "gpurun_out", "r03_dist")
-    try:  # kept as evidence (copied to profiles/r03/ by hand): the RCCL branch of bench.py ran on this build
+    logdir = os.path.join(ROOT, "gpurun_out", "r04_dist")
+    try:  # kept as evidence (copied to profiles/r04/ by hand): the RCCL branch of bench.py ran on this build
         os.makedirs(logdir, exist_ok=True)
         with open(os.path.join(logdir, tag + ".log"), "w") as f:
             f.write("$ %s\n[exit %d]\n--- stdout\n%s\n--- stderr (tail)\n%s\n" % (" ".join(cmd), out.returncode, out.stdout, out.stderr[-3000:]))
@@ -84,8 +84,53 @@ def test_bench_gather_deadline_fails_visibly_after_the_line():
     assert len(lines) == 1, out.stdout  # the result line is out ...
     d = json.loads(lines[0])
     assert d["gather_ok"] is False and d["value"] > 0
-    assert out.returncode != 0  # ... and the run failed (the rank left with exit code 3; the launcher reports a failure)
-    assert "exitcode" in out.stderr.lower() or "exit code" in out.stderr.lower() or "3" in out.stderr
+    assert out.returncode != 0  # ... and the run failed: the launcher's failure record names the rank's exit code 3
+    import re
+    assert re.search(r"exitcode\s*:\s*3\b", out.stderr), out.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it (the form the driver uses for N = 1) must start the ranks
+    itself as child processes.  One GPU here, so: one rank, forced through the launcher (ISSCABAC_SELF_LAUNCH) and through
+    the multi-rank branch (ISSCABAC_FORCE_DIST) -- RCCL group, barriers, MAX reduction, gather into the root's buffer."""
+    env = dict(os.environ, ISSCABAC_FORCE_DIST="1", ISSCABAC_SELF_LAUNCH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--streams", "8192",
+           "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    logdir = os.path.join(ROOT, "gpurun_out", "r04_dist")
+    try:
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, "self_launch.log"), "w") as f:
+            f.write("$ ISSCABAC_FORCE_DIST=1 ISSCABAC_SELF_LAUNCH=1 %s\n[exit %d]\n--- stdout\n%s\n--- stderr (tail)\n%s\n"
+                    % (" ".join(cmd), out.returncode, out.stdout, out.stderr[-3000:]))
+    except OSError:
+        pass
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["gather_ok"] is True and d["gather_bytes"] == d["config"]["payload_bytes_per_gpu"] and d["verified_bit_exact"] is True
+
+
+def test_bench_self_launch_two_ranks_meet_without_a_gpu():
+    """the launcher half of `python bench.py --gpus 2` on CPU: two child ranks under torch.distributed.run rendezvous on
+    127.0.0.1 (gloo), reduce, rank 0 prints one line, the parent returns the launcher's status"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"rendezvous_only": True, "world": 2, "max_rank_plus_1": 2.0}
+    # a rank that fails makes the whole call fail: --gpus disagreeing with the world the launcher made
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                          "127.0.0.1", "--master-port", "0", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
 
 
 def test_default_metric_string_is_baseline_json_verbatim():
