@@ -345,7 +345,18 @@ struct BinOfWord {
 #ifndef ISSCABAC_ENC_PICK_VCC
 #define ISSCABAC_ENC_PICK_VCC 1
 #endif
-#if ISSCABAC_ENC_PICK_VCC
+#if ISSCABAC_ENC_PICK_VCC == 2
+// the flag byte is 0x00 / 0xFF: sign-extended by the operand select it IS the mask -- one SDWA move, a bit select and a
+// full-rate and (4 + 4 + 2 issue cycles against 4 + 4 + 4 for compare + two selects; the and runs at twice the rate of
+// a select on gfx950: tools/ubench/valu_ops)
+template <int K>
+__device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  uint32_t m;
+  asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
+  r = select_mask(m, lps, rmps);
+  a = rmps & m;
+}
+#elif ISSCABAC_ENC_PICK_VCC
 template <int K>
 __device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
   asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
@@ -408,8 +419,21 @@ struct LdsStates {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
   }
   // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
+#ifndef ISSCABAC_MUL24
+#define ISSCABAC_MUL24 0  // experiment: the table address as a 24-bit multiply instead of a shift (shifts issue at half rate)
+#endif
+  __device__ __forceinline__ uint32_t times(uint32_t q, uint32_t k) const {
+#if ISSCABAC_MUL24
+    uint32_t r;
+    if (k == 4) asm("v_mul_u32_u24_e32 %0, 4, %1" : "=v"(r) : "v"(q));
+    else asm("v_mul_u32_u24_e32 %0, 8, %1" : "=v"(r) : "v"(q));
+    return r;
+#else
+    return q * k;
+#endif
+  }
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + (q << 2)));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + times(q, 4)));
   }
   // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
   __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
@@ -420,7 +444,7 @@ struct LdsStates {
     const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
     return (uint64_t)row | (uint64_t)sp << 32;
 #else
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(qb << 3));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)times(qb, 8));
 #endif
   }
   // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
@@ -1083,7 +1107,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #define ISSCABAC_EXP_SPREAD_ST 0  // timing experiment (wrong output): one store instruction behind every chunk instead of eight per
                                   // block -- 3.01 ms against 2.95: the bursts are not what the stores cost
 #endif
-  auto store_one = [&](uint32_t off, int k) {
+  [[maybe_unused]] auto store_one = [&](uint32_t off, int k) {
     const uint32_t ln = opaque((uint32_t)lane);
     const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
     const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
@@ -1473,11 +1497,15 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t *len
 // ------------------------------------------------------------------------------------------------
 // slots -> tight payload: 16 lanes per stream
 // ------------------------------------------------------------------------------------------------
+#ifndef ISSCABAC_GATHER_LPS
+#define ISSCABAC_GATHER_LPS 16  // lanes per stream
+#endif
+constexpr uint32_t kGatherLps = ISSCABAC_GATHER_LPS;
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens,
                                                 const uint64_t *offsets, uint64_t S, uint8_t *payload, uint64_t cap) {
   const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t s = gid >> 4;
-  const uint32_t li = (uint32_t)gid & 15u;
+  const uint64_t s = gid / kGatherLps;
+  const uint32_t li = (uint32_t)gid & (kGatherLps - 1u);
   if (s >= S) return;
   const uint32_t len = lens[s];
   const uint64_t off = offsets[s];
@@ -1494,7 +1522,7 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t s
   uint32_t *dst32 = reinterpret_cast<uint32_t *>(dst + head);
   const uint32_t sh = 8 * head;
   struct alignas(4) Q4 { uint32_t w[4]; };
-  for (uint32_t q = li; q < nq; q += 16) {
+  for (uint32_t q = li; q < nq; q += kGatherLps) {
     const uint4 v = *reinterpret_cast<const uint4 *>(src32 + 4 * q);  // the slot is 16-byte aligned and padded to 16
     const uint32_t x = src32[4 * q + 4];
     Q4 o;
@@ -1508,7 +1536,7 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t s
     }
     *reinterpret_cast<Q4 *>(dst32 + 4 * q) = o;
   }
-  for (uint32_t j = 4 * nq + li; j < nd; j += 16) {
+  for (uint32_t j = 4 * nq + li; j < nd; j += kGatherLps) {
     const uint32_t lo = src32[j], hi = src32[j + 1];
     dst32[j] = head == 0 ? lo : (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
   }
@@ -1750,7 +1778,7 @@ hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, 
 
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,
                          uint64_t S, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream) {
-  const uint64_t nblk = (S * 16 + 255) / 256;
+  const uint64_t nblk = (S * kGatherLps + 255) / 256;
   hipLaunchKernelGGL(k_gather, dim3((unsigned)nblk), dim3(256), 0, stream, d_slots, slot_stride, d_lens, d_offsets, S,
                      d_payload, payload_cap);
   return hipGetLastError();

@@ -305,7 +305,7 @@ struct EncWordAcc {
 };
 // high word of the encoder's 8-byte entry for packed state ps (= q >> 1; its mps is bit 0), see enc_bin_row_acc
 constexpr uint32_t enc_entry_hi(uint32_t ps, uint32_t succ_bin0, uint32_t succ_bin1) {
-  return succ_bin0 | succ_bin1 << 8 | ((ps & 1u) ? 1u : 0u) << 16 | ((ps & 1u) ? 0u : 1u) << 24;
+  return succ_bin0 | succ_bin1 << 8 | ((ps & 1u) ? 0xFFu : 0u) << 16 | ((ps & 1u) ? 0u : 0xFFu) << 24;  // flag bytes 0x00 / 0xFF
 }
 // The encoder's step for one bin of an input word (first: the word's first bin) -- everything except `low` and W, which
 // enc_word_close updates -- on ONE table lookup: entry_mem(q) -> 64 bits by packed state (q >> 1): the state's 4-byte rangeTabLps row

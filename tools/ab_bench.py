@@ -16,7 +16,7 @@ rounds = 3
 if "--rounds" in sys.argv:
     rounds = int(sys.argv[sys.argv.index("--rounds") + 1])
     libs = [a for a in libs if a != str(rounds)]
-res = {l: {"encode": [], "decode": [], "value": []} for l in libs}
+res = {l: {"encode": [], "decode": [], "gather": [], "value": []} for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, ISSCABAC_LIB=os.path.abspath(l), ISSCABAC_BENCH_FULL_CAP="1")
@@ -29,9 +29,11 @@ for r in range(rounds):
             continue
         res[l]["encode"].append(d["kernels_ms"]["encode"])
         res[l]["decode"].append(d["kernels_ms"]["decode"])
+        res[l]["gather"].append(d["kernels_ms"]["gather"] + d["kernels_ms"]["scan"])
         res[l]["value"].append(d["value"])
 for l in libs:
     x = res[l]
     if x["value"]:
-        print("%-40s enc %.3f ms  dec %.3f ms  value %.1f Gbin/s   (medians of %d)" % (
-            os.path.basename(l), statistics.median(x["encode"]), statistics.median(x["decode"]), statistics.median(x["value"]), len(x["value"])))
+        print("%-40s enc %.3f ms  dec %.3f ms  scan+gather %.3f ms  value %.1f Gbin/s   (medians of %d)" % (
+            os.path.basename(l), statistics.median(x["encode"]), statistics.median(x["decode"]), statistics.median(x["gather"]),
+            statistics.median(x["value"]), len(x["value"])))

@@ -41,6 +41,62 @@ OPS = [
     ("s_nop 0", "s_nop 0"),
     ("s_waitcnt lgkmcnt(0)", "s_waitcnt lgkmcnt(0)"),
 ]
+# second list (round 4): candidates for replacing half-rate instructions of the coder steps -- 24-bit multiplies as shifts by
+# constants, min / max, packed 16-bit forms, DPP moves, float conversions as byte extract / normaliser
+OPS2 = [
+    ("v_add_u32 e32 (reference)", "v_add_u32 {d}, {d}, {y}"),
+    ("v_lshlrev_b32 imm (reference)", "v_lshlrev_b32 {d}, 3, {d}"),
+    ("v_mul_u32_u24 imm", "v_mul_u32_u24 {d}, 4, {d}"),
+    ("v_mul_u32_u24 vreg", "v_mul_u32_u24 {d}, {y}, {d}"),
+    ("v_mul_i32_i24 imm", "v_mul_i32_i24 {d}, 4, {d}"),
+    ("v_mad_u32_u24", "v_mad_u32_u24 {d}, {d}, 4, {y}"),
+    ("v_mul_lo_u32", "v_mul_lo_u32 {d}, {d}, {y}"),
+    ("v_min_u32", "v_min_u32 {d}, {d}, {y}"),
+    ("v_max_u32", "v_max_u32 {d}, {d}, {y}"),
+    ("v_max_i32", "v_max_i32 {d}, {d}, {y}"),
+    ("v_med3_u32", "v_med3_u32 {d}, {d}, {y}, {y}"),
+    ("v_not_b32", "v_not_b32 {d}, {d}"),
+    ("v_or_b32 e32", "v_or_b32 {d}, {d}, {y}"),
+    ("v_or3_b32", "v_or3_b32 {d}, {d}, {y}, {y}"),
+    ("v_lshl_or_b32", "v_lshl_or_b32 {d}, {d}, 2, {y}"),
+    ("v_xad_u32", "v_xad_u32 {d}, {d}, {y}, {y}"),
+    ("v_ashrrev_i32 imm", "v_ashrrev_i32 {d}, 3, {d}"),
+    ("v_lshrrev_b32 imm", "v_lshrrev_b32 {d}, 3, {d}"),
+    ("v_lshlrev_b16 imm", "v_lshlrev_b16 {d}, 3, {d}"),
+    ("v_add_u16", "v_add_u16 {d}, {d}, {y}"),
+    ("v_pk_add_u16", "v_pk_add_u16 {d}, {d}, {y}"),
+    ("v_pk_sub_u16", "v_pk_sub_u16 {d}, {d}, {y}"),
+    ("v_pk_lshlrev_b16", "v_pk_lshlrev_b16 {d}, {y}, {d}"),
+    ("v_pk_max_u16", "v_pk_max_u16 {d}, {d}, {y}"),
+    ("v_pk_mad_u16", "v_pk_mad_u16 {d}, {d}, {y}, {y}"),
+    ("v_mov_b32 dpp row_shr:1", "v_mov_b32_dpp {d}, {d} row_shr:1 row_mask:0xf bank_mask:0xf"),
+    ("v_add_u32 dpp quad_perm", "v_add_u32_dpp {d}, {d}, {y} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"),
+    ("v_cvt_f32_ubyte1", "v_cvt_f32_ubyte1 {d}, {d}"),
+    ("v_cvt_f32_u32", "v_cvt_f32_u32 {d}, {d}"),
+    ("v_frexp_exp_i32_f32", "v_frexp_exp_i32_f32 {d}, {d}"),
+    ("v_bfm_b32", "v_bfm_b32 {d}, {d}, {y}"),
+    ("v_bcnt_u32_b32", "v_bcnt_u32_b32 {d}, {d}, {y}"),
+    ("v_mbcnt_lo_u32_b32", "v_mbcnt_lo_u32_b32 {d}, {d}, {y}"),
+    ("v_mov_b32 sdwa sext byte", "v_mov_b32_sdwa {d}, sext({d}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2"),
+    ("v_and_b32 sdwa sext byte", "v_and_b32_sdwa {d}, {y}, sext({d}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"),
+    ("v_sub_u32 sdwa src byte", "v_sub_u32_sdwa {d}, {d}, {y} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"),
+    ("v_readfirstlane_b32", "v_readfirstlane_b32 s20, {d}"),
+    ("v_add_co_u32 e32", "v_add_co_u32_e32 {d}, vcc, {d}, {y}"),
+    ("v_subb_co_u32 e32", "v_subb_co_u32_e32 {d}, vcc, {d}, {y}, vcc"),
+    ("v_cmp_ne_u32 sdwa vcc", "v_cmp_ne_u32_sdwa vcc, {y}, {d} src0_sel:DWORD src1_sel:BYTE_2"),
+    ("v_alignbyte_b32", "v_alignbyte_b32 {d}, {d}, {y}, {y}"),
+    ("v_sad_u32", "v_sad_u32 {d}, {d}, {y}, {y}"),
+    ("v_lshlrev_b32 + v_add (2 ops)", "v_lshlrev_b32 {d}, 2, {d}\\n v_add_u32 {d}, {d}, {y}"),
+    ("s_lshl_b32", "s_lshl_b32 s20, s20, 1"),
+    ("s_bfe_u32", "s_bfe_u32 s20, s20, 0x80008"),
+    ("s_cmp_lt_u32", "s_cmp_lt_u32 s20, s21"),
+    ("s_cselect_b32", "s_cselect_b32 s20, s20, s21"),
+    ("s_mov_b32", "s_mov_b32 s20, s21"),
+]
+import sys
+OUT = "valu_ops.hip"
+if len(sys.argv) > 1 and sys.argv[1] == "2":
+    OPS, OUT = OPS2, "valu_ops2.hip"
 HEAD = r'''// valu_ops.hip -- generated by tools/ubench/gen_valu_ops.py: per-instruction issue cost on gfx950.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -93,4 +149,4 @@ for i, (name, tpl) in enumerate(OPS):
     src += KERNEL % (i, body)
     calls += '  run(k%d, "%s");\n' % (i, name)
 src += TAIL.replace('@CALLS@', calls)
-open(__file__.replace("gen_valu_ops.py", "valu_ops.hip"), "w").write(src)
+open(__file__.replace("gen_valu_ops.py", OUT), "w").write(src)
