@@ -419,21 +419,9 @@ struct LdsStates {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
   }
   // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
-#ifndef ISSCABAC_MUL24
-#define ISSCABAC_MUL24 0  // experiment: the table address as a 24-bit multiply instead of a shift (shifts issue at half rate)
-#endif
-  __device__ __forceinline__ uint32_t times(uint32_t q, uint32_t k) const {
-#if ISSCABAC_MUL24
-    uint32_t r;
-    if (k == 4) asm("v_mul_u32_u24_e32 %0, 4, %1" : "=v"(r) : "v"(q));
-    else asm("v_mul_u32_u24_e32 %0, 8, %1" : "=v"(r) : "v"(q));
-    return r;
-#else
-    return q * k;
-#endif
-  }
+  // (the address as a 16-bit shift: full rate, cabac_lane.h: shl16; a 24-bit multiply is half rate like the 32-bit shift)
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + times(q, 4)));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + shl16c<2>(q)));
   }
   // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
   __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
@@ -444,7 +432,7 @@ struct LdsStates {
     const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
     return (uint64_t)row | (uint64_t)sp << 32;
 #else
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)times(qb, 8));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)shl16c<3>(qb));
 #endif
   }
   // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
@@ -563,7 +551,7 @@ struct EncLatPipe {
 #undef ISSCABAC_LAT_AT0
 #undef ISSCABAC_LAT_AT1
     }
-    asm volatile("v_lshlrev_b32_e32 %1, 2, %2\n\t"
+    asm volatile("v_lshlrev_b16_e32 %1, 2, %2\n\t"  // (full rate; the 32-bit shift is half rate: cabac_lane.h shl16)
                  "ds_read_b64 %0, %1 offset:768"
                  : "=&v"(ent), "=&v"(t)
                  : "v"(q)

@@ -102,6 +102,35 @@ CABAC_HD uint32_t prob_row_index(uint32_t p) { return (p < 50u ? 50u - p : p - 5
 
 CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 
+// x << n for results that fit 16 bits -- the renormalised range (9 bits), table addresses (11 bits).  On gfx950
+// v_lshlrev_b32 issues at half rate and v_lshlrev_b16 at full rate (tools/ubench/valu_ops2: 1.77 against 0.99 ns per
+// instruction and SIMD at four waves; right shifts are full rate either way); the 16-bit form writes zeros to bits 16..31.
+// x must be below 2^16 and n below 16.
+#ifndef ISSCABAC_SHL16
+#define ISSCABAC_SHL16 1
+#endif
+CABAC_HD uint32_t shl16(uint32_t x, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__) && ISSCABAC_SHL16
+  uint32_t r;
+  asm("v_lshlrev_b16_e32 %0, %1, %2" : "=v"(r) : "v"(n), "v"(x));
+  return r;
+#else
+  return (x << n) & 0xFFFFu;
+#endif
+}
+template <int K>
+CABAC_HD uint32_t shl16c(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__) && ISSCABAC_SHL16
+  uint32_t r;
+  static_assert(K == 2 || K == 3, "the shifts the table lookups use");
+  if (K == 2) asm("v_lshlrev_b16_e32 %0, 2, %1" : "=v"(r) : "v"(x));
+  else asm("v_lshlrev_b16_e32 %0, 3, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return (x << K) & 0xFFFFu;
+#endif
+}
+
 // Context states are kept "doubled": q = m_ucState << 1 = (state << 2) | (mps << 1).  q is directly the byte
 // address of entry `state` in a table of dwords (and the ds_bpermute address of lane `state`), and the
 // mps sits at bit 1 where one xor with a pre-shifted bin decides LPS/MPS.
@@ -338,7 +367,7 @@ CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Ad
   const uint32_t n = clz32(r) - 23u;
   g.T = ((first ? 0u : g.T) + a) << n;
   g.S = (first ? 0u : g.S) + n;
-  e.range = r << n;
+  e.range = shl16(r, n);
 }
 CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
   e.low = (e.low << g.S) + g.T;
@@ -371,7 +400,7 @@ CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, 
   const uint32_t nt = n - mb;                    // ... which moves low by one bit all the same
   g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & bmask);
   g.S = (first ? 0u : g.S) + nt;
-  e.range = r << n;
+  e.range = shl16(r, n);
 }
 
 // Latency-oriented form of enc_bin_row_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides an
@@ -397,7 +426,7 @@ CABAC_HD void enc_lat_arith(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint
   const uint32_t n = clz32(r) - 23u;
   g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
   g.S = (first ? 0u : g.S) + n;
-  e.range = r << n;
+  e.range = shl16(r, n);
 }
 template <class States, class Addr, class Bin>
 CABAC_HD uint32_t enc_bin_lat_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, uint32_t q, States &st) {

@@ -942,3 +942,52 @@ print("same")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), cases, str(tmp_path))
     out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, ISSCABAC_SYM_NO_TRIE="1"), capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stderr[-2000:]
+
+
+def test_symbol_kernels_follow_the_second_derivation(engine):
+    """SURVEY 8 rows a14 / a15 on the device against tests/golden/sym_sel_fixture.json -- bin strings and context ids worked
+    out by an independent Python restatement of the reference's MATLAB text (tests/golden/make_sym_fixture.py; the oracle
+    is held to the same file in tests/test_sym_fixture.py).  Encoder: the symbol kernels' per-bin trace must BE the fixture's
+    (bin, context) sequence.  Decoder: a bitstream built from the fixture's sequence by the bin-level kernels -- pinned by
+    the compiled reference -- must decode to the fixture's symbols (the selector runs on decoded bins and the end-of-symbol
+    rule decides where a symbol stops: one wrong context or boundary derails the arithmetic decoder)."""
+    import json
+    import os
+    from isscabac_amd import SymbolParams
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sym_sel_fixture.json")) as f:
+        fx = json.load(f)
+    meth = {"DEC2TU": ("TU", 0), "DEC2EG0": ("EG", 0), "DEC2EG1": ("EG", 1), "DEC2EG2": ("EG", 2)}
+    rng = np.random.default_rng(9)
+
+    def check(sym, params, init, seqs):
+        """sym [S, R]; seqs: per stream (bins, ctx) of the fixture"""
+        S, R = sym.shape
+        payload, offsets, nbins, hist, cost, hb, rec = engine.encode_symbols_stats(sym, params, init, trace=True)
+        nb = np.array([len(b) for b, _ in seqs], np.uint32)
+        assert (nbins == nb).all()
+        B = max(16, (int(nb.max()) + 15) // 16 * 16)
+        bins, ctx = np.zeros((S, B), np.uint8), np.zeros((S, B), np.uint8)
+        for s, (b, c) in enumerate(seqs):
+            r = rec[s, :len(b)]
+            assert ((r >> 11) & 1).all()
+            assert ((r >> 10) & 1).tolist() == b and (r & 0x3FF).tolist() == c, s
+            assert (np.bincount(np.array(c, np.int64), minlength=64)[:64] == hist[s]).all()
+            bins[s, :len(b)], ctx[s, :len(b)] = b, c
+        p2, o2 = engine.encode(bins, ctx, init, nbins=nb)  # the fixture's sequence through the bin-level kernels
+        assert (o2 == offsets).all() and p2.tobytes() == payload.tobytes()
+        dec, status = engine.decode_symbols(p2, o2, R, params, init)
+        assert (status == 0).all() and (dec == sym).all()
+
+    for case in fx["iss"]:
+        m, k = meth[case["method"]]
+        G = np.array(case["G"], np.uint8)
+        init = rng.integers(0, 126, 7 * case["nlbp"] + 2).astype(np.uint8)
+        cols = [(c["bins"], c["ctx"]) for c in case["columns"]]
+        check(G.T.copy(), SymbolParams.iss(case["nq"], m, k, case["types_mask"], case["nlbp"]), init, cols)
+        # the whole matrix as ONE stream: the columns' sequences back to back, the neighbour restarting at every column
+        whole = ([b for c in case["columns"] for b in c["bins"]], [x for c in case["columns"] for x in c["ctx"]])
+        check(G.T.reshape(1, -1).copy(), SymbolParams.iss(case["nq"], m, k, case["types_mask"], case["nlbp"], col_rows=case["rows"]),
+              init, [whole])
+    for case in fx["demo"]:
+        init = rng.integers(0, 126, 3).astype(np.uint8)
+        check(np.array(case["symbols"], np.uint8)[None, :], SymbolParams.demo(case["nq"]), init, [(case["bins"], case["ctx"])])

@@ -39,13 +39,30 @@ __global__ void __launch_bounds__(256, 4) k_calib(uint8_t *buf, unsigned *sink) 
       for (int k = 0; k < 8; k++) go(rows + (k * 8 + (lane >> 3)) * kPitch + off + (lane & 7) * 16);
   } else if (MODE == 2) {
     for (uint32_t off = 0; off < kPitch; off += 16) go(rows + lane * kPitch + off);
-  } else {
+  } else if (MODE == 3) {
     for (uint32_t off = 0; off < 64 * kPitch; off += 1024) go(rows + off + lane * 16);
+  } else if (MODE == 4) {  // seg64, but only the FIRST 64-byte half of every 128-byte line: what does a 64-byte miss fetch?
+    for (uint32_t off = 0; off < kPitch; off += 128)
+#pragma unroll
+      for (int k = 0; k < 4; k++) go(rows + (k * 16 + (lane >> 2)) * kPitch + off + (lane & 3) * 16);
+  } else if (MODE == 5) {  // 32-byte pieces (2 lanes x 16 B per row), only the first 32 bytes of every 128-byte line
+    for (uint32_t off = 0; off < kPitch; off += 128)
+#pragma unroll
+      for (int k = 0; k < 2; k++) go(rows + (k * 32 + (lane >> 1)) * kPitch + off + (lane & 1) * 16);
+  } else if (MODE == 6) {  // lane16, only the first 16 bytes of every 128-byte line
+    for (uint32_t off = 0; off < kPitch; off += 128) go(rows + lane * kPitch + off);
+  } else if (MODE == 7) {  // lane16, only the first 16 bytes of every 64-byte half line
+    for (uint32_t off = 0; off < kPitch; off += 64) go(rows + lane * kPitch + off);
+  } else {  // MODE 8: seg64, both halves of every line but the second one a whole sweep later (an L2 lifetime apart)
+    for (int half = 0; half < 2; half++)
+      for (uint32_t off = 0; off < kPitch; off += 128)
+#pragma unroll
+        for (int k = 0; k < 4; k++) go(rows + (k * 16 + (lane >> 2)) * kPitch + off + half * 64 + (lane & 3) * 16);
   }
   if (!ST && acc == 0x12345678u) *sink = acc;
 }
 template <int MODE, bool NT, bool ST>
-static void run(const char *name, uint8_t *buf, unsigned *sink, uint32_t waves) {
+static void run(const char *name, uint8_t *buf, unsigned *sink, uint32_t waves, double useful = 1.0) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
@@ -55,8 +72,8 @@ static void run(const char *name, uint8_t *buf, unsigned *sink, uint32_t waves) 
   (void)hipEventSynchronize(e1);
   float ms;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  const double bytes = (double)waves * 64 * kPitch;
-  printf("%-26s %.3f ms  %.3f GB true bytes  %.2f TB/s\n", name, ms, bytes / 1e9, bytes / ms / 1e9);
+  const double bytes = (double)waves * 64 * kPitch * useful;  // bytes the lanes asked for
+  printf("%-34s %.3f ms  %.3f GB requested  %.2f TB/s of requested bytes\n", name, ms, bytes / 1e9, bytes / ms / 1e9);
 }
 int main() {
   const uint32_t waves = 16384;
@@ -78,6 +95,14 @@ int main() {
     run<1, true, true>("store seg128 nt", buf, sink, waves);
     run<2, false, true>("store lane16 plain", buf, sink, waves);
     run<3, false, true>("store wide plain", buf, sink, waves);
+    // what a miss fetches: pieces of a line only.  If the time follows the lines touched (4.3 GB) and not the bytes asked
+    // for, the memory side moves whole 128-byte lines whatever the request
+    run<4, false, false>("load first 64 B of each line", buf, sink, waves, 0.5);
+    run<4, true, false>("load first 64 B of each line nt", buf, sink, waves, 0.5);
+    run<5, false, false>("load first 32 B of each line", buf, sink, waves, 0.25);
+    run<6, false, false>("load first 16 B of each line", buf, sink, waves, 0.125);
+    run<7, false, false>("load first 16 B of each 64 B", buf, sink, waves, 0.25);
+    run<8, false, false>("load seg64 halves a sweep apart", buf, sink, waves);
   }
   return 0;
 }
