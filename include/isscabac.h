@@ -357,6 +357,31 @@ int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const ui
 int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
                                 const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
                                 const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status);
+/* the same with the bins as bits: as isscabac_encode_batch_packed / isscabac_decode_batch_packed */
+int isscabac_multi_encode_batch_packed(isscabac_multi *m, const uint8_t *bins_bits, const uint8_t *ctx,
+                                       const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                       const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                                       uint64_t *offsets, uint64_t *total_bytes);
+int isscabac_multi_decode_batch_packed(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets,
+                                       const uint8_t *ctx, const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins,
+                                       uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *bins_bits_out,
+                                       uint32_t *status);
+/* symbol-level calls over the shards: as isscabac_encode_symbols[_stats] / isscabac_decode_symbols (host buffers; stats may
+ * be NULL).  Streams -- columns, or whole matrices with col_rows -- are split like the bin batches; a single stream is one
+ * device's work (ref: the whole-matrix stream of ISS/+coder/cabacEncode.m:45-70 is serial by construction). */
+int isscabac_multi_encode_symbols(isscabac_multi *m, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                                  uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                  const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                                  uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out);
+int isscabac_multi_encode_symbols_stats(isscabac_multi *m, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                                        uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                        const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                                        uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out,
+                                        const isscabac_symbol_stats *stats);
+int isscabac_multi_decode_symbols(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets,
+                                  const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                  const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                                  uint8_t *sym_out, uint32_t *status);
 /* device-resident shards: d_bins[g] / d_ctx[g] (/ d_nbins[g], the array or its entries may be NULL) live on device g and
  * hold that device's block of streams; the payload and the S + 1 offsets are gathered on the FIRST listed device with
  * hipMemcpyPeerAsync, every device pushing its piece straight to the root (no ring). */
@@ -364,6 +389,15 @@ int isscabac_multi_encode_batch_dev(isscabac_multi *m, const uint8_t *const *d_b
                                     const uint32_t *const *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
                                     const uint8_t *ctx_init, int nctx, uint8_t *d_payload_root, uint64_t payload_cap,
                                     uint64_t *d_offsets_root, uint64_t *total_bytes);
+/* ... and back: payload and offsets on the FIRST listed device (where the call above leaves them), every device pulls its
+ * slice from there (hipMemcpyPeerAsync) and decodes its block into its own d_bins_out[g] / d_status[g] (d_status or its
+ * entries may be NULL).  The peer copies between DIFFERENT devices are unmeasured: no multi-GPU node was available to the
+ * builder (the tests run several engines on one device). */
+int isscabac_multi_decode_batch_dev(isscabac_multi *m, const uint8_t *d_payload_root, uint64_t payload_bytes,
+                                    const uint64_t *d_offsets_root, const uint8_t *const *d_ctx,
+                                    const uint32_t *const *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                    const uint8_t *ctx_init, int nctx, uint8_t *const *d_bins_out,
+                                    uint32_t *const *d_status);
 
 /* ---- on-disk container (host side, no GPU work) --------------------------------------------------------------------
  * The reference hands encoder output to the decoder through ONE FILE PER STREAM (ref: CABAC/SimpleCABACMex.cpp:195,288)

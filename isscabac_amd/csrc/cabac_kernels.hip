@@ -128,7 +128,11 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 // waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
-constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
+#ifndef ISSCABAC_ENC_BINADDR
+#define ISSCABAC_ENC_BINADDR 0  // the plain step's table lookup by (state, bin): see LdsStates::entry_bin
+#endif
+constexpr int kTabBin8Off = 1792;  // [1792,3840) with ISSCABAC_ENC_BINADDR: 256 entries of 8 bytes by (q | bin)
+constexpr int kTabBytes = ISSCABAC_ENC_BINADDR ? 3840 : 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
                                  // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
                                  // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
                                  // by packed state, the state's row and its two successors (by bin / by path)
@@ -343,7 +347,7 @@ struct BinOfWord {
 // enc_pick (cabac_lane.h) for the kernel's bins: t = the entry's high word shifted by the bin, its byte 2 the flag "the bin
 // is not the state's mps" (enc_entry_hi) -- one SDWA compare into VCC, two selects
 #ifndef ISSCABAC_ENC_PICK_VCC
-#define ISSCABAC_ENC_PICK_VCC 1
+#define ISSCABAC_ENC_PICK_VCC 2  // 2: the mask form below (same-box A/B, medians of 6: k_encode 2.870 -> 2.847 ms); 1: compare + two selects
 #endif
 #if ISSCABAC_ENC_PICK_VCC == 2
 // the flag byte is 0x00 / 0xFF: sign-extended by the operand select it IS the mask -- one SDWA move, a bit select and a
@@ -423,6 +427,14 @@ struct LdsStates {
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + shl16c<2>(q)));
   }
+  // the plain step's entry by (state, bin): e = q | bin -> 8 bytes at kTabBin8Off + 8 e: the state's rangeTabLps row, the
+  // successor for this bin (byte 4, what the state store takes) and the flag "the bin is not the mps" as 0x00 / 0xFF in
+  // byte 5 -- read a second time SIGN-EXTENDED (ds_read_i8), which makes it the select mask without a VALU instruction
+  __device__ __forceinline__ uint64_t entry_bin(uint32_t e, uint32_t &m) const {
+    const uint32_t a = shl16c<3>(e);
+    m = (uint32_t)(int32_t)*reinterpret_cast<const __attribute__((address_space(3))) int8_t *>((uintptr_t)(kTabBin8Off + 5 + a));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabBin8Off + a));
+  }
   // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
   __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
 #if ISSCABAC_DEC_SPLIT_TAB
@@ -432,7 +444,10 @@ struct LdsStates {
     const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
     return (uint64_t)row | (uint64_t)sp << 32;
 #else
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)shl16c<3>(qb));
+#ifndef ISSCABAC_DEC_SHL16
+#define ISSCABAC_DEC_SHL16 1
+#endif
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3));
 #endif
   }
   // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
@@ -643,6 +658,14 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabRowOff / 4 + 2 * ps] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
     tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
+#if ISSCABAC_ENC_BINADDR
+  for (int eb = tid; eb < 256; eb += blockDim.x) {  // e = q | bin: packed state e >> 1, bin e & 1
+    const uint32_t ps = eb >> 1, bin = eb & 1u;
+    const uint32_t succ = (c_next.eb[ps >> 1] >> (16 * (ps & 1) + 8 * bin)) & 0xFFu;
+    tab[kTabBin8Off / 4 + 2 * eb] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
+    tab[kTabBin8Off / 4 + 2 * eb + 1] = ps >= 126 ? 0u : succ | ((bin != (ps & 1u)) ? 0xFF00u : 0u);
+  }
+#endif
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * enc_waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
@@ -796,6 +819,15 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1, w8 = w1 << 3;
             // `low` takes the word's four additions at once (EncWordAcc): one 64-bit shift + add per word, not per bin
+#if ISSCABAC_ENC_BINADDR
+            if ((k & 3) == 0) enc_bin_binaddr_acc(e, acc, true, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
+            else if ((k & 3) == 1) enc_bin_binaddr_acc(e, acc, false, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
+            else if ((k & 3) == 2) enc_bin_binaddr_acc(e, acc, false, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
+            else {
+              enc_bin_binaddr_acc(e, acc, false, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
+              enc_word_close(e, acc);
+            }
+#else
             if ((k & 3) == 0) enc_bin_row_acc(e, acc, true, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
             else if ((k & 3) == 1) enc_bin_row_acc(e, acc, false, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
             else if ((k & 3) == 2) enc_bin_row_acc(e, acc, false, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
@@ -803,6 +835,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
               enc_bin_row_acc(e, acc, false, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
               enc_word_close(e, acc);
             }
+#endif
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)

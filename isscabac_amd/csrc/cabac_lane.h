@@ -369,6 +369,25 @@ CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Ad
   g.S = (first ? 0u : g.S) + n;
   e.range = shl16(r, n);
 }
+// The same step on a table indexed by (state, bin): entry_bin(q | bin, m) -> the row in the low word, the successor for THIS
+// bin in byte 4 and the LPS decision as a ready 32-bit mask m (the kernel reads the entry's flag byte a second time,
+// sign-extended by the LDS instruction) -- no shift by the bin and no mask instruction: one more LDS read, two fewer
+// half-rate VALU instructions per bin.  Bin policy: or_q(q) -> q | bin.
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_binaddr_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  uint32_t m;
+  const uint64_t ent = st.entry_bin(bin.or_q(q), m);
+  st.store_at(at, (uint32_t)(ent >> 32));  // the store takes the low byte: the successor
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t a = rmps & m;
+  const uint32_t n = clz32(r) - 23u;
+  g.T = ((first ? 0u : g.T) + a) << n;
+  g.S = (first ? 0u : g.S) + n;
+  e.range = shl16(r, n);
+}
 CABAC_HD void enc_word_close(EncCore &e, const EncWordAcc &g) {
   e.low = (e.low << g.S) + g.T;
   e.W += (int32_t)g.S;

@@ -87,6 +87,7 @@ int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out) {
   if (!out) return multi_fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_create_multi: out is null");
   *out = nullptr;
   if (!device_ids || n < 1 || n > 64) return multi_fail(nullptr, ISSCABAC_ERR_ARG, "isscabac_create_multi: 1..64 devices");
+  DeviceGuard restore;  // first: isscabac_create() switches the device and never switches back; both exits below restore it
   isscabac_multi *m = new isscabac_multi;
   for (int g = 0; g < n; g++) {
     isscabac_engine *e = nullptr;
@@ -98,7 +99,6 @@ int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out) {
     m->eng.push_back(e);
     m->dev.push_back(device_ids[g]);
   }
-  DeviceGuard restore;
   m->d_pay.assign(n, nullptr);
   m->pay_cap.assign(n, 0);
   m->d_off.assign(n, nullptr);
@@ -139,13 +139,14 @@ void isscabac_multi_shard(const isscabac_multi *m, uint64_t S, int g, uint64_t *
 }
 
 // ---- host buffers ---------------------------------------------------------------------------------------------------
-int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
-                                uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
-                                uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
-  if (!m) return ISSCABAC_ERR_ARG;
-  if (!bins || !ctx || !payload || !offsets || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_batch: null buffer");
+}  // extern "C"
+
+// Shard-wise host encode: code(g, lo, hi, part, cap, poff, &tot) codes streams [lo, hi) on engine g into a scratch of its own
+// (sizes are not known before); then the pieces are placed and the offsets rebased.  bound = worst-case bytes per stream.
+template <class F>
+static int multi_encode_host(isscabac_multi *m, const char *who, uint64_t S, uint64_t bound, uint8_t *payload, uint64_t payload_cap,
+                             uint64_t *offsets, uint64_t *total_bytes, F code) {
   const int n = (int)m->eng.size();
-  // every device codes its shard into a scratch of its own (sizes are not known before), then the pieces are placed
   std::vector<std::unique_ptr<uint8_t[]>> part(n);  // (new uint8_t[k]: not zeroed -- a value-initialised vector would touch
   std::vector<uint64_t> part_cap(n, 0);             //  every page of ~3 GiB per Mi streams before the engine writes them)
   std::vector<std::vector<uint64_t>> poff(n);
@@ -155,18 +156,17 @@ int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const ui
     uint64_t lo, hi;
     shard_of(S, g, n, &lo, &hi);
     if (hi == lo) return ISSCABAC_OK;
-    part_cap[g] = (hi - lo) * isscabac_stream_bound(nbins);
+    part_cap[g] = (hi - lo) * bound;
     part[g].reset(new (std::nothrow) uint8_t[part_cap[g]]);
-    if (!part[g]) return engine_fail(m->eng[g], ISSCABAC_ERR_NOMEM, "isscabac_multi_encode_batch: no host memory for %llu scratch bytes", (unsigned long long)part_cap[g]);
+    if (!part[g]) return engine_fail(m->eng[g], ISSCABAC_ERR_NOMEM, "%s: no host memory for %llu scratch bytes", who, (unsigned long long)part_cap[g]);
     poff[g].resize(hi - lo + 1);
-    return isscabac_encode_batch(m->eng[g], bins + lo * pitch, ctx + lo * pitch, nbins_per_stream ? nbins_per_stream + lo : nullptr,
-                                 hi - lo, nbins, pitch, ctx_init, nctx, part[g].get(), part_cap[g], poff[g].data(), &tot[g]);
+    return code(g, lo, hi, part[g].get(), part_cap[g], poff[g].data(), &tot[g]);
   });
   if (rc) return rc;
   uint64_t total = 0;
   for (int g = 0; g < n; g++) total += tot[g];
   if (total_bytes) *total_bytes = total;
-  if (total > payload_cap) return multi_fail(m, ISSCABAC_ERR_CAPACITY, "isscabac_multi_encode_batch: payload needs " + std::to_string(total) + " bytes");
+  if (total > payload_cap) return multi_fail(m, ISSCABAC_ERR_CAPACITY, std::string(who) + ": payload needs " + std::to_string(total) + " bytes");
   uint64_t base = 0;
   for (int g = 0; g < n; g++) {
     uint64_t lo, hi;
@@ -179,19 +179,17 @@ int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const ui
   return ISSCABAC_OK;
 }
 
-int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
-                                const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
-                                const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status) {
-  if (!m) return ISSCABAC_ERR_ARG;
-  if (!payload || !offsets || !ctx || !bins_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: null buffer");
+// Shard-wise host decode: decode(g, lo, hi, payload slice, offsets from 0) -- after the WHOLE offsets array has been checked,
+// before any shard touches the payload: the device threads run at the same time, and a shard whose own slice looks fine
+// would otherwise upload payload[offsets[lo], offsets[hi]) from the caller's buffer although a later entry shows the array
+// to be malformed (e.g. [0, 1000000, 5]) -- a host read out of bounds.  After this check every shard's slice lies inside
+// [0, offsets[S]), which is what the caller vouches for.
+template <class F>
+static int multi_decode_host(isscabac_multi *m, const char *who, const uint8_t *payload, const uint64_t *offsets, uint64_t S, F decode) {
   const int n = (int)m->eng.size();
-  // the whole array once, before any shard touches the payload: the device threads run at the same time, and a shard whose
-  // own slice looks fine would otherwise upload payload[offsets[lo], offsets[hi]) from the caller's buffer although a
-  // later entry shows the array to be malformed (e.g. [0, 1000000, 5]) -- a host read out of bounds.  After this check
-  // every shard's slice lies inside [0, offsets[S]), which is what the caller vouches for.
   for (uint64_t s = 0; s < S; s++) {
-    if (offsets[s + 1] < offsets[s]) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: offsets not monotone at stream " + std::to_string(s));
-    if (offsets[s + 1] - offsets[s] > 0xFFFFFFFFull) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: stream " + std::to_string(s) + " longer than 4 GiB");
+    if (offsets[s + 1] < offsets[s]) return multi_fail(m, ISSCABAC_ERR_ARG, std::string(who) + ": offsets not monotone at stream " + std::to_string(s));
+    if (offsets[s + 1] - offsets[s] > 0xFFFFFFFFull) return multi_fail(m, ISSCABAC_ERR_ARG, std::string(who) + ": stream " + std::to_string(s) + " longer than 4 GiB");
   }
   DeviceGuard restore;
   return on_all(m, [&](int g) -> int {
@@ -200,10 +198,109 @@ int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const
     if (hi == lo) return ISSCABAC_OK;
     std::vector<uint64_t> off(hi - lo + 1);
     for (uint64_t s = lo; s <= hi; s++) off[s - lo] = offsets[s] - offsets[lo];
-    return isscabac_decode_batch(m->eng[g], payload + offsets[lo], off.data(), ctx + lo * pitch,
-                                 nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins, pitch, ctx_init, nctx,
-                                 bins_out + lo * pitch, status ? status + lo : nullptr);
+    return decode(g, lo, hi, payload + offsets[lo], off.data());
   });
+}
+
+extern "C" {
+
+int isscabac_multi_encode_batch(isscabac_multi *m, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                                uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                                uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!bins || !ctx || !payload || !offsets || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_batch: null buffer");
+  return multi_encode_host(m, "isscabac_multi_encode_batch", S, isscabac_stream_bound(nbins), payload, payload_cap, offsets, total_bytes,
+                           [&](int g, uint64_t lo, uint64_t hi, uint8_t *part, uint64_t cap, uint64_t *poff, uint64_t *tot) {
+                             return isscabac_encode_batch(m->eng[g], bins + lo * pitch, ctx + lo * pitch,
+                                                          nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins, pitch,
+                                                          ctx_init, nctx, part, cap, poff, tot);
+                           });
+}
+
+int isscabac_multi_decode_batch(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                                const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!payload || !offsets || !ctx || !bins_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch: null buffer");
+  return multi_decode_host(m, "isscabac_multi_decode_batch", payload, offsets, S,
+                           [&](int g, uint64_t lo, uint64_t hi, const uint8_t *pay, const uint64_t *off) {
+                             return isscabac_decode_batch(m->eng[g], pay, off, ctx + lo * pitch,
+                                                          nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins, pitch,
+                                                          ctx_init, nctx, bins_out + lo * pitch, status ? status + lo : nullptr);
+                           });
+}
+
+// the same with the bins as bits on the caller's side (row s of bins_bits: pitch / 8 bytes)
+int isscabac_multi_encode_batch_packed(isscabac_multi *m, const uint8_t *bins_bits, const uint8_t *ctx, const uint32_t *nbins_per_stream,
+                                       uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                                       uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!bins_bits || !ctx || !payload || !offsets || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_batch_packed: null buffer");
+  return multi_encode_host(m, "isscabac_multi_encode_batch_packed", S, isscabac_stream_bound(nbins), payload, payload_cap, offsets, total_bytes,
+                           [&](int g, uint64_t lo, uint64_t hi, uint8_t *part, uint64_t cap, uint64_t *poff, uint64_t *tot) {
+                             return isscabac_encode_batch_packed(m->eng[g], bins_bits + lo * (pitch / 8), ctx + lo * pitch,
+                                                                 nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins,
+                                                                 pitch, ctx_init, nctx, part, cap, poff, tot);
+                           });
+}
+
+int isscabac_multi_decode_batch_packed(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
+                                       const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                       const uint8_t *ctx_init, int nctx, uint8_t *bins_bits_out, uint32_t *status) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!payload || !offsets || !ctx || !bins_bits_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch_packed: null buffer");
+  return multi_decode_host(m, "isscabac_multi_decode_batch_packed", payload, offsets, S,
+                           [&](int g, uint64_t lo, uint64_t hi, const uint8_t *pay, const uint64_t *off) {
+                             return isscabac_decode_batch_packed(m->eng[g], pay, off, ctx + lo * pitch,
+                                                                 nbins_per_stream ? nbins_per_stream + lo : nullptr, hi - lo, nbins,
+                                                                 pitch, ctx_init, nctx, bins_bits_out + lo * (pitch / 8),
+                                                                 status ? status + lo : nullptr);
+                           });
+}
+
+// symbol-level calls over the shards (config 4's path: every column a stream; a whole-matrix stream is one stream = one device)
+int isscabac_multi_encode_symbols_stats(isscabac_multi *m, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
+                                        uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
+                                        int nctx, uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes,
+                                        uint32_t *nbins_out, const isscabac_symbol_stats *stats) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!sym || !params || !payload || !offsets || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_symbols: null buffer");
+  const uint32_t mb = isscabac_symbol_max_bins(params);
+  if (mb == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_encode_symbols: unsupported symbol parameters");
+  return multi_encode_host(m, "isscabac_multi_encode_symbols", S, isscabac_stream_bound(nsym * mb), payload, payload_cap, offsets, total_bytes,
+                           [&](int g, uint64_t lo, uint64_t hi, uint8_t *part, uint64_t cap, uint64_t *poff, uint64_t *tot) {
+                             isscabac_symbol_stats st = {nullptr, nullptr, nullptr, nullptr, 0};
+                             if (stats) {  // per-stream arrays: this shard's rows
+                               st.ctx_hist = stats->ctx_hist ? stats->ctx_hist + lo * ISSCABAC_STAT_CTX : nullptr;
+                               st.ctx_cost = stats->ctx_cost ? stats->ctx_cost + lo * ISSCABAC_STAT_CTX : nullptr;
+                               st.sym_bits = stats->sym_bits ? stats->sym_bits + lo * pitch : nullptr;
+                               st.bin_trace = stats->bin_trace ? stats->bin_trace + lo * stats->bin_trace_pitch : nullptr;
+                               st.bin_trace_pitch = stats->bin_trace_pitch;
+                             }
+                             return isscabac_encode_symbols_stats(m->eng[g], sym + lo * pitch, nsym_per_stream ? nsym_per_stream + lo : nullptr,
+                                                                  hi - lo, nsym, pitch, params, ctx_init, nctx, part, cap, poff, tot,
+                                                                  nbins_out ? nbins_out + lo : nullptr, stats ? &st : nullptr);
+                           });
+}
+
+int isscabac_multi_encode_symbols(isscabac_multi *m, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym,
+                                  uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                                  uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out) {
+  return isscabac_multi_encode_symbols_stats(m, sym, nsym_per_stream, S, nsym, pitch, params, ctx_init, nctx, payload, payload_cap, offsets,
+                                             total_bytes, nbins_out, nullptr);
+}
+
+int isscabac_multi_decode_symbols(isscabac_multi *m, const uint8_t *payload, const uint64_t *offsets, const uint32_t *nsym_per_stream,
+                                  uint64_t S, uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                  const uint8_t *ctx_init, int nctx, uint8_t *sym_out, uint32_t *status) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!payload || !offsets || !params || !sym_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_symbols: null buffer");
+  return multi_decode_host(m, "isscabac_multi_decode_symbols", payload, offsets, S,
+                           [&](int g, uint64_t lo, uint64_t hi, const uint8_t *pay, const uint64_t *off) {
+                             return isscabac_decode_symbols(m->eng[g], pay, off, nsym_per_stream ? nsym_per_stream + lo : nullptr,
+                                                            hi - lo, nsym, pitch, params, ctx_init, nctx, sym_out + lo * pitch,
+                                                            status ? status + lo : nullptr);
+                           });
 }
 
 // ---- device-resident shards, bitstream gathered on the root device ----------------------------------------------------------
@@ -279,6 +376,62 @@ int isscabac_multi_encode_batch_dev(isscabac_multi *m, const uint8_t *const *d_b
   HIP_TRY(r, hipMemcpyAsync(d_offsets_root + S, &total, sizeof total, hipMemcpyHostToDevice, r->stream));
   HIP_TRY(r, hipStreamSynchronize(r->stream));
   return ISSCABAC_OK;
+}
+
+// The decode side of the device-resident form: payload and offsets live on the ROOT device (where encode_batch_dev left them);
+// every device pulls its slice [offsets[lo], offsets[hi]) and its offsets straight from the root (hipMemcpyPeerAsync, all
+// links of the root busy at once), rebases the offsets to its slice on the device and decodes its shard into its own
+// d_bins_out[g] / d_status[g].  The only host visit: the n + 1 shard boundaries out of the offsets array.
+int isscabac_multi_decode_batch_dev(isscabac_multi *m, const uint8_t *d_payload_root, uint64_t payload_bytes,
+                                    const uint64_t *d_offsets_root, const uint8_t *const *d_ctx, const uint32_t *const *d_nbins,
+                                    uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                    uint8_t *const *d_bins_out, uint32_t *const *d_status) {
+  if (!m) return ISSCABAC_ERR_ARG;
+  if (!d_payload_root || !d_offsets_root || !d_ctx || !d_bins_out || S == 0) return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch_dev: null buffer");
+  const int n = (int)m->eng.size();
+  DeviceGuard restore;
+  isscabac_engine *r = m->eng[0];
+  HIP_TRY(r, hipSetDevice(m->dev[0]));
+  std::vector<uint64_t> edge(n + 1, 0);  // offsets[first stream of shard g], and offsets[S]
+  for (int g = 0; g <= n; g++) {
+    uint64_t lo = S, hi = S;
+    if (g < n) shard_of(S, g, n, &lo, &hi);
+    HIP_TRY(r, hipMemcpyAsync(&edge[g], d_offsets_root + lo, sizeof(uint64_t), hipMemcpyDeviceToHost, r->stream));
+  }
+  HIP_TRY(r, hipStreamSynchronize(r->stream));
+  for (int g = 0; g < n; g++)
+    if (edge[g + 1] < edge[g] || edge[g + 1] > payload_bytes)
+      return multi_fail(m, ISSCABAC_ERR_ARG, "isscabac_multi_decode_batch_dev: offsets not monotone or beyond the payload at shard " + std::to_string(g));
+  return on_all(m, [&](int g) -> int {
+    uint64_t lo, hi;
+    shard_of(S, g, n, &lo, &hi);
+    if (hi == lo) return ISSCABAC_OK;
+    isscabac_engine *e = m->eng[g];
+    HIP_TRY(e, hipSetDevice(m->dev[g]));
+    const uint64_t bytes = edge[g + 1] - edge[g], need = bytes + 16, oneed = (hi - lo + 1) * sizeof(uint64_t);
+    if (m->pay_cap[g] < need) {
+      if (m->d_pay[g]) HIP_TRY(e, hipFree(m->d_pay[g]));
+      m->d_pay[g] = nullptr;
+      m->pay_cap[g] = 0;
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&m->d_pay[g]), need));
+      m->pay_cap[g] = need;
+    }
+    if (m->off_cap[g] < oneed) {
+      if (m->d_off[g]) HIP_TRY(e, hipFree(m->d_off[g]));
+      m->d_off[g] = nullptr;
+      m->off_cap[g] = 0;
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&m->d_off[g]), oneed));
+      m->off_cap[g] = oneed;
+    }
+    if (bytes) HIP_TRY(e, hipMemcpyPeerAsync(m->d_pay[g], m->dev[g], d_payload_root + edge[g], m->dev[0], bytes, e->stream));
+    HIP_TRY(e, hipMemcpyPeerAsync(m->d_off[g], m->dev[g], d_offsets_root + lo, m->dev[0], oneed, e->stream));
+    const uint64_t cnt = hi - lo + 1;
+    hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, m->d_off[g], m->d_off[g], cnt,
+                       (uint64_t)0 - edge[g]);  // (unsigned wrap-around: subtracts the slice's first byte)
+    HIP_TRY(e, hipGetLastError());
+    return isscabac_decode_batch_dev(e, m->d_pay[g], bytes, m->d_off[g], d_ctx[g], d_nbins ? d_nbins[g] : nullptr, hi - lo, nbins, pitch,
+                                     ctx_init, nctx, d_bins_out[g], d_status ? d_status[g] : nullptr);
+  });
 }
 
 }  // extern "C"

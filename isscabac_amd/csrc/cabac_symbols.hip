@@ -392,8 +392,19 @@ struct WalkBin {
   __device__ __forceinline__ uint32_t next_of(uint32_t hi) const { return hi >> b8; }
 };
 
-// enc_pick (cabac_lane.h) on the flag byte of the shifted entry: one SDWA compare into VCC, two selects (as in k_encode)
+// enc_pick (cabac_lane.h) on the flag byte of the shifted entry, as in k_encode: the flag byte (0x00 / 0xFF) sign-extended by
+// an SDWA move is the select mask; ISSCABAC_SYM_PICK_VCC = 1: one SDWA compare into VCC and two selects
+#ifndef ISSCABAC_SYM_PICK_VCC
+#define ISSCABAC_SYM_PICK_VCC 0
+#endif
 __device__ __forceinline__ void enc_pick(const WalkBin &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+#if !ISSCABAC_SYM_PICK_VCC
+  uint32_t m;
+  asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
+  r = select_mask(m, lps, rmps);
+  a = rmps & m;
+  return;
+#endif
   asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
       "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
       "v_cndmask_b32_e32 %1, 0, %4, vcc"

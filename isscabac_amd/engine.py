@@ -174,6 +174,12 @@ def _load():
                                               C.c_int, _u8p, _u32p]
     L.isscabac_multi_encode_batch_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_uint64, C.c_uint32,
                                                   C.c_uint32, _u8p, C.c_int, _vp, C.c_uint64, _vp, _u64p]
+    L.isscabac_multi_decode_batch_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, C.POINTER(_vp), C.POINTER(_vp), C.c_uint64, C.c_uint32,
+                                                  C.c_uint32, _u8p, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
+    L.isscabac_multi_encode_batch_packed.argtypes = L.isscabac_encode_batch_packed.argtypes
+    L.isscabac_multi_decode_batch_packed.argtypes = L.isscabac_decode_batch_packed.argtypes
+    L.isscabac_multi_encode_symbols_stats.argtypes = L.isscabac_encode_symbols_stats.argtypes
+    L.isscabac_multi_decode_symbols.argtypes = L.isscabac_decode_symbols.argtypes
     # on-disk container
     _strs = C.POINTER(C.c_char_p)
     L.isscabac_write_stream_files.argtypes = [_u8p, _u64p, C.c_uint64, _strs]
@@ -703,6 +709,88 @@ class MultiEngine:
                                                             ci.size, _vp(d_payload_root), int(payload_cap), _vp(d_offsets_root),
                                                             C.byref(total)))
         return int(total.value)
+
+    def decode_dev(self, d_payload_root, payload_bytes, d_offsets_root, d_ctx, S, nbins, pitch, ctx_init, d_bins_out,
+                   d_status=None, d_nbins=None):
+        """the way back: payload + offsets on the first device, every device decodes its block into its own d_bins_out[g]"""
+        ci = _np(ctx_init, np.uint8)
+        arr = lambda xs: (_vp * self.n)(*[_vp(int(x) or None) for x in xs]) if xs is not None else None
+        self._check(self._L.isscabac_multi_decode_batch_dev(self._h, _vp(d_payload_root), int(payload_bytes), _vp(d_offsets_root),
+                                                            arr(d_ctx), arr(d_nbins), int(S), int(nbins), int(pitch),
+                                                            _ptr(ci, _u8p), ci.size, arr(d_bins_out), arr(d_status)))
+
+    def encode_packed(self, bins_bits, ctx, ctx_init, nbins=None):
+        """bins as bits (numpy.packbits(bins, axis=1, bitorder="little") of rows padded to the pitch): [S, pitch / 8]"""
+        bits, ctx = _np(bins_bits, np.uint8), _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        assert bits.shape == (S, pitch // 8)
+        cp = Engine._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        cap = S * stream_bound(B)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_multi_encode_batch_packed(self._h, _ptr(bits, _u8p), _ptr(cp, _u8p), _ptr(nb, _u32p), S, B,
+                                                               pitch, _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
+                                                               _ptr(offsets, _u64p), C.byref(total)))
+        return payload[:int(total.value)].copy(), offsets
+
+    def decode_packed(self, payload, offsets, ctx, ctx_init, nbins=None):
+        payload, offsets, ctx = _np(payload, np.uint8), _np(offsets, np.uint64), _np(ctx, np.uint8)
+        S, B = ctx.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        cp = Engine._pad_rows(ctx, pitch)
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        out = np.zeros((S, pitch // 8), np.uint8)
+        status = np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_multi_decode_batch_packed(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(cp, _u8p),
+                                                               _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
+                                                               _ptr(out, _u8p), _ptr(status, _u32p)))
+        return out, status
+
+    def encode_symbols(self, sym, params, ctx_init, nsym=None, stats=False):
+        """as Engine.encode_symbols / encode_symbols_stats, the streams split over the devices"""
+        sym = _np(sym, np.uint8)
+        S, R = sym.shape
+        pitch = max(16, (R + 15) // 16 * 16)
+        symp = Engine._pad_rows(sym, pitch)
+        ci = _np(ctx_init, np.uint8)
+        ns = None if nsym is None else _np(nsym, np.uint32)
+        mb = int(self._L.isscabac_symbol_max_bins(C.byref(params)))
+        if mb == 0:
+            raise EngineError(1, "unsupported symbol parameters")
+        cap = S * stream_bound(R * mb)
+        payload = np.empty(cap, np.uint8)
+        offsets = np.zeros(S + 1, np.uint64)
+        nbins = np.zeros(S, np.uint32)
+        total = C.c_uint64(0)
+        st, hist, cost, hb = None, None, None, None
+        if stats:
+            hist, cost = np.zeros((S, STAT_CTX), np.uint32), np.zeros((S, STAT_CTX), np.uint32)
+            hb = np.zeros((S, pitch), np.uint16)
+            st = SymbolStats(hist.ctypes.data_as(_u32p), cost.ctypes.data_as(_u32p), hb.ctypes.data_as(C.POINTER(C.c_uint16)), None, 0)
+        self._check(self._L.isscabac_multi_encode_symbols_stats(self._h, _ptr(symp, _u8p), _ptr(ns, _u32p), S, R, pitch,
+                                                                C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap,
+                                                                _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p),
+                                                                C.byref(st) if st is not None else None))
+        out = (payload[:int(total.value)].copy(), offsets, nbins)
+        return out + (hist, cost, hb[:, :R].copy()) if stats else out
+
+    def decode_symbols(self, payload, offsets, R, params, ctx_init, nsym=None):
+        payload, offsets = _np(payload, np.uint8), _np(offsets, np.uint64)
+        S = offsets.size - 1
+        pitch = max(16, (R + 15) // 16 * 16)
+        ci = _np(ctx_init, np.uint8)
+        ns = None if nsym is None else _np(nsym, np.uint32)
+        out = np.zeros((S, pitch), np.uint8)
+        status = np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_multi_decode_symbols(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ns, _u32p), S,
+                                                          R, pitch, C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(out, _u8p),
+                                                          _ptr(status, _u32p)))
+        return out[:, :R].copy(), status
 
 
 class Stream:

@@ -376,7 +376,6 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     // (pitch = B rounded up to 16; B = rows of ctx) -- an eighth of the bins' bytes crosses the PCIe link
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs < 4 || nrhs > 5) mexErrMsgTxt("Error: encodeBatchPacked needs the handle, the bins as bits, ctx and optionally nbins\n");
-    if (g_multi) mexErrMsgTxt("Error: the packed batch commands run on one device (call setDevices with a single id)\n");
     const uint8_t *bits = u8_arg(prhs[2], "Error: the packed bins must be a uint8 matrix (one stream per column)\n");
     const uint8_t *ctx = u8_arg(prhs[3], "Error: ctx must be a uint8 matrix (one stream per column)\n");
     const size_t B = mxGetM(prhs[3]), S = mxGetN(prhs[3]);
@@ -391,15 +390,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
     uint64_t total = 0;
     engine();
-    check(isscabac_encode_batch_packed(g_engine, bits, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(), (int)h->ctx_init.size(), payload,
-                                       cap, offsets, &total), "encodeBatchPacked");
+    if (g_multi)
+      check_multi(isscabac_multi_encode_batch_packed(g_multi, bits, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(), (int)h->ctx_init.size(),
+                                                     payload, cap, offsets, &total), "encodeBatchPacked");
+    else
+      check(isscabac_encode_batch_packed(g_engine, bits, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(), (int)h->ctx_init.size(), payload,
+                                         cap, offsets, &total), "encodeBatchPacked");
     plhs[0] = mxCreateNumericMatrix(total, 1, mxUINT8_CLASS, mxREAL);
     memcpy(mxGetData(plhs[0]), payload, total);
     if (nlhs > 1) plhs[1] = doubles_of_u64(offsets, S + 1);
   } else if (c == "decodeBatchPacked") {
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs < 5 || nrhs > 6) mexErrMsgTxt("Error: decodeBatchPacked needs the handle, payload, offsets, ctx and optionally nbins\n");
-    if (g_multi) mexErrMsgTxt("Error: the packed batch commands run on one device (call setDevices with a single id)\n");
     const uint8_t *payload = u8_arg(prhs[2], "Error: payload must be uint8\n");
     if (!mxIsClass(prhs[3], "double")) mexErrMsgTxt("Error: offsets must be double\n");
     const uint8_t *ctx = u8_arg(prhs[4], "Error: ctx must be a uint8 matrix (one stream per column)\n");
@@ -415,8 +417,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     uint32_t *status = (uint32_t *)scratch(S * sizeof(uint32_t));
     plhs[0] = mxCreateNumericMatrix(pitch / 8, S, mxUINT8_CLASS, mxREAL);  // the bits, straight into the result
     engine();
-    check(isscabac_decode_batch_packed(g_engine, payload, offsets, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(),
-                                       (int)h->ctx_init.size(), (uint8_t *)mxGetData(plhs[0]), status), "decodeBatchPacked");
+    if (g_multi)
+      check_multi(isscabac_multi_decode_batch_packed(g_multi, payload, offsets, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(),
+                                                     (int)h->ctx_init.size(), (uint8_t *)mxGetData(plhs[0]), status), "decodeBatchPacked");
+    else
+      check(isscabac_decode_batch_packed(g_engine, payload, offsets, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(),
+                                         (int)h->ctx_init.size(), (uint8_t *)mxGetData(plhs[0]), status), "decodeBatchPacked");
     if (nlhs > 1) plhs[1] = doubles_of_u32(status, S, 1);
   } else if (c == "encodeSymbols" || c == "encodeSymbolsStats") {
     // one call per matrix instead of one per bin: binarisation, context selection and coding run on the GPU
@@ -445,8 +451,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       st.ctx_cost = (uint32_t *)scratch(S * ISSCABAC_STAT_CTX * sizeof(uint32_t));
       st.sym_bits = (uint16_t *)scratch(S * (size_t)pitch * sizeof(uint16_t));
     }
-    check(isscabac_encode_symbols_stats(engine(), sym, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), payload,
-                                        cap, offsets, &total, nbins, stats ? &st : NULL), cmd);
+    engine();
+    if (g_multi)  // the streams (columns, or whole matrices) split over the devices of 'setDevices'
+      check_multi(isscabac_multi_encode_symbols_stats(g_multi, sym, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(),
+                                                      payload, cap, offsets, &total, nbins, stats ? &st : NULL), cmd);
+    else
+      check(isscabac_encode_symbols_stats(g_engine, sym, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), payload,
+                                          cap, offsets, &total, nbins, stats ? &st : NULL), cmd);
     plhs[0] = mxCreateNumericMatrix(total, 1, mxUINT8_CLASS, mxREAL);
     memcpy(mxGetData(plhs[0]), payload, total);
     if (nlhs > 1) plhs[1] = doubles_of_u64(offsets, S + 1);
@@ -479,8 +490,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const uint32_t pitch = (uint32_t)((R + 15) / 16 * 16);
     uint8_t *sym = scratch((size_t)pitch * S);
     uint32_t *status = (uint32_t *)scratch(S * sizeof(uint32_t));
-    check(isscabac_decode_symbols(engine(), payload, offsets, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), sym,
-                                  status), "decodeSymbols");
+    engine();
+    if (g_multi)
+      check_multi(isscabac_multi_decode_symbols(g_multi, payload, offsets, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(),
+                                                (int)h->ctx_init.size(), sym, status), "decodeSymbols");
+    else
+      check(isscabac_decode_symbols(g_engine, payload, offsets, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), sym,
+                                    status), "decodeSymbols");
     plhs[0] = mxCreateNumericMatrix(R, S, mxUINT8_CLASS, mxREAL);
     uint8_t *out = (uint8_t *)mxGetData(plhs[0]);
     for (size_t s = 0; s < S; s++) memcpy(out + s * R, sym + s * pitch, R);

@@ -322,6 +322,31 @@ def test_stream_file_commands_and_multi_device_batches(gw, oracle, reference, tm
     assert p3.ravel().tobytes() == want_p.tobytes() and o3.ravel().tolist() == want_o.tolist()
     dec, status = gw.call("decodeBatch", h, p3, o3, ctx.T.copy(), nlhs=2)
     assert (dec.T == bins).all() and (status == 0).all()
+    # ... and the packed and the symbol-level commands under 'setDevices' (three engines: an uneven split)
+    gw.call("setDevices", np.array([0.0, 0.0, 0.0]))
+    Bm, Sm = bins.shape[1], bins.shape[0]
+    pitch = (Bm + 15) // 16 * 16
+    padded = np.zeros((pitch, Sm), np.uint8)
+    padded[:Bm] = bins.T
+    bits = np.packbits(padded, axis=0, bitorder="little")
+    p5, o5 = gw.call("encodeBatchPacked", h, bits, ctx.T.copy(), nlhs=2)
+    assert p5.ravel().tobytes() == want_p.tobytes() and o5.ravel().tolist() == want_o.tolist()
+    dbits, status = gw.call("decodeBatchPacked", h, p5, o5, ctx.T.copy(), nlhs=2)
+    assert (status == 0).all() and (np.unpackbits(dbits, axis=0, bitorder="little")[:Bm] == bins.T).all()
+    rng = np.random.default_rng(12)
+    rows, cols, nq = 50, 11, 8
+    G = np.minimum(np.abs(rng.normal(0, 2.0, (rows, cols))).astype(np.int64), nq - 1).astype(np.uint8)
+    (hs,) = gw.call("initByProb", str(tmp_path / "sym.bin"), np.full(23, 0.5), nlhs=1)
+    params = _iss_params(nq, 0)  # every column a stream
+    ps, os_, nbs, hist, cost, hbits = gw.call("encodeSymbolsStats", hs, G, params, nlhs=6)
+    init = oracle.init_by_prob(np.full(23, 0.5))
+    for c in range(cols):
+        want, want_nb = oracle.iss_encode_column(G[:, c], nq, "EG", 0, 15, 3, init)
+        assert ps.ravel()[int(os_.ravel()[c]):int(os_.ravel()[c + 1])].tobytes() == want.tobytes() and int(nbs.ravel()[c]) == want_nb
+        assert int(hist[:, c].sum()) == want_nb and int(hbits[:, c].sum()) <= 8 * want.size
+    sym, status = gw.call("decodeSymbols", hs, ps, os_, float(rows), params, nlhs=2)
+    assert (status == 0).all() and (sym == G).all()
+    gw.call("delete", hs)
     gw.call("setDevices", np.zeros((0, 0)))
     p4, _ = gw.call("encodeBatch", h, bins.T.copy(), ctx.T.copy(), nlhs=2)
     assert p4.ravel().tobytes() == want_p.tobytes()
