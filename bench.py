@@ -263,6 +263,7 @@ def main():
     eng.sync()
     eng.kernel_ms_mean()  # forget the warm-up launches
     eng.kernel_ms_samples()
+    eng.kernel_ms_samples_dropped()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -271,6 +272,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.sync()  # raises if a payload buffer was too small (reports the most recent encode; the others are checked below)
     ksamples = eng.kernel_ms_samples()  # every launch of the timed steps (the same events the means below come from)
+    kdropped = eng.kernel_ms_samples_dropped()  # non-zero: more launches than the engine keeps -- the series is truncated
     kms, klaunches = eng.kernel_ms_mean()  # HIP events on the launch stream around every kernel of the timed steps
     assert klaunches["encode"] == args.steps * len(bufs) and klaunches["decode"] == args.steps * len(bufs)
     # kernel time of every step (all launches of the step, all four kernels): min / median beside the mean, so that two
@@ -383,6 +385,7 @@ def main():
             "kernels_ms_median": {k: (sorted(v)[len(v) // 2] if v else None) for k, v in ksamples.items()},
             "step_kernel_ms_min": min(step_ms) if step_ms else None,
             "step_kernel_ms_median": sorted(step_ms)[len(step_ms) // 2] if step_ms else None,
+            "kernel_samples_truncated": {k: v for k, v in kdropped.items() if v} or None,  # min / median then cover the first 65536 launches only
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": kbytes, "ms_per_launch": kms_avg},

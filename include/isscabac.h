@@ -127,7 +127,9 @@ int isscabac_encode_batch_dev(isscabac_engine *e, const uint8_t *d_bins, const u
 
 /* replaces decodeStart / decodeBin / decodeFinish (ref: SimpleCABACMex.cpp:280-354,
  * CABAC_ArithmeticDecoder.cpp:54-190,288-331,423-472) for S streams at once.
- *   d_bins_out : device, [S * pitch] bytes; bins beyond a stream's count are written as 0
+ *   d_bins_out : device, [S * pitch] bytes; bins beyond a stream's count are written as 0 -- up to nbins rounded up to a
+ *                multiple of 128 (or the pitch, if smaller): row bytes behind that are not written by the device calls
+ *                (the caller's buffer keeps what it held) and are zero in the host-buffer calls (bytes or bits)
  *   d_status   : device, S x u32 ISSCABAC_ST_* flags, or NULL
  *   payload_bytes : offsets[S] (size of the valid part of d_payload) */
 int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
@@ -444,9 +446,12 @@ int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]);
  * launches each mean covers; waits for the enqueued work first.  Up to 128 calls are kept between reads (a full ring is read out early, which waits for the stream). */
 int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4]);
 /* the individual launch times of one slot (0 encode kernel, 1 scan, 2 gather, 3 decode kernel) recorded since the
- * previous complete read, oldest first (at most 4096 are kept): *count = how many there are; the first min(cap, *count)
+ * previous complete read, oldest first (at most 65536 are kept): *count = how many there are; the first min(cap, *count)
  * are copied to ms, and they are forgotten once cap covered them all.  Waits for the enqueued work first. */
 int isscabac_kernel_ms_samples(isscabac_engine *e, int slot, float *ms, uint32_t cap, uint32_t *count);
+/* launches of `slot` whose time was NOT kept because 65536 were already waiting to be read; reading resets the count.  A
+ * non-zero value says the series of isscabac_kernel_ms_samples is truncated (the means of isscabac_kernel_ms_mean are not). */
+int isscabac_kernel_ms_samples_dropped(isscabac_engine *e, int slot, uint64_t *dropped);
 
 /* synthetic workload generator of SURVEY.md section 8(d) (counter based, identical to
  * oracle/cabac_oracle.c:orc_synth_fill), filling device buffers for global streams s0 .. s0+S-1 */

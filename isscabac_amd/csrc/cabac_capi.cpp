@@ -219,6 +219,7 @@ static int prof_drain(isscabac_engine *e) {
         e->sum_ms[k] += ms;
         e->sum_n[k]++;
         if (e->samples[k].size() < isscabac_engine::kMaxSamples) e->samples[k].push_back(ms);
+        else e->samples_dropped[k]++;
       }
     } else {
       HIP_TRY(e, hipEventElapsedTime(&ms, p.ev[0], p.ev[1]));
@@ -226,6 +227,7 @@ static int prof_drain(isscabac_engine *e) {
       e->sum_ms[3] += ms;
       e->sum_n[3]++;
       if (e->samples[3].size() < isscabac_engine::kMaxSamples) e->samples[3].push_back(ms);
+      else e->samples_dropped[3]++;
     }
     e->prof_count--;
   }
@@ -284,9 +286,14 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
   PROF_MARK(e, ps, 1);
-  HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
-  PROF_MARK(e, ps, 2);
-  HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
+  if (scan_gather_is_fused(S)) {  // a handful of streams: offsets and payload in one launch (timed as the scan; the gather slot reads ~0)
+    HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
+    PROF_MARK(e, ps, 2);
+  } else {
+    HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
+    PROF_MARK(e, ps, 2);
+    HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
+  }
   PROF_MARK(e, ps, 3);
   HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   e->pending_total = true;
@@ -364,8 +371,9 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
 //   * the batch is cut into groups of streams: group g is decoded while group g + 1's contexts are still arriving and
 //     group g - 1's bins are already leaving;
 //   * every device buffer is grow-only scratch of the engine: no allocation after the first call of a size.
-namespace {
+}  // extern "C"
 
+namespace isscabac {
 // copy n bytes with a few threads (one memcpy stream tops out near 10 GB/s; the PCIe link takes 50+)
 void parallel_copy(void *dst, const void *src, size_t n) {
   const size_t kMin = 1u << 20;
@@ -399,63 +407,10 @@ int pipe_init(isscabac_engine *e) {
   }
   return ISSCABAC_OK;
 }
+}  // namespace isscabac
 
-// The pinned ring, used by one direction at a time per call site.  H2D: the host fills a slot, the copy is enqueued, the
-// slot's event marks it free again.  D2H: the copy into a slot is enqueued, and when its event has fired the host moves
-// the block to the caller's memory.  Slots [first, first + count) of the engine's ring.
-struct HostPipe {
-  isscabac_engine *e;
-  int first, count, next = 0;
-  // pending D2H blocks (slot -> where its bytes go)
-  struct Out {
-    void *dst;
-    size_t n;
-    bool live;
-  } out[isscabac_engine::kPinSlots] = {};
-
-  int upload(void *d_dst, const void *h_src, uint64_t bytes) {
-    const uint64_t B = isscabac_engine::kPinBytes;
-    for (uint64_t off = 0; off < bytes; off += B) {
-      const uint64_t n = std::min(B, bytes - off);
-      const int slot = first + next;
-      next = (next + 1) % count;
-      HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));  // the DMA that last read this slot is done
-      parallel_copy(e->pin[slot], (const char *)h_src + off, n);
-      HIP_TRY(e, hipMemcpyAsync((char *)d_dst + off, e->pin[slot], n, hipMemcpyHostToDevice, e->h2d_stream));
-      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->h2d_stream));
-    }
-    return ISSCABAC_OK;
-  }
-  int drain_slot(int slot) {
-    if (!out[slot].live) return ISSCABAC_OK;
-    HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));
-    parallel_copy(out[slot].dst, e->pin[slot], out[slot].n);
-    out[slot].live = false;
-    return ISSCABAC_OK;
-  }
-  // enqueue d_src -> h_dst on the D2H stream (which the caller has made wait for the producing kernel)
-  int download(void *h_dst, const void *d_src, uint64_t bytes) {
-    const uint64_t B = isscabac_engine::kPinBytes;
-    for (uint64_t off = 0; off < bytes; off += B) {
-      const uint64_t n = std::min(B, bytes - off);
-      const int slot = first + next;
-      next = (next + 1) % count;
-      const int rc = drain_slot(slot);
-      if (rc) return rc;
-      HIP_TRY(e, hipMemcpyAsync(e->pin[slot], (const char *)d_src + off, n, hipMemcpyDeviceToHost, e->d2h_stream));
-      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->d2h_stream));
-      out[slot] = Out{(char *)h_dst + off, (size_t)n, true};
-    }
-    return ISSCABAC_OK;
-  }
-  int drain() {
-    for (int k = 0; k < count; k++) {  // oldest first
-      const int rc = drain_slot(first + (next + k) % count);
-      if (rc) return rc;
-    }
-    return ISSCABAC_OK;
-  }
-};
+extern "C" {
+namespace {
 
 // streams per group: about 64 MiB of bins (and as much ctx) per group, at least 4 groups for a big batch
 uint64_t group_streams(uint64_t S, uint32_t pitch) {
@@ -470,10 +425,11 @@ uint64_t group_streams(uint64_t S, uint32_t pitch) {
 static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *ctx, const uint32_t *nbins_per_stream,
                        uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
                        uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, bool packed) {
+  const char *who = packed ? "isscabac_encode_batch_packed" : "isscabac_encode_batch";  // the entry point error texts name
   BatchShape sh;
-  int rc = check_shape(e, "isscabac_encode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
+  int rc = check_shape(e, who, S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
-  if (!bins || !ctx || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch: null buffer");
+  if (!bins || !ctx || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "%s: null buffer", who);
   HIP_TRY(e, hipSetDevice(e->device));
   if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch;
@@ -515,8 +471,7 @@ static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *c
     HIP_TRY(e, launch_encode(g, d_bins + s0 * pitch, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, e->slots + s0 * stride, stride,
                              e->lens + s0, e->stream));
   }
-  HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
-  HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, dev_cap, e->stream));
+  HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, dev_cap, e->stream));
   if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
   HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -546,13 +501,14 @@ int isscabac_encode_batch_packed(isscabac_engine *e, const uint8_t *bins_bits, c
 static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint8_t *ctx,
                        const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch,
                        const uint8_t *ctx_init, int nctx, uint8_t *bins_out, uint32_t *status, bool packed) {
+  const char *who = packed ? "isscabac_decode_batch_packed" : "isscabac_decode_batch";
   BatchShape sh;
-  int rc = check_shape(e, "isscabac_decode_batch", S, nbins, pitch, ctx_init, nctx, &sh);
+  int rc = check_shape(e, who, S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
-  if (!payload || !offsets || !ctx || !bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch: null buffer");
+  if (!payload || !offsets || !ctx || !bins_out) return fail(e, ISSCABAC_ERR_ARG, "%s: null buffer", who);
   for (uint64_t s = 0; s < S; s++)
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
-      return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch: offsets not monotone at stream %llu", (unsigned long long)s);
+      return fail(e, ISSCABAC_ERR_ARG, "%s: offsets not monotone at stream %llu", who, (unsigned long long)s);
   HIP_TRY(e, hipSetDevice(e->device));
   if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch, total = offsets[S];
@@ -585,6 +541,9 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
     HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
     BatchShape g = sh;
     g.S = n;
+    // the kernel writes a row up to nbins rounded up to its 128-bin block (clipped to the pitch); with a pitch beyond that,
+    // the rest of the staging rows -- scratch that earlier calls used for their own bins -- would travel back as it is
+    if ((uint64_t)(nbins + 127u) / 128u * 128u < pitch) HIP_TRY(e, hipMemsetAsync(d_out + s0 * pitch, 0, n * pitch, e->stream));
     // (offsets are positions in the whole payload: the group's kernels get the array from its first stream on)
     HIP_TRY(e, launch_decode(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, d_out + s0 * pitch,
                              d_status + s0, e->flag, e->stream));
@@ -661,6 +620,13 @@ int isscabac_kernel_ms_samples(isscabac_engine *e, int slot, float *ms, uint32_t
   *count = (uint32_t)v.size();
   for (uint32_t i = 0; i < cap && i < v.size(); i++) ms[i] = v[i];
   if (cap >= v.size()) v.clear();  // a sizing call (cap too small) leaves them in place
+  return ISSCABAC_OK;
+}
+
+int isscabac_kernel_ms_samples_dropped(isscabac_engine *e, int slot, uint64_t *dropped) {
+  if (!e || slot < 0 || slot > 3 || !dropped) return ISSCABAC_ERR_ARG;
+  *dropped = e->samples_dropped[slot];
+  e->samples_dropped[slot] = 0;
   return ISSCABAC_OK;
 }
 

@@ -4,6 +4,8 @@
 #define ISSCABAC_INTERNAL_H
 
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include <string>
@@ -59,7 +61,8 @@ struct isscabac_engine {
   double sum_ms[4] = {0, 0, 0, 0};
   uint32_t sum_n[4] = {0, 0, 0, 0};
   std::vector<float> samples[4];  // every launch's time since the last isscabac_kernel_ms_samples (bounded: kMaxSamples)
-  static constexpr size_t kMaxSamples = 4096;
+  static constexpr size_t kMaxSamples = 65536;
+  uint64_t samples_dropped[4] = {0, 0, 0, 0};  // launches whose time did not fit (isscabac_kernel_ms_samples_dropped)
 };
 
 
@@ -97,6 +100,9 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
 uint64_t scan_tmp_bytes(uint64_t S);
 hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream);
 // slots -> tight payload (streams whose range would exceed payload_cap are skipped)
+bool scan_gather_is_fused(uint64_t S);
+hipError_t launch_scan_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,
                          uint64_t S, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 // decode: payload/offsets/ctx -> bins (+status)
@@ -120,6 +126,67 @@ hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);
+
+
+// ---- pinned staging ring of the host-buffer entry points (cabac_capi.cpp, cabac_symbols.hip) -----------------------------------
+void parallel_copy(void *dst, const void *src, size_t n);  // a few host threads: one memcpy stream tops out near 10 GB/s
+int pipe_init(isscabac_engine *e);                          // the ring, the two copy streams and their events, once per engine
+// The pinned ring, used by one direction at a time per call site.  H2D: the host fills a slot, the copy is enqueued, the
+// slot's event marks it free again.  D2H: the copy into a slot is enqueued, and when its event has fired the host moves
+// the block to the caller's memory.  Slots [first, first + count) of the engine's ring.
+struct HostPipe {
+  isscabac_engine *e;
+  int first, count, next = 0;
+  // pending D2H blocks (slot -> where its bytes go)
+  struct Out {
+    void *dst;
+    size_t n;
+    bool live;
+  } out[isscabac_engine::kPinSlots] = {};
+
+  int upload(void *d_dst, const void *h_src, uint64_t bytes) {
+    const uint64_t B = isscabac_engine::kPinBytes;
+    for (uint64_t off = 0; off < bytes; off += B) {
+      const uint64_t n = std::min(B, bytes - off);
+      const int slot = first + next;
+      next = (next + 1) % count;
+      HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));  // the DMA that last read this slot is done
+      parallel_copy(e->pin[slot], (const char *)h_src + off, n);
+      HIP_TRY(e, hipMemcpyAsync((char *)d_dst + off, e->pin[slot], n, hipMemcpyHostToDevice, e->h2d_stream));
+      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->h2d_stream));
+    }
+    return ISSCABAC_OK;
+  }
+  int drain_slot(int slot) {
+    if (!out[slot].live) return ISSCABAC_OK;
+    HIP_TRY(e, hipEventSynchronize(e->pin_ev[slot]));
+    parallel_copy(out[slot].dst, e->pin[slot], out[slot].n);
+    out[slot].live = false;
+    return ISSCABAC_OK;
+  }
+  // enqueue d_src -> h_dst on the D2H stream (which the caller has made wait for the producing kernel)
+  int download(void *h_dst, const void *d_src, uint64_t bytes) {
+    const uint64_t B = isscabac_engine::kPinBytes;
+    for (uint64_t off = 0; off < bytes; off += B) {
+      const uint64_t n = std::min(B, bytes - off);
+      const int slot = first + next;
+      next = (next + 1) % count;
+      const int rc = drain_slot(slot);
+      if (rc) return rc;
+      HIP_TRY(e, hipMemcpyAsync(e->pin[slot], (const char *)d_src + off, n, hipMemcpyDeviceToHost, e->d2h_stream));
+      HIP_TRY(e, hipEventRecord(e->pin_ev[slot], e->d2h_stream));
+      out[slot] = Out{(char *)h_dst + off, (size_t)n, true};
+    }
+    return ISSCABAC_OK;
+  }
+  int drain() {
+    for (int k = 0; k < count; k++) {  // oldest first
+      const int rc = drain_slot(first + (next + k) % count);
+      if (rc) return rc;
+    }
+    return ISSCABAC_OK;
+  }
+};
 
 }  // namespace isscabac
 #endif

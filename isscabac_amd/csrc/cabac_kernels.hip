@@ -1522,14 +1522,9 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t *len
 #define ISSCABAC_GATHER_LPS 16  // lanes per stream
 #endif
 constexpr uint32_t kGatherLps = ISSCABAC_GATHER_LPS;
-__global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens,
-                                                const uint64_t *offsets, uint64_t S, uint8_t *payload, uint64_t cap) {
-  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t s = gid / kGatherLps;
-  const uint32_t li = (uint32_t)gid & (kGatherLps - 1u);
-  if (s >= S) return;
-  const uint32_t len = lens[s];
-  const uint64_t off = offsets[s];
+// one stream's bytes from its slot to its place in the payload, by the kGatherLps lanes li = 0 .. kGatherLps - 1
+__device__ __forceinline__ void gather_stream(const uint8_t *slots, uint64_t slot_stride, uint64_t s, uint32_t li, uint32_t len,
+                                              uint64_t off, uint8_t *payload, uint64_t cap) {
   if (off + len > cap) return;
   const uint8_t *src = slots + s * slot_stride;  // 16-byte aligned
   uint8_t *dst = payload + off;
@@ -1563,6 +1558,41 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t s
   }
   const uint32_t done = head + nd * 4;
   if (done + li < len) dst[done + li] = src[done + li];
+}
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens,
+                                                const uint64_t *offsets, uint64_t S, uint8_t *payload, uint64_t cap) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t s = gid / kGatherLps;
+  if (s >= S) return;
+  gather_stream(slots, slot_stride, s, (uint32_t)gid & (kGatherLps - 1u), lens[s], offsets[s], payload, cap);
+}
+// Small batches (S <= kScanBlock: the reference's own use -- a handful of streams per call): offsets scan AND gather in one
+// single-block launch instead of four, the offsets handed from the scan to the gather through LDS
+__global__ void __launch_bounds__(kScanThreads) k_scan_gather_small(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens,
+                                                                    uint64_t S, uint64_t *offsets, uint8_t *payload, uint64_t cap) {
+  __shared__ uint64_t soff[kScanBlock + 1];
+  const uint32_t i0 = threadIdx.x * kScanItems;
+  uint32_t l[kScanItems];
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    l[k] = i0 + k < S ? lens[i0 + k] : 0;
+    v += l[k];
+  }
+  uint64_t tot;
+  uint64_t run = block_excl_scan_u64(v, &tot);
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    if (i0 + k < S) {
+      offsets[i0 + k] = run;
+      soff[i0 + k] = run;
+    }
+    run += l[k];
+  }
+  if (threadIdx.x == 0) offsets[S] = tot;
+  __syncthreads();
+  const uint32_t li = threadIdx.x & (kGatherLps - 1u);
+  for (uint64_t s = threadIdx.x / kGatherLps; s < S; s += kScanThreads / kGatherLps) gather_stream(slots, slot_stride, s, li, lens[s], soff[s], payload, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1795,6 +1825,19 @@ hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, 
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, bsum, nblk);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(kScanThreads), 0, stream, d_lens, S, bsum, d_offsets);
   return hipGetLastError();
+}
+
+bool scan_gather_is_fused(uint64_t S) { return S <= (uint64_t)kScanBlock; }
+// lens -> offsets and slots -> payload: one launch for S <= kScanBlock streams, scan (3) + gather (1) otherwise
+hipError_t launch_scan_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream) {
+  if (scan_gather_is_fused(S)) {
+    hipLaunchKernelGGL(k_scan_gather_small, dim3(1), dim3(kScanThreads), 0, stream, d_slots, slot_stride, d_lens, S, d_offsets, d_payload,
+                       payload_cap);
+    return hipGetLastError();
+  }
+  const hipError_t err = launch_scan(d_lens, S, d_offsets, d_tmp, stream);
+  return err != hipSuccess ? err : launch_gather(d_slots, slot_stride, d_lens, d_offsets, S, d_payload, payload_cap, stream);
 }
 
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,

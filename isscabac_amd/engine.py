@@ -118,6 +118,8 @@ def _load():
     L.isscabac_decode_batch_dev_async.argtypes = L.isscabac_decode_batch_dev.argtypes
     L.isscabac_sync.argtypes = [_vp, _u64p]
     L.isscabac_kernel_ms_mean.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    if hasattr(L, "isscabac_kernel_ms_samples_dropped"):
+        L.isscabac_kernel_ms_samples_dropped.argtypes = [_vp, C.c_int, _u64p]
     L.isscabac_kernel_ms_samples.argtypes = [_vp, C.c_int, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]
     L.isscabac_encode_batch.argtypes = [_vp, _u8p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
                                         _u8p, C.c_uint64, _u64p, _u64p]
@@ -174,12 +176,14 @@ def _load():
                                               C.c_int, _u8p, _u32p]
     L.isscabac_multi_encode_batch_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_uint64, C.c_uint32,
                                                   C.c_uint32, _u8p, C.c_int, _vp, C.c_uint64, _vp, _u64p]
-    L.isscabac_multi_decode_batch_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, C.POINTER(_vp), C.POINTER(_vp), C.c_uint64, C.c_uint32,
-                                                  C.c_uint32, _u8p, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
-    L.isscabac_multi_encode_batch_packed.argtypes = L.isscabac_encode_batch_packed.argtypes
-    L.isscabac_multi_decode_batch_packed.argtypes = L.isscabac_decode_batch_packed.argtypes
-    L.isscabac_multi_encode_symbols_stats.argtypes = L.isscabac_encode_symbols_stats.argtypes
-    L.isscabac_multi_decode_symbols.argtypes = L.isscabac_decode_symbols.argtypes
+    # (an older build of the ABI loaded for an A/B -- ISSCABAC_LIB, tools/ab_bench.py -- lacks the entry points of this round)
+    if not os.environ.get("ISSCABAC_LIB") or hasattr(L, "isscabac_multi_decode_batch_dev"):
+        L.isscabac_multi_decode_batch_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, C.POINTER(_vp), C.POINTER(_vp), C.c_uint64,
+                                                      C.c_uint32, C.c_uint32, _u8p, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]
+        L.isscabac_multi_encode_batch_packed.argtypes = L.isscabac_encode_batch_packed.argtypes
+        L.isscabac_multi_decode_batch_packed.argtypes = L.isscabac_decode_batch_packed.argtypes
+        L.isscabac_multi_encode_symbols_stats.argtypes = L.isscabac_encode_symbols_stats.argtypes
+        L.isscabac_multi_decode_symbols.argtypes = L.isscabac_decode_symbols.argtypes
     # on-disk container
     _strs = C.POINTER(C.c_char_p)
     L.isscabac_write_stream_files.argtypes = [_u8p, _u64p, C.c_uint64, _strs]
@@ -314,6 +318,17 @@ class Engine:
             buf = (C.c_float * max(1, n.value))()
             self._check(self._L.isscabac_kernel_ms_samples(self._h, i, buf, n.value, C.byref(n)))
             out[k] = [float(buf[j]) for j in range(n.value)]
+        return out
+
+    def kernel_ms_samples_dropped(self):
+        """launches whose time was not kept since the last call (the series above is truncated if any): per kernel"""
+        out = {}
+        if not hasattr(self._L, "isscabac_kernel_ms_samples_dropped"):
+            return {k: 0 for k in ("encode", "scan", "gather", "decode")}
+        for i, k in enumerate(("encode", "scan", "gather", "decode")):
+            n = C.c_uint64(0)
+            self._check(self._L.isscabac_kernel_ms_samples_dropped(self._h, i, C.byref(n)))
+            out[k] = int(n.value)
         return out
 
     # ---- device-buffer hot path ------------------------------------------------------------------------

@@ -8,16 +8,28 @@ def update_traffic(summary, note):
     """FETCH_SIZE / WRITE_SIZE of the coder kernels (KiB per launch) -> profiles/pmc_traffic.json, which bench.py quotes"""
     d = json.load(open(summary))
     t = json.load(open("profiles/pmc_traffic.json"))
-    for k, x in d.items():
-        for name in ("k_decode", "k_encode"):
-            if k.startswith(name + "<") and "FETCH_SIZE" in x:
-                f, w = x["FETCH_SIZE"] * 1024, x["WRITE_SIZE"] * 1024
-                t.setdefault("config3", {}).setdefault(name, {}).update(fetch_bytes=f, write_bytes=w, hbm_bytes_per_launch=f + w, source=note)
+    for name in ("k_decode", "k_encode"):
+        # config 3 under automatic tuning runs ONE instance of each kernel: <= 64 contexts, throughput, not bucketed.  A summary
+        # that holds others as well (small batches, > 128 contexts, bucketed launches) must not overwrite it silently.
+        want = name + "<1, false, false>"
+        hits = [k for k in d if k.startswith(name + "<") and "FETCH_SIZE" in d[k]]
+        if want not in hits:
+            if hits:
+                raise SystemExit("refresh_profiles: %s not in the PMC summary (found %s)" % (want, hits))
+            continue
+        x = d[want]
+        # FETCH_SIZE tallies 64 bytes per L2 line fill although a fill moves the whole 128-byte line whatever the request
+        # asked for (profiles/r04/fetch_calibration.txt): reads = 2 x the counter.  WRITE_SIZE is exact.
+        f, w = 2.0 * x["FETCH_SIZE"] * 1024, x["WRITE_SIZE"] * 1024
+        t.setdefault("config3", {}).setdefault(name, {}).update(fetch_counter_bytes=x["FETCH_SIZE"] * 1024, fetch_bytes=f, write_bytes=w,
+                                                                 hbm_bytes_per_launch=f + w, source=note)
     json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
 
 
 if sys.argv[1] == "--traffic-only":  # on the GPU box, between the PMC passes and the bench line (tools/evidence_run.sh)
-    update_traffic(sys.argv[2], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, same evidence run (see profiles/README.md)")
+    update_traffic(sys.argv[2], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, same evidence run; reads = 2 x FETCH_SIZE "
+                   "(64 B tallied per 128-byte line fill: profiles/r04/fetch_calibration.txt); Infinity Cache hits included: an upper bound "
+                   "of the HBM bytes (see profiles/README.md)")
     sys.exit(0)
 src, rnd = sys.argv[1], sys.argv[2]
 dst = "profiles/%s/" % rnd
@@ -27,8 +39,9 @@ shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], dst + "final_kern
 for f in ("pmc_summary.json", "pmc_table.txt", "other_shapes.txt", "s_sweep.txt", "s_sweep.json"):
     if os.path.exists(src + "/" + f):
         shutil.copy(src + "/" + f, dst + "final_" + f)
-note = ("profiles/%s/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE calibrated 1:1 "
-        "on k_encode whose reads are exactly 2 B/bin)" % rnd)
+note = ("profiles/%s/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; reads = 2 x FETCH_SIZE: the "
+        "counter tallies 64 B per 128-byte line fill, calibrated on known byte counts in profiles/r04/fetch_calibration.txt; the "
+        "fills include those served by the Infinity Cache, so this is an upper bound of the HBM bytes)" % rnd)
 update_traffic(src + "/pmc_summary.json", note)
 b = json.load(open(src + "/bench.json"))
 print("value %.1f Gbin/s" % b["value"], b["kernels_ms"], "frac %.3f" % b["roofline"]["frac"], "cpu %.4f" % b["cpu_baseline"]["value"])
