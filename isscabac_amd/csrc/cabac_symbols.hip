@@ -913,12 +913,7 @@ int isscabac_iss_init_context_model(isscabac_engine *e, const uint8_t *sym, uint
   HIP_TRY(e, hipSetDevice(e->device));
   int rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], S * pitch);
   if (rc) return rc;
-  if ((rc = pipe_init(e))) return rc;
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  HostPipe up{e, 0, isscabac_engine::kPinSlots};  // pageable caller memory: through the pinned ring
-  if ((rc = up.upload(e->stage[0], sym, S * pitch))) return rc;
-  HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
-  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, S * pitch, hipMemcpyHostToDevice, e->stream));
   return isscabac_iss_init_context_model_dev(e, static_cast<uint8_t *>(e->stage[0]), S, nsym, pitch, p, p0_out, p0_bytes_out);
 }
 
@@ -1090,6 +1085,11 @@ int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32
                                        offsets, total_bytes, nbins_out, nullptr);
 }
 
+// Host-buffer forms.  The caller's arrays are pageable; the copies are plain hipMemcpyAsync calls on the engine's stream.  Moving
+// them onto the bin-level calls' pinned ring (cabac_internal.h: HostPipe) was tried and measured SLOWER here (config 4 tiled
+// x 16 384, 131 MB in / 30 MB out: encode 4.70 against 3.92 ms, decode 4.16 against 3.44; profiles/r04/symbol_host_rate.txt):
+// the runtime's own staging of a pageable copy runs at 35-40 GB/s on this system, and a symbol batch has no stream groups
+// whose transfers the ring could overlap with the kernels of their neighbours.
 int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S,
                                   uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
                                   int nctx, uint8_t *payload, uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes,
@@ -1106,16 +1106,8 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
   if ((rc = sym_grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = sym_grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
-  // the caller's arrays are pageable: through the engine's pinned ring (cabac_internal.h: HostPipe), the host copies into the
-  // slots running beside the DMA of the slots before -- as the bin-level host calls do
-  if ((rc = pipe_init(e))) return rc;
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const int half = isscabac_engine::kPinSlots / 2;
-  HostPipe up{e, 0, half}, down{e, half, isscabac_engine::kPinSlots - half};
-  if ((rc = up.upload(e->stage[0], sym, in_bytes))) return rc;
-  if (nsym_per_stream && (rc = up.upload(e->stage[2], nsym_per_stream, S * sizeof(uint32_t)))) return rc;
-  HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
-  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, in_bytes, hipMemcpyHostToDevice, e->stream));
+  if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
   // statistics: one device block behind the staged symbols' own buffer [hist | cost | sym_bits]
   isscabac_symbol_stats dst = {nullptr, nullptr, nullptr, nullptr, 0};
   const uint64_t hbytes = S * ISSCABAC_STAT_CTX * sizeof(uint32_t), sbytes = (S * pitch * sizeof(uint16_t) + 3) & ~3ull;
@@ -1137,19 +1129,19 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
                                          ctx_init, nctx, static_cast<uint8_t *>(e->stage[3]), dev_cap,
                                          static_cast<uint64_t *>(e->stage[4]), &total, static_cast<uint32_t *>(e->stage[5]), &dst);
   if (rc) return rc;
+  if (dst.ctx_hist) HIP_TRY(e, hipMemcpyAsync(stats->ctx_hist, dst.ctx_hist, hbytes, hipMemcpyDeviceToHost, e->stream));
+  if (dst.ctx_cost) HIP_TRY(e, hipMemcpyAsync(stats->ctx_cost, dst.ctx_cost, hbytes, hipMemcpyDeviceToHost, e->stream));
+  if (dst.sym_bits) HIP_TRY(e, hipMemcpyAsync(stats->sym_bits, dst.sym_bits, S * pitch * sizeof(uint16_t), hipMemcpyDeviceToHost, e->stream));
+  if (dst.bin_trace) HIP_TRY(e, hipMemcpyAsync(stats->bin_trace, dst.bin_trace, tbytes, hipMemcpyDeviceToHost, e->stream));
   if (total_bytes) *total_bytes = total;
   if (total > payload_cap)
     return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols: payload needs %llu bytes, capacity is %llu",
                        (unsigned long long)total, (unsigned long long)payload_cap);
-  // (the device call has waited for its kernels: the copy stream may start at once)
-  if ((rc = down.download(payload, e->stage[3], total))) return rc;
-  if ((rc = down.download(offsets, e->stage[4], (S + 1) * sizeof(uint64_t)))) return rc;
-  if (nbins_out && (rc = down.download(nbins_out, e->stage[5], S * sizeof(uint32_t)))) return rc;
-  if (dst.ctx_hist && (rc = down.download(stats->ctx_hist, dst.ctx_hist, hbytes))) return rc;
-  if (dst.ctx_cost && (rc = down.download(stats->ctx_cost, dst.ctx_cost, hbytes))) return rc;
-  if (dst.sym_bits && (rc = down.download(stats->sym_bits, dst.sym_bits, S * pitch * sizeof(uint16_t)))) return rc;
-  if (dst.bin_trace && (rc = down.download(stats->bin_trace, dst.bin_trace, tbytes))) return rc;
-  return down.drain();
+  HIP_TRY(e, hipMemcpyAsync(payload, e->stage[3], total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(offsets, e->stage[4], (S + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  if (nbins_out) HIP_TRY(e, hipMemcpyAsync(nbins_out, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
 }
 
 int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint32_t *nsym_per_stream,
@@ -1168,22 +1160,17 @@ int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const ui
   if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
   if ((rc = sym_grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = sym_grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
-  if ((rc = pipe_init(e))) return rc;
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const int half = isscabac_engine::kPinSlots / 2;
-  HostPipe up{e, 0, half}, down{e, half, isscabac_engine::kPinSlots - half};  // the pinned ring, as in isscabac_encode_symbols
-  if (nsym_per_stream && (rc = up.upload(e->stage[2], nsym_per_stream, S * sizeof(uint32_t)))) return rc;
-  if ((rc = up.upload(e->stage[3], payload, total))) return rc;
-  if ((rc = up.upload(e->stage[4], offsets, (S + 1) * sizeof(uint64_t)))) return rc;
-  HIP_TRY(e, hipEventRecord(e->pipe_ev[0], e->h2d_stream));
-  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->pipe_ev[0], 0));
+  if (nsym_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nsym_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[3], payload, total, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[4], offsets, (S + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   rc = isscabac_decode_symbols_dev(e, static_cast<uint8_t *>(e->stage[3]), total, static_cast<uint64_t *>(e->stage[4]),
                                    nsym_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nsym, pitch, params, ctx_init,
                                    nctx, static_cast<uint8_t *>(e->stage[0]), static_cast<uint32_t *>(e->stage[5]));
   if (rc) return rc;
-  if ((rc = down.download(sym_out, e->stage[0], out_bytes))) return rc;
-  if (status && (rc = down.download(status, e->stage[5], S * sizeof(uint32_t)))) return rc;
-  return down.drain();
+  HIP_TRY(e, hipMemcpyAsync(sym_out, e->stage[0], out_bytes, hipMemcpyDeviceToHost, e->stream));
+  if (status) HIP_TRY(e, hipMemcpyAsync(status, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
 }
 
 }  // extern "C"
