@@ -444,9 +444,6 @@ struct LdsStates {
     const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
     return (uint64_t)row | (uint64_t)sp << 32;
 #else
-#ifndef ISSCABAC_DEC_SHL16
-#define ISSCABAC_DEC_SHL16 0  // the 16-bit shift (inline assembly) measured SLOWER in the decode kernel: 2.879 against 2.812 ms, medians of 8 on
-#endif                        // one box -- the compiler schedules its own shift better than one it cannot see into
 
     return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3));
 #endif

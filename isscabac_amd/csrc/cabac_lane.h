@@ -109,6 +109,11 @@ CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 #ifndef ISSCABAC_SHL16
 #define ISSCABAC_SHL16 1
 #endif
+// ... but not for the decode kernels' table address: there the 16-bit shift (inline assembly) measured SLOWER, 2.879 against
+// 2.812 ms (medians of 8 on one box) -- the compiler places its own shift better than one it cannot see into
+#ifndef ISSCABAC_DEC_SHL16
+#define ISSCABAC_DEC_SHL16 0
+#endif
 CABAC_HD uint32_t shl16(uint32_t x, uint32_t n) {
 #if defined(__HIP_DEVICE_COMPILE__) && ISSCABAC_SHL16
   uint32_t r;

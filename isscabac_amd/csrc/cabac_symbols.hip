@@ -383,7 +383,7 @@ struct WalkStates {
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)a) = (uint8_t)q; }
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)shl16c<2>(q)); }
   // the decoder's entry by raw state byte (bit 0 = a stale bin): 256 entries at LDS 0
-  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)shl16c<3>(qb)); }
+  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3)); }
 };
 // Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where it is the shift that picks the successor
 struct WalkBin {
