@@ -310,6 +310,9 @@ def main():
             try:
                 torch.cuda.set_device(local_rank)  # the current device is per thread
                 p_mine, o_mine = sharding.concat_launches([(b["payload"][:t], b["offsets"]) for b, t in zip(bufs, totals)])
+                # untimed first pass over each rank's first stream: the first all-gather and the first send / receive between two
+                # ranks set up RCCL's channels and load torch's copy kernels (tens of ms, once per process) -- not the exchange
+                sharding.gather_payload(p_mine[:int(o_mine[1])], o_mine[:2], dist)
                 fence()
                 g0 = time.perf_counter()
                 p_all, o_all = sharding.gather_payload(p_mine, o_mine, dist)

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch  # noqa: F401
-from isscabac_amd.engine import MultiEngine
+from isscabac_amd.engine import MultiEngine, stream_bound
 from oracle.pyoracle import Oracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -26,6 +26,48 @@ while time.time() - t0 < budget:
     bins = (rng.random((S, B)) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
     nb = rng.integers(0, B + 1, S).astype(np.uint32) if rng.random() < 0.4 else None
     want_p, want_o = orc.encode_batch(bins, ctx, init, nb)
+    form = int(rng.integers(0, 3))  # 0: bins as bytes, 1: bins as bits, 2: device-resident shards gathered on / pulled from the root
+    pitch = max(16, (B + 15) // 16 * 16)
+    if form == 1:
+        padded = np.zeros((S, pitch), np.uint8)
+        padded[:, :B] = bins
+        got_p, got_o = eng.encode_packed(np.packbits(padded, axis=1, bitorder="little"), ctx, init, nb)
+        dbits, st = eng.decode_packed(got_p, got_o, ctx, init, nb)
+        assert not st.any(), ("status packed", S, B, Cn, ep)
+        dec = np.unpackbits(dbits, axis=1, bitorder="little")[:, :B]
+        for s in range(S):
+            n = B if nb is None else int(nb[s])
+            assert np.array_equal(dec[s, :n], bins[s, :n]), ("bins packed", S, B, Cn, ep, s)
+    elif form == 2:
+        dev = torch.device("cuda:0")
+        tb, tc, tn, tout, tst = [], [], [], [], []
+        bp, cp = np.zeros((S, pitch), np.uint8), np.zeros((S, pitch), np.uint8)
+        bp[:, :B], cp[:, :B] = bins, ctx
+        for g in range(eng.n):
+            lo, hi = eng.shard(S, g)
+            tb.append(torch.from_numpy(bp[lo:hi].copy()).to(dev))
+            tc.append(torch.from_numpy(cp[lo:hi].copy()).to(dev))
+            tn.append(torch.from_numpy((nb if nb is not None else np.full(S, B, np.uint32))[lo:hi].astype(np.int32)).to(dev))
+            tout.append(torch.zeros((max(1, hi - lo), pitch), dtype=torch.uint8, device=dev))
+            tst.append(torch.ones(max(1, hi - lo), dtype=torch.int32, device=dev))
+        cap = S * stream_bound(B)
+        dpay = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        doff = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        ptr = lambda ts: [t.data_ptr() for t in ts]
+        total = eng.encode_dev(ptr(tb), ptr(tc), S, B, pitch, init, dpay.data_ptr(), cap, doff.data_ptr(), d_nbins=ptr(tn))
+        assert doff.cpu().numpy().astype(np.uint64).tolist() == want_o.tolist(), ("offsets dev", S, B, Cn, ep)
+        assert dpay[:total].cpu().numpy().tobytes() == want_p.tobytes(), ("payload dev", S, B, Cn, ep)
+        eng.decode_dev(dpay.data_ptr(), total, doff.data_ptr(), ptr(tc), S, B, pitch, init, ptr(tout), ptr(tst), d_nbins=ptr(tn))
+        torch.cuda.synchronize()
+        for g in range(eng.n):
+            lo, hi = eng.shard(S, g)
+            if hi == lo:
+                continue
+            assert not tst[g].cpu().numpy().any(), ("status dev", S, B, Cn, ep, g)
+            d = tout[g].cpu().numpy()
+            for s in range(lo, hi):
+                n = B if nb is None else int(nb[s])
+                assert np.array_equal(d[s - lo, :n], bins[s, :n]), ("bins dev", S, B, Cn, ep, s)
     got_p, got_o = eng.encode(bins, ctx, init, nb)
     assert np.array_equal(got_o, want_o), ("offsets", S, B, Cn, ep)
     assert got_p.tobytes() == want_p.tobytes(), ("payload", S, B, Cn, ep)
@@ -47,4 +89,4 @@ while time.time() - t0 < budget:
         flagged += int((st != 0).sum())
     rounds += 1
     bins_total += S * B
-print("multi soak ok: %d rounds, %.1f M bins, %d corrupted streams flagged, %.0f s" % (rounds, bins_total / 1e6, flagged, time.time() - t0))
+print("multi soak (byte, packed and device-resident forms) ok: %d rounds, %.1f M bins, %d corrupted streams flagged, %.0f s" % (rounds, bins_total / 1e6, flagged, time.time() - t0))
