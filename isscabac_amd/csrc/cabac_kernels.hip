@@ -250,6 +250,40 @@ struct TileT {
     *reinterpret_cast<uint4 *>(tile + lds_off(lane, j)) = v;
   }
 };
+// The same round with the lanes paired differently: lanes 2 r and 2 r + 1 fetch 32 contiguous bytes of row r (+ 32 for odd k),
+// instruction k covers 32 rows x 32 bytes, and the instructions k = 2 h and 2 h + 1 together hold exactly part h of all 64 rows
+// -- so a part goes to LDS in TWO ds_write_b128 with every lane active, where TileT<4> needs four with half of the lanes and
+// TileT<8> eight with a quarter of them (a wave-wide LDS store costs its 13 transfer cycles whatever the number of lanes).
+// The instructions k and k + 2 ask for the two (T = 64) or more pieces of the same lines back to back.
+template <int LPR>
+struct TilePairT {
+  static constexpr int T = 16 * LPR, H = 32, NLD = LPR, NP = T / H;
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return (uint32_t)(lane >> 1) + 32u * (uint32_t)(k & 1); }
+  __device__ static __forceinline__ uint32_t ch_of(int k, int lane) { return 2u * (uint32_t)(k >> 1) + (uint32_t)(lane & 1); }
+  template <bool NT = false>
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch, uint32_t off,
+                                              int lane) {
+    const uint32_t ro0 = min(row_of(0, lane), nrows - 1u) * pitch, ro1 = min(row_of(1, lane), nrows - 1u) * pitch;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint32_t voff = ((k & 1) ? ro1 : ro0) + min(off + ch_of(k, lane) * 16, pitch - 16u);  // (clamped like TileT::load)
+      r[k] = NT ? nt_load16(rows + voff) : ld16(rows + voff);
+    }
+  }
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(kk, lane), lane & 1)) = r[2 * h + kk];
+  }
+  __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
+    return *reinterpret_cast<const uint4 *>(tile + lds_off(lane, j));
+  }
+  // (the length-bucketed instances keep TileT -- their rows are not neighbours --; these two only let `if (PERM)` compile)
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows(uint4 (&)[NLD], const uint8_t *, const uint32_t (&)[NLD], uint32_t, uint32_t, int) {}
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows_ids(uint4 (&)[NLD], const uint8_t *, const uint32_t *, uint32_t, uint32_t, int) {}
+};
 typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
 // the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
 // both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
@@ -267,10 +301,15 @@ typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input a
 #endif
 constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
                                                 // half of every 128-byte line is an L2 hit one round later only if the first allocated it
+#ifndef ISSCABAC_ENC_TILE_PAIR
+#define ISSCABAC_ENC_TILE_PAIR 0
+#endif
 template <bool PERM>
-using EncTileB = TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
 template <bool PERM>
-using EncTileC = TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>;
+using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type;
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
@@ -982,8 +1021,12 @@ constexpr int kDecTabBytes = 2048;
 #ifndef ISSCABAC_DEC_LPR_PERM
 #define ISSCABAC_DEC_LPR_PERM ISSCABAC_DEC_LPR
 #endif
+#ifndef ISSCABAC_DEC_TILE_PAIR
+#define ISSCABAC_DEC_TILE_PAIR 0
+#endif
 template <bool LAT, bool PERM>
-using DecTile = TileT<LAT ? 4 : PERM ? ISSCABAC_DEC_LPR_PERM : ISSCABAC_DEC_LPR>;
+using DecTile = typename std::conditional<!LAT && !PERM && ISSCABAC_DEC_TILE_PAIR, TilePairT<ISSCABAC_DEC_LPR>,
+                                          TileT<LAT ? 4 : PERM ? ISSCABAC_DEC_LPR_PERM : ISSCABAC_DEC_LPR>>::type;
 template <int CM, bool PERM>
 struct DecLds {
   static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
