@@ -299,6 +299,9 @@ typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input a
 #ifndef ISSCABAC_ENC_DEPTH2
 #define ISSCABAC_ENC_DEPTH2 0
 #endif
+#ifndef ISSCABAC_ENC_SPLIT_FETCH
+#define ISSCABAC_ENC_SPLIT_FETCH 0  // experiment: the ctx array's loads one chunk later than the bins array's (two bursts of four instead of one of eight)
+#endif
 constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
                                                 // half of every 128-byte line is an L2 hit one round later only if the first allocated it
 #ifndef ISSCABAC_ENC_TILE_PAIR
@@ -798,7 +801,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's bytes again and again)
       // registers are free again: the set's next round
       if (h % BTile::NP == BTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, false);
-      if (h % CTile::NP == CTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
+      const bool fetch_c = h % CTile::NP == CTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax;
+      if (!ISSCABAC_ENC_SPLIT_FETCH && fetch_c) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
+#else
+      const bool fetch_c = false;
 #endif
 #if ISSCABAC_ENC_ROLLED
 #pragma unroll 1
@@ -806,6 +812,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = pos + j * 16;
         if (i0 >= nmax) break;
+        if (ISSCABAC_ENC_SPLIT_FETCH && j == 1 && fetch_c) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
         const uint4 wb = BTile::row_chunk(tile_b, lane, j);
         const uint4 wc = CTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;

@@ -359,12 +359,38 @@ CABAC_HD void enc_pick(const Bin &bin, uint32_t q, uint32_t t, uint32_t lps, uin
   r = select_mask(m, lps, rmps);
   a = rmps & m;
 }
+// timing experiments (wrong output, never in the product build): which half of the step bounds the kernel?
+//   ISSCABAC_EXP_STEP 1: arithmetic only -- no state read / write, the table entry by a constant state (one LDS read, no chain)
+//   ISSCABAC_EXP_STEP 2: arithmetic only, no LDS at all (the entry out of registers)
+//   ISSCABAC_EXP_STEP 3: state pass only -- state read, entry read, successor write; no range / low arithmetic
+#ifndef ISSCABAC_EXP_STEP
+#define ISSCABAC_EXP_STEP 0
+#endif
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
+#if ISSCABAC_EXP_STEP == 1 || ISSCABAC_EXP_STEP == 2
+  const uint32_t q = opaque(40u);
+#if ISSCABAC_EXP_STEP == 1
+  const uint64_t ent = st.entry_mem(q);
+#else
+  const uint64_t ent = (uint64_t)opaque(0x3B332B23u) | ((uint64_t)opaque(0x00FF2C24u) << 32);
+#endif
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  (void)at;
+#elif ISSCABAC_EXP_STEP == 3
+  const uint32_t q = st.load_at(at);
+  const uint64_t ent = st.entry_mem(q);
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  st.store_at(at, t);
+  if (first) g.T = g.S = 0;
+  g.T += (uint32_t)ent >> 31;  // (keeps the row alive)
+  return;
+#else
   const uint32_t q = st.load_at(at);
   const uint64_t ent = st.entry_mem(q);
   const uint32_t t = bin.next_of((uint32_t)(ent >> 32));  // low byte: the successor; bit 16: the bin is not q's mps
   st.store_at(at, t);
+#endif
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   uint32_t r, a;
