@@ -376,6 +376,37 @@ struct BinOfWord {
     return r;
   }
   __device__ __forceinline__ uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)__builtin_amdgcn_sbfe(t, 16, 1); }
+  // x | byte K of y, x + byte K of y, x * byte K of y (x below 2^24): one SDWA instruction each -- per-bin fields of a per-word
+  // SWAR word without an extraction of their own
+  __device__ __forceinline__ uint32_t or_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t add_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t mul_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t lps_mask_sext(uint32_t t) const {  // the shifted entry's flag byte (0x00 / 0xFF) as a 32-bit mask
+    uint32_t m;
+    asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
+    return m;
+  }
   __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
     uint32_t r;
     if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));
@@ -665,7 +696,13 @@ struct WaveLds {
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
-  static constexpr uint32_t BYTES = SB + 2 * TILE + STAGE + IDS;
+#ifndef ISSCABAC_ENC_MIXED2
+#define ISSCABAC_ENC_MIXED2 1  // the mixed step on a dummy context (enc_bin_mixed2_acc); 0: the select-based step of rounds 2-3
+#endif
+  // one more row of the state image, behind its last context group: the "context" bypass bins read and write in the mixed
+  // step (a byte nobody else looks at).  Not with 255 contexts: there the mixed step does not run and the row would cost a wave per CU
+  static constexpr uint32_t DUMMY = (ISSCABAC_ENC_MIXED2 && CM != 2) ? 256u : 0u;
+  static constexpr uint32_t BYTES = SB + DUMMY + 2 * TILE + STAGE + IDS;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -714,7 +751,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const uint32_t sbytes = CM == 2 ? a.img_bytes : WL::SB;  // the wave's state image
   const uint32_t ctx_lim = min(sbytes >> 6, 255u), ctx_kadd = (256u - ctx_lim) * 0x01010101u;
   uint8_t *wbase = smem + kTabBytes + wib * (WL::BYTES - WL::SB + sbytes);
-  uint8_t *tile_b = wbase + sbytes, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
+  uint8_t *tile_b = wbase + sbytes + WL::DUMMY, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
 
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
@@ -745,6 +782,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     // and overruns the slot bound of 6
     const uint32_t ngrp = sbytes / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+    if (WL::DUMMY) st32[ngrp * 64] = 0;  // the bypass bins' dummy context: always an even byte (it only ever receives the all-zero entry's successor, 0)
   }
   LdsStates stx{wbase + lane * 4};
 
@@ -895,11 +933,21 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 #pragma unroll
           for (int k = 0; k < 16; k++) {
             const uint32_t cw = word_of(wc, k >> 2);
-            const CtxQuad z = stx.prep4(cw & kIn);
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+#if ISSCABAC_ENC_MIXED2
+            // per word: the bypass bits as bytes of 0 / 1, of 0 / 0xFE (or-ed into the state: 0xFE is the all-zero table entry),
+            // and the bypass bins of value 1; a bypass bin's state address is the dummy context behind the image
+            constexpr uint32_t kDummy = (CM == 1 ? 64u : 128u) * 0x01010101u;
+            const uint32_t cwm = (cw >> 7) & 0x01010101u, mbfe = cwm * 0xFEu;
+            const CtxQuad z = stx.prep4(select_mask(mbfe | cwm, kDummy, cw & kIn));
+            const uint32_t wbm = w1 & cwm;
+            with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed2_acc(e, acc, (k & 3) == 0, bin, cwm, mbfe, wbm, stx.addr_of(z, k & 3), stx); return 0; });
+#else
+            const CtxQuad z = stx.prep4(cw & kIn);
             const uint32_t wbm = w1 & (cw >> 7);  // per word: bit 0 of byte k = "bypass bin of 1"
             const uint32_t mb = byte_bit_mask(cw, k & 3, 7), bm = byte_bit_mask(wbm, k & 3, 0);
             with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed_acc(e, acc, (k & 3) == 0, bin, mb, bm, stx.addr_of(z, k & 3), stx); return 0; });
+#endif
             if ((k & 3) == 3) {
               enc_word_close(e, acc);
               if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);

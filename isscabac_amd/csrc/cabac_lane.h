@@ -453,6 +453,30 @@ CABAC_HD void enc_bin_mixed_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, 
   e.range = shl16(r, n);
 }
 
+// The mixed step without its three selects (round 4).  A bypass bin is given a state of its own to read and write -- a dummy
+// context behind the state image, whose byte only ever receives the all-zero entry's successor (0) --, its table index is made
+// kEncBypassQ's neighbour 0xFE by OR-ing a per-word byte (mbfe) into whatever it read, and the three per-bin quantities that
+// depend on the kind of the bin come out of per-word SWAR words by operand select: cwm (bytes of 0 / 1: the extra shift of a
+// bypass bin), mbfe (0 / 0xFE), wbm (1 where a bypass bin is 1: times the range = what `low` gains).  Same results as
+// enc_bin_mixed_acc; device only (the Bin policy's *_byte members are SDWA instructions).
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_mixed2_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t cwm, uint32_t mbfe, uint32_t wbm, Addr at,
+                                 States &st) {
+  const uint32_t q = st.load_at(at);
+  const uint64_t ent = st.entry_mem(bin.or_byte(q, mbfe));  // a bypass bin: entry 0xFE >> 1 = 127, all zero
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  st.store_at(at, t);                                       // (a bypass bin: 0 into its dummy byte)
+  const uint32_t m = bin.lps_mask_sext(t);                  // ~0: a context bin that is not its mps
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);      // a bypass bin: 0
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);             // ... the range itself
+  const uint32_t n = clz32(r) - 23u;                        // ... 0
+  const uint32_t nt = bin.add_byte(n, cwm);                 // ... which moves low by one bit all the same
+  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + bin.mul_byte(e.range, wbm);
+  g.S = (first ? 0u : g.S) + nt;
+  e.range = shl16(r, n);
+}
+
 // Latency-oriented form of enc_bin_row_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides an
 // LDS round trip, so none may sit on a bin-to-bin dependency chain).  The caller hands in the state q -- loaded one bin
 // ahead, with the previous bin's successor forwarded in a register when both bins use the same context.  In two halves,
