@@ -2,7 +2,7 @@
 """One-off scale check: a batch whose payload exceeds 4 GiB (64-bit offsets everywhere).  5 Mi streams x 8 Ki bins,
 50% bypass -> ~4.7 GB of payload; device round trip + sampled streams against the oracle.  Needs ~170 GB of HBM."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from isscabac_amd import Engine

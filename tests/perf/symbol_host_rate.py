@@ -11,12 +11,12 @@ included.  Three routes, beside the CPU on one core:
                (one MEX call per bin) are not part of that figure
 Shapes: W 400 x 20 and H 109 x 20 (ISS.m:32,36) tiled x 16 384 -> 327 680 columns as independent streams, Nq = 8, EG0,
 23 contexts; and config 4 at its real size (40 columns), where a call is launch latency.
-    python tools/symbol_host_rate.py [--tile 16384] [--no-gateway]"""
+    python tests/perf/symbol_host_rate.py [--tile 16384] [--no-gateway]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
