@@ -991,3 +991,38 @@ def test_symbol_kernels_follow_the_second_derivation(engine):
     for case in fx["demo"]:
         init = rng.integers(0, 126, 3).astype(np.uint8)
         check(np.array(case["symbols"], np.uint8)[None, :], SymbolParams.demo(case["nq"]), init, [(case["bins"], case["ctx"])])
+
+
+@pytest.mark.parametrize("S", [1023, 1024, 1025])
+def test_offsets_and_payload_across_the_fused_scan_gather_boundary(engine, oracle, S):
+    """batches of up to 1 024 streams run the offsets scan and the payload gather as ONE launch (k_scan_gather_small), bigger
+    ones as scan (3) + gather: the same bytes on both sides of the switch, ragged lengths and empty streams included"""
+    rng = np.random.default_rng(S)
+    B, C = 96, 7
+    bins, ctx = oracle.synth(0xCABAC005, 17, S, B, C, True)
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    nb = rng.integers(0, B + 1, S).astype(np.uint32)
+    nb[:3] = [0, 1, B]
+    for nbins in (None, nb):
+        want_p, want_o = oracle.encode_batch(bins, ctx, init, nbins)
+        got_p, got_o = engine.encode(bins, ctx, init, nbins=nbins)
+        assert (got_o == want_o).all() and got_p.tobytes() == want_p.tobytes()
+
+
+def test_kernel_time_series_reports_no_truncation_for_a_short_run(engine):
+    import torch
+    dev = torch.device("cuda:0")
+    S, B = 256, 64
+    bins = torch.randint(0, 2, (S, B), dtype=torch.uint8, device=dev)
+    ctx = torch.randint(0, 3, (S, B), dtype=torch.uint8, device=dev)
+    cap = S * 128
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    engine.set_profiling(True)
+    engine.kernel_ms_samples()
+    engine.kernel_ms_samples_dropped()
+    for _ in range(3):
+        engine.encode_dev(bins.data_ptr(), ctx.data_ptr(), S, B, B, np.zeros(3, np.uint8), payload.data_ptr(), cap, offsets.data_ptr())
+    s = engine.kernel_ms_samples()
+    assert len(s["encode"]) == 3 and len(s["scan"]) == 3 and all(v == 0 for v in engine.kernel_ms_samples_dropped().values())
+    engine.set_profiling(False)
