@@ -64,3 +64,12 @@ def test_payload_beyond_4_gib_offsets_are_64_bit():
                                         [0, 1, S // 2, S - 1] + list(range(S - 100_000, S - 100_000 + 64)), 1100)
     assert total > (1 << 32)
     assert int(off[S - 100_000]) > (1 << 32)  # the sampled run does start beyond 4 GiB
+
+
+def test_streams_of_the_maximum_length():
+    """ISSCABAC_MAX_PITCH: 64 streams (one full wave) of 2^25 bins each -- the longest rows the batch calls take; the lanes' 32-bit
+    row offsets reach 63 * 2^25 + 2^25 - 16 < 2^32, a stream's payload ~3 MB, its slot ~25 MB.  Device round trip over all
+    2.1 G bins, the first and the last stream byte for byte against the oracle (33 M bins each)."""
+    S, B = 64, 1 << 25
+    total, off = _round_trip_and_sample(S, B, 64, 0xCABAC003, False, [0, S - 1], B // 8 + 64)
+    assert 0.09 * S * B < total < 0.11 * S * B
