@@ -1,0 +1,414 @@
+// cabac_pair.hip -- the encode kernel for SMALL launches (at most two waves of streams per SIMD): a producer / consumer
+// PAIR of wavefronts per 64 streams, written for gfx950 (MI355X, wave64).
+//
+// Why a pair.  With one wave per 64 streams (cabac_kernels.hip) a launch of <= 128 Ki streams leaves two of a SIMD's four
+// wave slots and half of the LDS empty, and a wave by itself issues no faster than one instruction per ~2.2 ns whatever
+// the other wave does: the ~29 instructions of a bin then ARE the time.  In the encoder the context states evolve from the
+// bins and contexts alone -- no range, no low (ref: CABAC/CABAC_ArithmeticEncoder.cpp:113-178 reads the state, never the
+// other way round; ContextModel.cpp:107-123) -- so the per-bin work splits into two recurrences that never feed back:
+//   wave A (producer): input tiles, context-state pass (state -> table entry -> successor), per bin ONE record for B:
+//                      the state's 4-byte rangeTabLps row and one bit "this bin is not the state's mps";
+//   wave B (consumer): the range / low arithmetic on those records (pure VALU: no table, no state image, no input
+//                      arrays), the 16-bit digit flush and the byte sink.
+// Records travel through an LDS ring of two slots of 16 bins (one chunk); the two waves of a workgroup meet at one
+// s_barrier per chunk: A fills slot c & 1 while B codes slot (c - 1) & 1.  Each wave's instruction stream is about half of
+// the single wave's, both SIMD slots and the idle LDS are used, and neither chain contains the other's latency.
+//
+// A chunk is PLAIN (every lane has 16 context-coded bins: straight-line code in both waves), MIXED (context-coded and
+// bypass bins only, config 5's chunks: the same state pass with a bypass bin on a dummy context and the all-zero table
+// entry -- cabac_lane.h: enc_bin_mixed2_acc --, two more bits per record, one select-free step in B) or GENERAL
+// (fixed-probability bins, streams that end inside it: A classifies every bin under the lane's own exec mask and B runs
+// a step whose record can say "nothing", "bypass bin b", or "row + flag").  Bytes are identical to
+// k_encode's for every input (the GPU parity tests run every case through both).
+//
+// LDS of a workgroup (19 712 bytes, eight workgroups per CU = 128 Ki streams resident):
+//   [0, 1024)       the 8-byte entries by packed state (cabac_lane.h: enc_entry_hi); the last 16 bytes -- state 63, which
+//                   no context ever holds -- carry the two slots' kind words
+//   [1024, 5376)    context states, one byte per (lane, context), cabac_wave.h: LdsStates, + the bypass bins' dummy context row
+//   [5376, 9472)    the two input half tiles (bins, ctx)
+//   [9472, 10496)   B's output staging, 16 bytes per lane
+//   [10496, 19712)  the ring: per slot 4 x 1 KiB of rows (word g of lane l at g * 1024 + 16 l: both the ds_write_b128 of A
+//                   and the ds_read_b128 of B are conflict-free) + 512 bytes of flag bits (8 bytes per lane)
+#include "cabac_wave.h"
+
+namespace isscabac {
+
+#ifndef ISSCABAC_ENC_PAIR
+#define ISSCABAC_ENC_PAIR 1
+#endif
+#ifndef ISSCABAC_PAIR_EXP  // timing experiments (wrong output, never in the product build): 1 = B skips its arithmetic, 2 = A skips
+#define ISSCABAC_PAIR_EXP 0  // the state pass, 3 = no barrier between the chunks
+#endif
+#ifndef ISSCABAC_PAIR_TILE_PAIR
+#define ISSCABAC_PAIR_TILE_PAIR 1  // A's input tiles by lane pairs (TilePairT: two full-wave LDS stores per part instead of four half-active ones)
+#endif
+#ifndef ISSCABAC_PAIR_NOSYNC
+#define ISSCABAC_PAIR_NOSYNC 0  // A's tile hand-over without draining lgkmcnt: a wave's LDS operations execute in order anyway
+#endif
+#ifndef ISSCABAC_PAIR_PRIO_A
+#define ISSCABAC_PAIR_PRIO_A 1  // s_setprio of the producer wave: its few chain instructions per bin should never queue behind B's arithmetic
+#endif
+#ifndef ISSCABAC_PAIR_PRIO_B
+#define ISSCABAC_PAIR_PRIO_B 0  // s_setprio of the consumer wave while it codes a chunk
+#endif
+
+namespace pairk {
+constexpr uint32_t kKind = 1008;
+constexpr uint32_t kStates = 1024;
+constexpr uint32_t kDummyRow = kStates + 4096;  // the bypass bins' "context" 64 in mixed chunks (cabac_lane.h: enc_bin_mixed2_acc)
+constexpr uint32_t kTileB = kDummyRow + 256, kTileC = kTileB + 2048, kStage = kTileC + 2048;
+constexpr uint32_t kRing = kStage + 1024;
+constexpr uint32_t kSlotRows = 4096, kSlotBytes = kSlotRows + 512;
+constexpr uint32_t kLdsBytes = kRing + 2 * kSlotBytes;
+static_assert(kLdsBytes == 19712 && 8 * kLdsBytes <= 160 * 1024, "eight workgroups per CU");
+constexpr uint32_t kPlain = 0, kGeneral = 1, kMixed = 2;
+// a GENERAL record's row word when the bin is no context / fixed-probability bin: real rows have no zero byte
+constexpr uint32_t kRecNone = 0u, kRecBypass = 1u;  // bypass: 1 | bin << 1
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+typedef __attribute__((address_space(3))) u32x4 lds_v4;
+
+// the 8-byte entry of the doubled state in the LOW BYTE of q (the bytes above may hold anything): [row | enc_entry_hi]
+__device__ __forceinline__ uint64_t entry_of(uint32_t q, uint32_t two) {
+  uint32_t a;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(two), "v"(q));
+  return *reinterpret_cast<const lds_u64 *>((uintptr_t)a);
+}
+// bit (16 + (i & 7)) of the flag word of bin i: the entry's flag byte (0x00 / 0xFF at bits 16..23 of t) masked to one bit
+__device__ __forceinline__ uint32_t flag_bit(int i) { return 1u << (16 + (i & 7)); }
+__device__ __forceinline__ void put_rows(uint32_t at, const uint4 &v) {
+  const u32x4 w = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<lds_v4 *>((uintptr_t)at) = w;
+}
+__device__ __forceinline__ uint4 get_rows(uint32_t at) {
+  const u32x4 w = *reinterpret_cast<const lds_v4 *>((uintptr_t)at);
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+}  // namespace pairk
+
+template <int K>
+__device__ __forceinline__ uint32_t pair_next_of(uint32_t w8, uint32_t hi) { return BinOfWord<K>{0u, 0u, w8}.next_of(hi); }
+__device__ __forceinline__ uint32_t pair_next_of_k(int k, uint32_t w8, uint32_t hi) {
+  switch (k & 3) {
+    case 0: return pair_next_of<0>(w8, hi);
+    case 1: return pair_next_of<1>(w8, hi);
+    case 2: return pair_next_of<2>(w8, hi);
+    default: return pair_next_of<3>(w8, hi);
+  }
+}
+
+
+// The producer's state pass over one chunk of 16 bins for every lane (PLAIN, or MIXED: context-coded and bypass bins).  The
+// lookup of bin k goes out as soon as the successor of bin k - 1 is back (it is the state of bin k when both name the same
+// context: forwarded in a register); the state of bin k + 1 is read one bin ahead, behind the store of the successor of
+// bin k - 1.  Leaves the rows in the slot (word g of the lane at rows_at + 1024 g) and returns the flag words: bit 16 + i
+// of f0 (bins 0..7) / f1 (bins 8..15) = "bin i is not its state's mps"; MIXED adds bit i = "bypass bin" and bit 8 + i =
+// "bypass bin of value 1".  A bypass bin reads and writes the dummy context behind the state image and looks up the
+// all-zero entry 127 (its state byte or-ed with 0xFE): row 0, successor 0, flag 0.
+template <bool MIXED>
+__device__ __forceinline__ void pair_state_pass(const LdsStates &stx, const uint4 &wb, const uint4 &wc, uint32_t rows_at, uint32_t two,
+                                                uint32_t &f0, uint32_t &f1) {
+  using namespace pairk;
+  constexpr uint32_t kIn = 0x3F3F3F3Fu, kDummy = 64u * 0x01010101u, kGather = 0x01020408u;
+  uint32_t mbfe = 0;
+  auto quad_of = [&](int g) {
+    const uint32_t cw = word_of(wc, g);
+    if (!MIXED) return stx.prep4(cw);
+    const uint32_t cwm = (cw >> 7) & 0x01010101u, wbm = word_of(wb, g) & cwm;
+    mbfe = cwm * 0xFEu;
+    // bytes of 0 / 1 -> four bits, bin 4 g + k at bit k
+    const uint32_t kb = (cwm * kGather) >> 24, vb = (wbm * kGather) >> 24;
+    uint32_t &f = g < 2 ? f0 : f1;
+    f |= (kb | vb << 8) << (4 * (g & 1));
+    return stx.prep4(select_mask(mbfe | cwm, kDummy, cw & kIn));
+  };
+  auto or_mbfe = [&](int k, uint32_t q) {
+    if (!MIXED) return q;
+    switch (k & 3) {
+      case 0: return BinOfWord<0>{0u, 0u, 0u}.or_byte(q, mbfe);
+      case 1: return BinOfWord<1>{0u, 0u, 0u}.or_byte(q, mbfe);
+      case 2: return BinOfWord<2>{0u, 0u, 0u}.or_byte(q, mbfe);
+      default: return BinOfWord<3>{0u, 0u, 0u}.or_byte(q, mbfe);
+    }
+  };
+  uint4 rw;
+  CtxQuad z = quad_of(0);
+  uint32_t at = stx.addr32_of(z, 0), at_prev = 0;
+  uint32_t qld = stx.load_at(at);
+  uint64_t same = 0, ent_prev = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    uint32_t q = qld, tk = 0;
+    if (k > 0) {
+      tk = pair_next_of_k(k - 1, word_of(wb, (k - 1) >> 2) << 3, (uint32_t)(ent_prev >> 32));
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(q) : "v"(qld), "v"(tk), "s"(same));
+    }
+    const uint64_t ent = entry_of(or_mbfe(k, q), two);
+    if (k > 0) {
+      stx.store_at(at_prev, tk);
+      if (k - 1 < 8) f0 |= tk & flag_bit(k - 1);
+      else f1 |= tk & flag_bit(k - 1);
+      set_word(rw, (k - 1) & 3, (uint32_t)ent_prev);
+      if (((k - 1) & 3) == 3) put_rows(rows_at + ((k - 1) >> 2) * 1024u, rw);
+    }
+    uint32_t at_next = 0, qld_next = 0;
+    uint64_t same_next = 0;
+    if (k < 15) {
+      if (((k + 1) & 3) == 0) z = quad_of((k + 1) >> 2);
+      at_next = stx.addr32_of(z, (k + 1) & 3);
+      qld_next = stx.load_at(at_next);
+      asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_next) : "v"(at_next), "v"(at));
+    }
+    ent_prev = ent;
+    at_prev = at;
+    at = at_next;
+    qld = qld_next;
+    same = same_next;
+  }
+  const uint32_t tk = pair_next_of<3>(wb.w << 3, (uint32_t)(ent_prev >> 32));
+  stx.store_at(at_prev, tk);
+  f1 |= tk & flag_bit(15);
+  rw.w = (uint32_t)ent_prev;
+  put_rows(rows_at + 3 * 1024u, rw);
+}
+
+__global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
+  using namespace pairk;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0: producer (A), 1: consumer (B)
+  {
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    const int ps = tid;  // 128 threads, 128 packed states
+    const uint32_t sb = c_next.eb[ps >> 1] >> (16 * (ps & 1));
+    tab[2 * ps] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
+    tab[2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
+  }
+  __syncthreads();
+  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+  if (s0 >= a.S) return;
+
+  const bool valid = s0 + lane < a.S;
+  const uint64_t s = valid ? s0 + lane : a.S - 1;
+  uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
+  n = min(n, a.nbins);
+  // wave-uniform, and the same in both waves: the number of chunks is the number of barriers
+  const uint32_t nmax = __builtin_amdgcn_readfirstlane(wave_max_u32(n)), nmin = __builtin_amdgcn_readfirstlane(wave_min_u32(n));
+  const uint32_t nchunks = (nmax + 15u) >> 4;
+  const uint32_t lane_rows = kRing + (uint32_t)lane * 16u, lane_flags = kRing + kSlotRows + (uint32_t)lane * 8u;
+
+  if (wib == 0) {
+    // ------------------------------------------------------------------------------------------ producer
+    uint8_t *wbase = smem + kStates;
+    {
+      uint32_t *st32 = reinterpret_cast<uint32_t *>(wbase) + lane;
+      for (uint32_t g = 0; g < 16; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;  // (see k_encode: the whole image)
+      st32[16 * 64] = 0;  // the dummy context: only ever receives the all-zero entry's successor
+    }
+    LdsStates stx{wbase + lane * 4};
+    if (ISSCABAC_PAIR_PRIO_A) __builtin_amdgcn_s_setprio(ISSCABAC_PAIR_PRIO_A);
+    uint8_t *tile_b = smem + kTileB, *tile_c = smem + kTileC;
+    using BTile = std::conditional<ISSCABAC_PAIR_TILE_PAIR != 0, TilePairT<4>, TileT<4>>::type;
+    using CTile = BTile;
+    auto tile_sync = [] {
+      if (ISSCABAC_PAIR_NOSYNC) asm volatile("" ::: "memory");  // (the compiler may not move LDS accesses across; the hardware keeps a wave's in order)
+      else wave_lds_sync();
+    };
+    const uint32_t nrounds = (nmax + BTile::T - 1) / BTile::T;
+    const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
+    const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
+    uint4 pb[BTile::NLD], pc[CTile::NLD];
+    if (nrounds) {
+      BTile::load(pb, bins_w, nrows, a.pitch, 0, lane);
+      CTile::load(pc, ctx_w, nrows, a.pitch, 0, lane);
+    }
+    tile_sync();
+    const uint32_t two = opaque(2u);
+    uint32_t c = 0;
+    for (uint32_t t = 0; t < nrounds; t++) {
+#pragma unroll
+      for (int h = 0; h < BTile::NP; h++) {
+        const uint32_t pos = t * BTile::T + h * 32;
+        if (pos >= nmax) break;
+        BTile::half_to_lds(tile_b, pb, h, lane);
+        CTile::half_to_lds(tile_c, pc, h, lane);
+        tile_sync();
+        if (h == BTile::NP - 1 && pos + 32 < nmax) {  // the registers are free again: the next round
+          BTile::load(pb, bins_w, nrows, a.pitch, pos + 32, lane);
+          CTile::load(pc, ctx_w, nrows, a.pitch, pos + 32, lane);
+        }
+        for (int j = 0; j < 2; j++) {
+          const uint32_t i0 = pos + j * 16;
+          if (i0 >= nmax) break;
+          const uint4 wb = BTile::row_chunk(tile_b, lane, j);
+          const uint4 wc = CTile::row_chunk(tile_c, lane, j);
+          const bool full = i0 + 16 <= nmin;
+          const bool hi = chunk_not_plain<1>(wc, 0u);
+          const uint32_t slot = (c & 1u) * kSlotBytes;
+          const uint32_t rows_at = lane_rows + slot, flags_at = lane_flags + slot;
+          uint32_t f0 = 0, f1 = 0;
+          [[maybe_unused]] uint4 rw;
+          if (ISSCABAC_PAIR_EXP == 2 || (ISSCABAC_PAIR_EXP == 4 && c >= 2)) {
+            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kPlain;
+          } else if (full && !hi) {
+            pair_state_pass<false>(stx, wb, wc, rows_at, two, f0, f1);
+            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kPlain;
+          } else if (full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
+            pair_state_pass<true>(stx, wb, wc, rows_at, two, f0, f1);
+            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kMixed;
+          } else {
+            // bypass bins, fixed-probability bins, ragged ends: every lane classifies its own bin (cabac_kernels.hip: the
+            // general path of k_encode) and leaves a record B's uniform step understands
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+              uint32_t row = kRecNone, fl = 0;
+              if (full || i0 + k < n) {
+                const uint32_t cb = byte_of(wc, k), bin = (word_of(wb, k >> 2) >> (8 * (k & 3))) & 1u;
+                if (is_ctx_byte<1>(cb, 64u)) {
+                  const uint32_t ak = stx.base32() + (((cb & ~3u) << 6) | (cb & 3u));
+                  const uint64_t ent = entry_of(stx.load_at(ak), two);
+                  const uint32_t tk = (uint32_t)(ent >> 32) >> (8u * bin);
+                  stx.store_at(ak, tk);
+                  row = (uint32_t)ent;
+                  fl = tk;
+                } else if (cb == kBypass || cb == kProbBase + 50u) {
+                  row = kRecBypass | bin << 1;
+                } else if (is_prob_ctx_byte<1>(cb) && prob_valid(cb - kProbBase)) {
+                  row = c_prob_rows[prob_row_index(cb - kProbBase)];
+                  fl = bin != (cb - kProbBase > 50u ? 1u : 0u) ? 0x00FF0000u : 0u;
+                }
+              }
+              if (k < 8) f0 |= fl & flag_bit(k);
+              else f1 |= fl & flag_bit(k);
+              set_word(rw, k & 3, row);
+              if ((k & 3) == 3) put_rows(rows_at + (k >> 2) * 1024u, rw);
+            }
+            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kGeneral;
+          }
+          *reinterpret_cast<lds_u64 *>((uintptr_t)flags_at) = (uint64_t)f0 | (uint64_t)f1 << 32;
+          if (ISSCABAC_PAIR_EXP != 3) __syncthreads();  // chunk c is in its slot; B has left slot (c + 1) & 1
+          c++;
+        }
+        tile_sync();
+      }
+    }
+    __syncthreads();  // (B's last chunk)
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------- consumer
+  EncCore e;
+  enc_start(e);
+  SlotSink sink;
+  sink.stage = smem + kStage + lane * 16;
+  sink.slots = a.slots + s0 * a.slot_stride;
+  sink.mine = (uint32_t)(s - s0) * (uint32_t)a.slot_stride;
+  sink.pos = 0;
+  sink.on = valid;
+  __syncthreads();  // chunk 0 is there
+  for (uint32_t c = 0; c < nchunks; c++) {
+    const uint32_t slot = (c & 1u) * kSlotBytes;
+    const uint32_t rows_at = lane_rows + slot, flags_at = lane_flags + slot;
+    const uint32_t kind = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))));
+    const uint64_t fw = *reinterpret_cast<const lds_u64 *>((uintptr_t)flags_at);
+    const uint32_t f0 = (uint32_t)fw, f1 = (uint32_t)(fw >> 32);
+    if (ISSCABAC_PAIR_PRIO_B) __builtin_amdgcn_s_setprio(ISSCABAC_PAIR_PRIO_B);
+    if (ISSCABAC_PAIR_EXP == 1) {
+      e.range += f0 + kind;
+    } else if (kind == kPlain) {
+      EncWordAcc acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint4 rw = get_rows(rows_at + g * 1024u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * g + k;
+          const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(i < 8 ? f0 : f1, 16 + (i & 7), 1);  // ~0: the bin is not its state's mps
+          const uint32_t lps = lps_of(word_of(rw, k), e.range);
+          const uint32_t rmps = e.range - lps;
+          const uint32_t r = select_mask(m, lps, rmps);
+          const uint32_t nn = clz32(r) - 23u;
+          acc.T = ((k == 0 ? 0u : acc.T) + (rmps & m)) << nn;
+          acc.S = (k == 0 ? 0u : acc.S) + nn;
+          e.range = shl16(r, nn);
+        }
+        enc_word_close(e, acc);
+        if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
+      }
+    } else if (kind == kMixed) {
+      // context-coded and bypass bins: one step for both (cabac_lane.h: enc_bin_mixed_acc) -- a bypass bin's record has row 0
+      // and flag 0, so its range passes through untouched (shift 0), bit i of the flag word adds its one bit of shift and
+      // bit 8 + i says whether `low` gains the range (ref: CABAC/CABAC_ArithmeticEncoder.cpp:250-270)
+      EncWordAcc acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint4 rw = get_rows(rows_at + g * 1024u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * g + k;
+          const uint32_t f = i < 8 ? f0 : f1;
+          const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(f, 16 + (i & 7), 1);
+          const uint32_t lps = lps_of(word_of(rw, k), e.range);
+          const uint32_t rmps = e.range - lps;
+          const uint32_t r = select_mask(m, lps, rmps);
+          const uint32_t nn = clz32(r) - 23u;
+          const uint32_t nt = nn + __builtin_amdgcn_ubfe(f, i & 7, 1);
+          acc.T = (((k == 0 ? 0u : acc.T) + (rmps & m)) << nt) + (e.range & (uint32_t)__builtin_amdgcn_sbfe(f, 8 + (i & 7), 1));
+          acc.S = (k == 0 ? 0u : acc.S) + nt;
+          e.range = shl16(r, nn);
+        }
+        enc_word_close(e, acc);
+        if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint4 rw = get_rows(rows_at + g * 1024u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * g + k;
+          const uint32_t row = word_of(rw, k);
+          if (row >= 4u) {  // a context-coded or fixed-probability bin (enc_bin_at_mem / enc_bin_prob: the same arithmetic)
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(i < 8 ? f0 : f1, 16 + (i & 7), 1);
+            const uint32_t lps = lps_of(row, e.range);
+            const uint32_t rmps = e.range - lps;
+            const uint32_t r = select_mask(m, lps, rmps);
+            const uint32_t nn = clz32(r) - 23u;
+            e.low = (e.low + (rmps & m)) << nn;
+            e.range = r << nn;
+            e.W += (int32_t)nn;
+          } else if (row & 1u) {
+            enc_bin_ep(e, row >> 1);
+          }
+        }
+        if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
+      }
+    }
+    if (ISSCABAC_PAIR_PRIO_B) __builtin_amdgcn_s_setprio(0);
+    if (ISSCABAC_PAIR_EXP != 3) __syncthreads();  // slot c & 1 is free again; chunk c + 1 is there
+  }
+  enc_flush16(e, sink);
+  enc_finish16(e, sink);
+  sink.close();
+  if (valid) a.lens[s] = sink.bytes();
+}
+
+bool encode_pair_enabled() { return ISSCABAC_ENC_PAIR != 0; }
+
+hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
+  static int static_lds = -1;  // absolute LDS addresses: the dynamic LDS must start at 0 (cabac_kernels.hip: run_encode)
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    const hipError_t err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode_pair));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
+  const uint64_t nblk = (a.S + 63) / 64;
+  hipLaunchKernelGGL(k_encode_pair, dim3((unsigned)nblk), dim3(128), pairk::kLdsBytes, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace isscabac

@@ -1,0 +1,575 @@
+// cabac_wave.h -- what the batch kernels of the engine share (device only, gfx950): the LDS tables and table layout, the
+// input tiles (64 streams x 64 or 128 bytes per load round through a 2 KiB LDS half tile), the context-state image
+// policy, the byte sink and the kernel argument blocks.  Included by cabac_kernels.hip (the one-wave-per-64-streams
+// kernels) and cabac_pair.hip (the producer / consumer wave pair for small launches).  Not installed.
+#ifndef ISSCABAC_WAVE_H
+#define ISSCABAC_WAVE_H
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "cabac_internal.h"
+#include "cabac_lane.h"
+
+#ifndef ISSCABAC_DEC_SPLIT_TAB
+#define ISSCABAC_DEC_SPLIT_TAB 0
+#endif
+#ifndef ISSCABAC_EXP_NOLOAD  // timing experiments, never in the product build
+#define ISSCABAC_EXP_NOLOAD 0
+#endif
+#ifndef ISSCABAC_EXP_NOPAYLOAD
+#define ISSCABAC_EXP_NOPAYLOAD 0
+#endif
+#ifndef ISSCABAC_DEC_ROLLED  // the four chunks of a load round as a real loop: a quarter of the code
+#define ISSCABAC_DEC_ROLLED 0
+#endif
+#ifndef ISSCABAC_ENC_ROLLED
+#define ISSCABAC_ENC_ROLLED 0
+#endif
+#ifndef ISSCABAC_EXP_INPLACE
+#define ISSCABAC_EXP_INPLACE 0
+#endif
+#ifndef ISSCABAC_EXP_CLK  // stall accounting of the decode kernel into the status words (tools/dec_stalls.py)
+#define ISSCABAC_EXP_CLK 0
+#endif
+
+namespace isscabac {
+
+static __device__ const uint32_t c_lps_rows[64] = {ISSCABAC_LPS_ROWS};
+static __device__ const uint32_t c_prob_rows[49] = {ISSCABAC_PROB_ROWS};  // fixed-probability bins: rare, read from memory
+struct NextTab {
+  uint32_t e[64];
+  uint32_t e16[64];  // two 16-bit entries per dword: packed states 2i, 2i + 1
+  uint32_t eb[64];   // four bytes per dword: (packed state, bin) = (2i, 0), (2i, 1), (2i + 1, 0), (2i + 1, 1)
+  uint32_t ep[64];   // four bytes per dword: (packed state, path) with path 0 = LPS, 1 = MPS: e16 with its bytes swapped
+  constexpr NextTab() : e{}, e16{}, eb{}, ep{} {
+    constexpr uint8_t trans[64] = {ISSCABAC_TRANS_LPS};
+    for (uint32_t s = 0; s < 64; s++) {
+      e[s] = next_state_entry(s, trans[s]);
+      e16[s] = next_state_entry16(2 * s, trans[s]) | next_state_entry16(2 * s + 1, trans[s]) << 16;
+      ep[s] = ((e16[s] & 0x00FF00FFu) << 8) | ((e16[s] >> 8) & 0x00FF00FFu);
+      eb[s] = next_state_by_bin(2 * s, 0, trans[s]) | next_state_by_bin(2 * s, 1, trans[s]) << 8 |
+              next_state_by_bin(2 * s + 1, 0, trans[s]) << 16 | next_state_by_bin(2 * s + 1, 1, trans[s]) << 24;
+    }
+  }
+};
+static __device__ const NextTab c_next{};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // what the nontemporal builtins accept
+__device__ __forceinline__ uint4 nt_load16(const uint8_t *p) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) {  // (through the plain vector type: HIP's uint4 keeps the tile arrays in scratch here)
+  const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store16(uint8_t *p, uint4 v) {
+  u32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
+}
+
+// ctx bytes that the plain 16-bin path cannot take: bypass (0xFF), contexts >= 128 and, with the 4 KiB state image of
+// <= 64 contexts, anything >= 64 -- an out-of-range context index must not reach another stream's LDS.  Such chunks take
+// the general path, which looks at every byte and ignores an invalid one (that stream's result is unspecified, its
+// neighbours' are not affected).
+template <int CM>
+constexpr uint32_t not_plain_mask() { return CM == 1 ? 0xC0C0C0C0u : 0x80808080u; }
+// CM 2 (> 128 contexts): the state image is as large as the batch's context count asks for (a multiple of four contexts),
+// `lim` = min(contexts of the image, 255): bytes from lim on are bypass bins (0xFF) or invalid (skipped, like everywhere)
+template <int CM>
+__device__ __forceinline__ bool is_ctx_byte(uint32_t c, uint32_t lim) { return CM == 1 ? c < 64u : CM == 3 ? c < 128u : c < lim; }
+template <int CM>
+__device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 && is_prob_byte(c); }
+
+// waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
+// let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
+#ifndef ISSCABAC_ENC_WPB
+#define ISSCABAC_ENC_WPB 4
+#endif
+#ifndef ISSCABAC_DEC_WPB
+#define ISSCABAC_DEC_WPB 4
+#endif
+// Issue priority of a wave while it codes a chunk's bins (s_setprio; 0 elsewhere: tile moves, loads, stores, window
+// boundaries).  A SIMD's four waves are in different phases; preferring the ones inside the serial bin arithmetic over the
+// ones that are about to wait for memory anyway measured, medians of six alternating runs on one box: k_encode 2.925 ->
+// 2.894 ms, k_decode 2.827 -> 2.798 ms, round trip 713 -> 722 Gbin/s (levels 1, 2 and 3 alike).
+#ifndef ISSCABAC_DEC_PRIO
+#define ISSCABAC_DEC_PRIO 1
+#endif
+#ifndef ISSCABAC_ENC_PRIO
+#define ISSCABAC_ENC_PRIO 1
+#endif
+#ifndef ISSCABAC_DEC_LAT_BARRIER
+#define ISSCABAC_DEC_LAT_BARRIER 1  // scheduling barriers around the latency-oriented decoder's per-bin tail
+#endif
+// waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
+constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
+constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
+#ifndef ISSCABAC_ENC_BINADDR
+#define ISSCABAC_ENC_BINADDR 0  // the plain step's table lookup by (state, bin): see LdsStates::entry_bin
+#endif
+constexpr int kTabBin8Off = 1792;  // [1792,3840) with ISSCABAC_ENC_BINADDR: 256 entries of 8 bytes by (q | bin)
+constexpr int kTabBytes = ISSCABAC_ENC_BINADDR ? 3840 : 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
+                                 // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
+                                 // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
+                                 // by packed state, the state's row and its two successors (by bin / by path)
+constexpr int kTabBinOff = 256, kTabPathOff = 512, kTabRowOff = 768;
+
+// ------------------------------------------------------------------------------------------------
+// small wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+  // all lanes of a wave run in lockstep; this only stops the compiler from moving LDS accesses of
+  // different lanes past each other and drains lgkmcnt
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+// some byte of the chunk's 16 ctx bytes names no context of the image (wave-uniform answer).  CM 2: byte >= lim, lim in
+// 129..255, as a carry into bit 7 of the low seven bits (kadd = (256 - lim) in every byte, no carry between bytes)
+template <int CM>
+__device__ __forceinline__ bool chunk_not_plain(const uint4 &wc, uint32_t kadd) {
+  if (CM != 2) return wave_any(((wc.x | wc.y | wc.z | wc.w) & not_plain_mask<CM>()) != 0);
+  auto f = [&](uint32_t x) { return ((x & 0x7F7F7F7Fu) + kadd) & x; };
+  return wave_any(((f(wc.x) | f(wc.y) | f(wc.z) | f(wc.w)) & 0x80808080u) != 0);
+}
+// fixed-probability bins exist in batches of at most 128 contexts (with more, bytes 129..254 are context indices)
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 64 streams x 64 bytes per load round, 32 bytes per stream resident in LDS at a time
+// ------------------------------------------------------------------------------------------------
+// A wave fetches 64 contiguous bytes of each of its 64 streams per round (4 lanes x 16 B cover one stream:
+// every HBM request is a full 64-byte segment -- 32-byte segments were measured to double FETCH_SIZE), keeps
+// them in registers, and moves one 32-byte half at a time through LDS, where lane r reads its own stream's
+// row back with ds_read_b128.  Halving the LDS residency is what lets 4 workgroups share a CU.
+// LPR = lanes per row and load instruction: 4 -> 64-byte row segments, a load round is 64 bytes per stream in 4
+// instructions per array (16 registers); 8 -> 128-byte segments, 128 bytes per stream in 8 instructions (32 registers).
+// Whole 128-byte lines per request are what the memory system likes (tools/ubench/store_seg.hip: two arrays read this
+// way, 1.30 ms against 2.54 ms with 64-byte segments at the coder kernels' occupancy), registers permitting.
+template <int LPR>
+struct TileT {
+  static constexpr int T = 16 * LPR;  // bytes per stream per load round
+  static constexpr int H = 32;        // bytes per stream resident in LDS
+  static constexpr int NLD = LPR;     // wave-wide load instructions per round (64 / LPR streams each)
+  static constexpr int NP = T / H;    // 32-byte parts per round
+  // LDS image: row r = 32 bytes = two 16-byte chunks; chunk c sits in slot c ^ ((r >> 3) & 1), which makes
+  // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * (64 / LPR) + lane / LPR; }
+  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % LPR; }
+
+  // rows = this wave's first row in the [S][pitch] array (wave-uniform pointer), nrows = how many of the wave's 64 rows
+  // exist (wave-uniform); the per-lane part of the address is a 32-bit offset (pitch <= 2^25, checked by the C ABI), so
+  // the row addresses cost one VGPR each instead of hoisted 64-bit pointers
+  // NT: non-temporal (streaming) loads -- the decode kernel's ctx stream then stops evicting the payload lines its
+  // lanes come back to (FETCH_SIZE 11.2 -> 8.9 GB per launch, 2% faster); in the encode kernel they only cost time
+  // A piece that would start past the row's end (off + 16 * piece >= pitch: the last round of a row whose pitch is no
+  // multiple of T) is clamped to the row's last 16 bytes instead of predicated away: no lane reads what it gets -- those
+  // bins lie past every stream's end -- and the loads stay unconditional (a predicate costs a zero fill of the registers,
+  // exec-mask code around every instruction and, in front of the fill, a wait for everything in flight)
+  template <bool NT = false>
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch,
+                                              uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint32_t row = min(row_of(k, lane), nrows - 1u);
+      const uint32_t voff = row * pitch + boff;
+      r[k] = NT ? nt_load16(rows + voff) : ld16(rows + voff);
+    }
+  }
+  // The same for a wave whose 64 streams are NOT neighbours in the array (length-bucketed launches, cabac_order.hip):
+  // rid[k] = stream id of the row this lane fetches a piece of with load k; one 64-bit multiply-add per load
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows(uint4 (&r)[NLD], const uint8_t *base, const uint32_t (&rid)[NLD], uint32_t pitch,
+                                                   uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint8_t *p = base + ((uint64_t)rid[k] * pitch + boff);
+      r[k] = NT ? nt_load16(p) : ld16(p);
+    }
+  }
+  // ... with the ids read from LDS (ids[row]) when the loads are issued instead of kept in NLD registers
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows_ids(uint4 (&r)[NLD], const uint8_t *base, const uint32_t *ids, uint32_t pitch,
+                                                       uint32_t off, int lane) {
+    const uint32_t boff = min(off + ch_of(lane) * 16, pitch - 16u);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint8_t *p = base + ((uint64_t)ids[row_of(k, lane)] * pitch + boff);
+      r[k] = NT ? nt_load16(p) : ld16(p);
+    }
+  }
+  // part h (bytes 32 h .. 32 h + 31 of the round) of the registers -> LDS
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
+    if ((int)(ch_of(lane) >> 1) == h) {
+#pragma unroll
+      for (int k = 0; k < NLD; k++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane) & 1)) = r[k];
+    }
+  }
+  __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
+    return *reinterpret_cast<const uint4 *>(tile + lds_off(lane, j));
+  }
+  __device__ static __forceinline__ void put_row_chunk(uint8_t *tile, int lane, int j, uint4 v) {
+    *reinterpret_cast<uint4 *>(tile + lds_off(lane, j)) = v;
+  }
+};
+// The same round with the lanes paired differently: lanes 2 r and 2 r + 1 fetch 32 contiguous bytes of row r (+ 32 for odd k),
+// instruction k covers 32 rows x 32 bytes, and the instructions k = 2 h and 2 h + 1 together hold exactly part h of all 64 rows
+// -- so a part goes to LDS in TWO ds_write_b128 with every lane active, where TileT<4> needs four with half of the lanes and
+// TileT<8> eight with a quarter of them (a wave-wide LDS store costs its 13 transfer cycles whatever the number of lanes).
+// The instructions k and k + 2 ask for the two (T = 64) or more pieces of the same lines back to back.
+template <int LPR>
+struct TilePairT {
+  static constexpr int T = 16 * LPR, H = 32, NLD = LPR, NP = T / H;
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return (uint32_t)(lane >> 1) + 32u * (uint32_t)(k & 1); }
+  __device__ static __forceinline__ uint32_t ch_of(int k, int lane) { return 2u * (uint32_t)(k >> 1) + (uint32_t)(lane & 1); }
+  template <bool NT = false>
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch, uint32_t off,
+                                              int lane) {
+    const uint32_t ro0 = min(row_of(0, lane), nrows - 1u) * pitch, ro1 = min(row_of(1, lane), nrows - 1u) * pitch;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const uint32_t voff = ((k & 1) ? ro1 : ro0) + min(off + ch_of(k, lane) * 16, pitch - 16u);  // (clamped like TileT::load)
+      r[k] = NT ? nt_load16(rows + voff) : ld16(rows + voff);
+    }
+  }
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(kk, lane), lane & 1)) = r[2 * h + kk];
+  }
+  __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
+    return *reinterpret_cast<const uint4 *>(tile + lds_off(lane, j));
+  }
+  // (the length-bucketed instances keep TileT -- their rows are not neighbours --; these two only let `if (PERM)` compile)
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows(uint4 (&)[NLD], const uint8_t *, const uint32_t (&)[NLD], uint32_t, uint32_t, int) {}
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows_ids(uint4 (&)[NLD], const uint8_t *, const uint32_t *, uint32_t, uint32_t, int) {}
+};
+typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
+// the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
+// both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
+#ifndef ISSCABAC_ENC_LPR_B
+#define ISSCABAC_ENC_LPR_B 4
+#endif
+#ifndef ISSCABAC_ENC_LPR_C
+#define ISSCABAC_ENC_LPR_C 4
+#endif
+#ifndef ISSCABAC_ENC_NT
+#define ISSCABAC_ENC_NT 0
+#endif
+#ifndef ISSCABAC_ENC_DEPTH2
+#define ISSCABAC_ENC_DEPTH2 0
+#endif
+#ifndef ISSCABAC_ENC_SPLIT_FETCH
+#define ISSCABAC_ENC_SPLIT_FETCH 0  // experiment: the ctx array's loads one chunk later than the bins array's (two bursts of four instead of one of eight)
+#endif
+constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
+                                                // half of every 128-byte line is an L2 hit one round later only if the first allocated it
+#ifndef ISSCABAC_ENC_TILE_PAIR
+#define ISSCABAC_ENC_TILE_PAIR 0
+#endif
+template <bool PERM>
+using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+template <bool PERM>
+using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type;
+
+// The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
+// are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
+// leave as full 128-byte row segments (64-byte segments, one per load round, were measured at 3.1 TB/s against 4.7 for
+// load + store: tools/ubench/tile_bw.hip, store_seg.hip -- the kernel was store-bound with them).  Dword (c, row) of the
+// eight chunks c sits at c * 64 + (row ^ 8 c): a lane writes its own row (all banks distinct), and the store pass
+// reads (8 rows) x (8 chunks) per instruction, again all banks distinct.
+struct OutBuf {
+  static constexpr uint32_t BYTES = 8 * 64 * 4;
+  __device__ static __forceinline__ uint32_t idx(uint32_t c, uint32_t row) { return c * 64 + (row ^ (c * 8)); }
+  __device__ static __forceinline__ uint32_t pack(const uint4 &v) {
+    const uint32_t M = 0x01010101u;
+    uint32_t d = v.x & M;
+    d |= (v.y & M) << 1;
+    d |= (v.z & M) << 2;
+    d |= (v.w & M) << 3;
+    return d;
+  }
+  __device__ static __forceinline__ uint4 unpack(uint32_t d) {
+    const uint32_t M = 0x01010101u;
+    return make_uint4(d & M, (d >> 1) & M, (d >> 2) & M, (d >> 3) & M);
+  }
+};
+
+__device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ void set_word(uint4 &v, int i, uint32_t w) {
+  if (i == 0) v.x = w;
+  else if (i == 1) v.y = w;
+  else if (i == 2) v.z = w;
+  else v.w = w;
+}
+__device__ __forceinline__ uint32_t byte_of(const uint4 &v, int k) { return (word_of(v, k >> 2) >> (8 * (k & 3))) & 0xFFu; }
+// a word whose bit 1 is bin k of the chunk (bins are bytes 0/1): what enc_bin's b1 wants, one shift
+__device__ __forceinline__ uint32_t bin_at_bit1(const uint4 &v, int k) {
+  const uint32_t w = word_of(v, k >> 2);
+  return (k & 3) == 0 ? (w << 1) : (w >> (8 * (k & 3) - 1));
+}
+
+// Bin policy of the encode kernel (cabac_lane.h: enc_bin_at): the four bins of one input word, pre-shifted so that bin k
+// sits at bit 1 of byte k; xor with the state picks the byte in the same instruction (SDWA operand select)
+template <int K>
+struct BinOfWord {
+  uint32_t w2;  // input word << 1
+  uint32_t w;   // input word
+  uint32_t w8;  // input word << 3: byte k = 8 * bin k, what next_of shifts by (only the single-lookup step reads it)
+  // the successor for bin K out of the entry's high word (byte 0: bin 0, byte 1: bin 1); the store takes the low byte
+  __device__ __forceinline__ uint32_t next_of(uint32_t hi) const {
+    uint32_t r;
+    if (K == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else if (K == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else if (K == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(w8), "v"(hi));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t or_q(uint32_t q) const {
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w));
+    else if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(q), "v"(w));
+    else if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(q), "v"(w));
+    else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)__builtin_amdgcn_sbfe(t, 16, 1); }
+  // x | byte K of y, x + byte K of y, x * byte K of y (x below 2^24): one SDWA instruction each -- per-bin fields of a per-word
+  // SWAR word without an extraction of their own
+  __device__ __forceinline__ uint32_t or_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t add_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t mul_byte(uint32_t x, uint32_t y) const {
+    uint32_t r;
+    if (K == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(y));
+    else if (K == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ uint32_t lps_mask_sext(uint32_t t) const {  // the shifted entry's flag byte (0x00 / 0xFF) as a 32-bit mask
+    uint32_t m;
+    asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
+    return m;
+  }
+  __device__ __forceinline__ uint32_t xor_q(uint32_t q) const {
+    uint32_t r;
+    if (K == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(q), "v"(w2));
+    else if (K == 1) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(q), "v"(w2));
+    else if (K == 2) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(q), "v"(w2));
+    else asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(q), "v"(w2));
+    return r;
+  }
+};
+
+// enc_pick (cabac_lane.h) for the kernel's bins: t = the entry's high word shifted by the bin, its byte 2 the flag "the bin
+// is not the state's mps" (enc_entry_hi) -- one SDWA compare into VCC, two selects
+#ifndef ISSCABAC_ENC_PICK_VCC
+#define ISSCABAC_ENC_PICK_VCC 2  // 2: the mask form below (same-box A/B, medians of 6: k_encode 2.870 -> 2.847 ms); 1: compare + two selects
+#endif
+#if ISSCABAC_ENC_PICK_VCC == 2
+// the flag byte is 0x00 / 0xFF: sign-extended by the operand select it IS the mask -- one SDWA move, a bit select and a
+// full-rate and (4 + 4 + 2 issue cycles against 4 + 4 + 4 for compare + two selects; the and runs at twice the rate of
+// a select on gfx950: tools/ubench/valu_ops)
+template <int K>
+__device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  uint32_t m;
+  asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
+  r = select_mask(m, lps, rmps);
+  a = rmps & m;
+}
+#elif ISSCABAC_ENC_PICK_VCC
+template <int K>
+__device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
+  asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
+      "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
+      "v_cndmask_b32_e32 %1, 0, %4, vcc"
+      : "=&v"(r), "=&v"(a)
+      : "v"(t), "v"(lps), "v"(rmps), "s"(0u)
+      : "vcc");
+}
+#endif
+
+// f(BinOfWord<k & 3>{w2, w1}) for a loop counter k that is a constant once the loop is unrolled
+template <class F>
+__device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1, F &&f) {
+  switch (k & 3) {
+    case 0: return f(BinOfWord<0>{w2, w1, w1 << 3});
+    case 1: return f(BinOfWord<1>{w2, w1, w1 << 3});
+    case 2: return f(BinOfWord<2>{w2, w1, w1 << 3});
+    default: return f(BinOfWord<3>{w2, w1, w1 << 3});
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// context-state policies (see cabac_lane.h: States)
+// ------------------------------------------------------------------------------------------------
+// One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
+// pick, lane l only ever touches bank l % 32.  The tables are byte tables in LDS, read by absolute LDS address.
+struct LdsStates {
+  uint8_t *base;  // wave's state region + lane * 4
+  __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
+  // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
+  __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
+  // address = lane base + 16-bit field of the quad, in ONE instruction (SDWA word select) and as a 32-bit LDS address
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+  __device__ __forceinline__ lds_u8 *addr_of(const CtxQuad &z, int k) const {
+    const uint32_t b32 = (uint32_t)(uintptr_t)(lds_u8 *)base, zz = k < 2 ? z.z01 : z.z23;
+    uint32_t a;
+    if ((k & 1) == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"(b32), "v"(zz));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a) : "v"(b32), "v"(zz));
+    return (lds_u8 *)(uintptr_t)a;
+  }
+  __device__ __forceinline__ uint32_t load_at(const lds_u8 *a) const { return *a; }
+  __device__ __forceinline__ void store_at(lds_u8 *a, uint32_t p) const { *a = (uint8_t)p; }
+  __device__ __forceinline__ uint32_t load_at(const uint8_t *a) const { return *a; }
+  __device__ __forceinline__ void store_at(uint8_t *a, uint32_t p) const { *a = (uint8_t)p; }
+  __device__ __forceinline__ uint32_t load(uint32_t c) const { return *addr(c); }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
+  // (LDS addresses as integers: the kernels' dynamic LDS starts at 0 -- they have no static __shared__, which the engine
+  // checks at start-up -- so a table's offset folds into the instruction and q itself is the address)
+  // the rangeTabLps rows at LDS 0 are a [state][column] byte table
+  __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
+  }
+  // successor bytes by [packed state][path], path 0 = LPS, 1 = MPS
+  __device__ __forceinline__ uint32_t path_index(uint32_t q) const { return kTabPathOff + q; }  // = the LDS address
+  __device__ __forceinline__ uint32_t next_path_mem(uint32_t addr) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)addr);
+  }
+  __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
+  }
+  // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
+  // (the address as a 16-bit shift: full rate, cabac_lane.h: shl16; a 24-bit multiply is half rate like the 32-bit shift)
+  __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + shl16c<2>(q)));
+  }
+  // the plain step's entry by (state, bin): e = q | bin -> 8 bytes at kTabBin8Off + 8 e: the state's rangeTabLps row, the
+  // successor for this bin (byte 4, what the state store takes) and the flag "the bin is not the mps" as 0x00 / 0xFF in
+  // byte 5 -- read a second time SIGN-EXTENDED (ds_read_i8), which makes it the select mask without a VALU instruction
+  __device__ __forceinline__ uint64_t entry_bin(uint32_t e, uint32_t &m) const {
+    const uint32_t a = shl16c<3>(e);
+    m = (uint32_t)(int32_t)*reinterpret_cast<const __attribute__((address_space(3))) int8_t *>((uintptr_t)(kTabBin8Off + 5 + a));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabBin8Off + a));
+  }
+  // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
+  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
+#if ISSCABAC_DEC_SPLIT_TAB
+    // two conflict-free reads -- either table is 256 bytes = one LDS bank row -- instead of one 8-byte read from 2 KiB:
+    // the rangeTabLps row by state at (qb & 0xFC), the successor pair by packed state at 256 + (qb & 0xFE)
+    const uint32_t row = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(qb & 0xFCu));
+    const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
+    return (uint64_t)row | (uint64_t)sp << 32;
+#else
+
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3));
+#endif
+  }
+  // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
+  __device__ __forceinline__ void store_at_hi(uint32_t a, uint32_t p) const {
+    asm volatile("ds_write_b8_d16_hi %0, %1" : : "v"(a), "v"(p) : "memory");
+  }
+  // state addresses as plain 32-bit LDS addresses (the latency-oriented paths compare them)
+  __device__ __forceinline__ uint32_t base32() const { return (uint32_t)(uintptr_t)(lds_u8 *)base; }
+  __device__ __forceinline__ uint32_t addr32_of(const CtxQuad &z, int k) const { return (uint32_t)(uintptr_t)addr_of(z, k); }
+  __device__ __forceinline__ uint32_t load_at(uint32_t a) const { return *(const lds_u8 *)(uintptr_t)a; }
+  __device__ __forceinline__ void store_at(uint32_t a, uint32_t p) const { *(lds_u8 *)(uintptr_t)a = (uint8_t)p; }
+};
+// ------------------------------------------------------------------------------------------------
+// byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
+// (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
+// ------------------------------------------------------------------------------------------------
+#ifndef ISSCABAC_ENC_NOSTORE  // timing experiment only
+#define ISSCABAC_ENC_NOSTORE 0
+#endif
+struct SlotSink {
+  uint8_t *stage;   // LDS, this lane's 16 bytes
+  uint8_t *slots;   // HBM, the wave's first slot (wave-uniform, 16-byte aligned)
+  uint32_t mine;    // byte offset of this stream's slot from there (64 slots stay far below 4 GiB)
+  uint32_t pos;
+  bool on;
+  __device__ __forceinline__ void put(uint32_t b) {
+    stage[pos & 15u] = (uint8_t)b;
+    pos++;
+    if ((pos & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage);
+      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+    }
+  }
+  // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
+  __device__ __forceinline__ void put16(uint32_t x) {
+    *reinterpret_cast<uint16_t *>(stage + (pos & 15u)) = (uint16_t)__builtin_amdgcn_perm(x, x, 0x0C0C0001u);  // low 16 bits, byte-swapped
+    pos += 2;
+    if ((pos & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage);
+      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+    }
+  }
+  __device__ __forceinline__ uint32_t bytes() const { return pos; }
+  __device__ __forceinline__ void close() {
+    if (on && (pos & 15u)) *reinterpret_cast<uint4 *>(slots + (mine + (pos & ~15u))) = *reinterpret_cast<const uint4 *>(stage);
+  }
+};
+
+struct EncArgs {
+  const uint8_t *bins, *ctx;
+  const uint32_t *nbins_per_stream;
+  const uint32_t *order;  // length-bucketed launch: lane l of wave w codes stream order[64 w + l] (else null)
+  uint8_t *slots;
+  uint32_t *lens;
+  uint64_t S, slot_stride;
+  uint32_t nbins, pitch, nctx;
+  uint32_t img_bytes;  // CM 2: bytes of a wave's state image, 256 per four contexts
+  uint32_t ctx_init[64];
+};
+
+// the digit flush of the encode kernels: digits leave `low` when some lane could overflow it within the next four bins
+#ifndef ISSCABAC_FLUSH_AT
+#define ISSCABAC_FLUSH_AT 39  // four more bins add at most 22 (context) bits: W stays <= 62
+#endif
+#ifndef ISSCABAC_FLUSH_FN
+#define ISSCABAC_FLUSH_FN enc_flush16_wave  // or enc_flush16: the general loop only
+#endif
+
+// cabac_pair.hip: the encode kernel of small launches (<= 64 contexts, no length bucketing)
+bool encode_pair_enabled();
+hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream);
+
+}  // namespace isscabac
+#endif

@@ -11,6 +11,11 @@ workload = "config3"
 if "--workload" in sys.argv:
     workload = sys.argv[sys.argv.index("--workload") + 1]
     sys.argv.remove("--workload"); sys.argv.remove(workload)
+extra = []
+if "--" in sys.argv:  # everything behind `--` goes to bench.py (e.g. -- --streams 65536 --tuning latency)
+    i = sys.argv.index("--")
+    extra = sys.argv[i + 1:]
+    del sys.argv[i:]
 libs = [a for a in sys.argv[1:] if not a.startswith("--")]
 rounds = 3
 if "--rounds" in sys.argv:
@@ -20,7 +25,7 @@ res = {l: {"encode": [], "decode": [], "gather": [], "value": []} for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, ISSCABAC_LIB=os.path.abspath(l), ISSCABAC_BENCH_FULL_CAP="1")
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--no-verify", "--workload", workload],
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--no-verify", "--workload", workload] + extra,
                              env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
