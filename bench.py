@@ -11,7 +11,10 @@ latency; sizes, the capacity check and the kernel times are read after the closi
 Workloads are BASELINE.json's configurations, named by their GLOBAL shape:
     config3   1 Mi streams x 4 Ki bins, 64 contexts                        (the shape `metric` is quoted on; default)
     config5   8 Mi streams x 8 Ki bins, 64 contexts, 50 % bypass bins      (one GPU runs it 1 Mi streams at a time)
-    config2   64 Ki streams x 1 Ki bins, 3 contexts
+    config2   64 Ki streams x 1 Ki bins, 3 contexts, ENCODE-ONLY as BASELINE.json names it (a step = encode kernel +
+              offsets scan + payload gather; --round-trip times encode + decode like the others).  Every line also
+              carries encode_Gbin_s (kernel + scan + gather) and decode_Gbin_s from the engine's HIP events (SURVEY 8(d):
+              "report encode-only and decode-only too").
 Streams are independent, so N ranks split the stream range and nothing is exchanged while coding:
     --scaling strong   the global shape is fixed, rank r codes sharding.shard_range(S, r, N) -- the mode under which the
                        metric's "1M streams x 4K bins" stays true for every N, and the north star's efficiency figure;
@@ -176,6 +179,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency"),
                     help="kernel instance (isscabac_set_tuning); auto picks by launch size")
+    ap.add_argument("--round-trip", action="store_true", help="config2: time encode + decode instead of its encode-only step")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final bitstream gather (N > 1)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -216,6 +220,7 @@ def main():
     if args.streams:
         wl["S"] = wl["per_gpu"] = args.streams
     B, C, seed, ep = wl["B"], wl["C"], wl["seed"], wl["ep"]
+    encode_only = args.workload == "config2" and not args.round_trip  # BASELINE.json: "64K streams x 1K bins, 3 contexts, encode-only"
     chunks = sharding.plan(wl["S"], wl["per_gpu"], rank, world, args.scaling, args.chunk_streams)
     job_streams = sharding.job_streams(wl["S"], wl["per_gpu"], world, args.scaling)
     my_streams = sum(hi - lo for lo, hi in chunks)
@@ -249,8 +254,12 @@ def main():
         for b in bufs:
             eng.encode_dev_async(b["bins"].data_ptr(), b["ctx"].data_ptr(), b["S"], B, B, init, b["payload"].data_ptr(),
                                  b["cap"], b["offsets"].data_ptr())
-            eng.decode_dev_async(b["payload"].data_ptr(), b["cap"], b["offsets"].data_ptr(), b["ctx"].data_ptr(), b["S"], B,
-                                 B, init, b["out"].data_ptr(), b["status"].data_ptr())
+            if not encode_only:
+                decode(b)
+
+    def decode(b):
+        eng.decode_dev_async(b["payload"].data_ptr(), b["cap"], b["offsets"].data_ptr(), b["ctx"].data_ptr(), b["S"], B, B, init,
+                             b["out"].data_ptr(), b["status"].data_ptr())
 
     def fence():
         if multi:
@@ -274,14 +283,22 @@ def main():
     ksamples = eng.kernel_ms_samples()  # every launch of the timed steps (the same events the means below come from)
     kdropped = eng.kernel_ms_samples_dropped()  # non-zero: more launches than the engine keeps -- the series is truncated
     kms, klaunches = eng.kernel_ms_mean()  # HIP events on the launch stream around every kernel of the timed steps
-    assert klaunches["encode"] == args.steps * len(bufs) and klaunches["decode"] == args.steps * len(bufs)
+    assert klaunches["encode"] == args.steps * len(bufs) and klaunches["decode"] == (0 if encode_only else args.steps * len(bufs))
+    if encode_only:  # the decode rate and the gate below still need the way back: one pass, outside the timed region
+        for b in bufs:
+            decode(b)
+        fence()
+        eng.sync()
+        kms_d, _ = eng.kernel_ms_mean()
+        kms["decode"] = kms_d["decode"]
     # kernel time of every step (all launches of the step, all four kernels): min / median beside the mean, so that two
     # builds can be compared from one run each (box-to-box spread is +- 3 %, within a run the steps agree to ~0.5 %)
     nl = len(bufs)
     step_ms = []
-    if all(len(ksamples[k]) == args.steps * nl for k in ("encode", "scan", "gather", "decode")):
+    step_kernels = ("encode", "scan", "gather") if encode_only else ("encode", "scan", "gather", "decode")
+    if all(len(ksamples[k]) == args.steps * nl for k in step_kernels):
         for i in range(args.steps):
-            step_ms.append(sum(sum(ksamples[k][i * nl:(i + 1) * nl]) for k in ("encode", "scan", "gather", "decode")))
+            step_ms.append(sum(sum(ksamples[k][i * nl:(i + 1) * nl]) for k in step_kernels))
     totals = [int(b["offsets"][-1]) for b in bufs]
     for b, tot in zip(bufs, totals):
         assert tot <= b["cap"], "payload buffer too small"
@@ -343,7 +360,7 @@ def main():
         enc_ms, dec_ms = kms["encode"], kms["decode"]
         enc_bytes = 2.0 * S_l * B + P_l + 8.0 * S_l
         dec_bytes = 2.0 * S_l * B + P_l + 8.0 * S_l
-        if enc_ms >= dec_ms:
+        if enc_ms >= dec_ms or encode_only:
             kname, kbytes, kms_avg = "k_encode", enc_bytes, enc_ms
         else:
             kname, kbytes, kms_avg = "k_decode", dec_bytes, dec_ms
@@ -361,7 +378,7 @@ def main():
         if args.workload == "config3" and job_streams == 1 << 20:
             metric = BASELINE_METRIC
         else:
-            metric = "Gbin/s encode+decode round-trip, %s; bit-exact vs HM CPU" % shape
+            metric = "Gbin/s %s, %s; bit-exact vs HM CPU" % ("encode-only" if encode_only else "encode+decode round-trip", shape)
         line = {
             "metric": metric,
             "value": value,
@@ -383,6 +400,10 @@ def main():
                        "bins_per_stream": B, "contexts": C, "payload_bytes_per_gpu": int(sum(totals)),
                        "bits_per_bin": 8.0 * sum(totals) / (float(my_streams) * B)},
             "verified_bit_exact": verified,
+            # one launch's bins over its kernel time (HIP events): encode = kernel + offsets scan + payload gather
+            "encode_Gbin_s": S_l * B / ((kms["encode"] + kms["scan"] + kms["gather"]) * 1e-3) / 1e9,
+            "decode_Gbin_s": S_l * B / (kms["decode"] * 1e-3) / 1e9 if kms.get("decode") else None,
+            "step": "encode (kernel + scan + gather)" if encode_only else "encode (kernel + scan + gather) + decode",
             "kernels_ms": kms,
             "kernels_ms_min": {k: (min(v) if v else None) for k, v in ksamples.items()},
             "kernels_ms_median": {k: (sorted(v)[len(v) // 2] if v else None) for k, v in ksamples.items()},

@@ -17,6 +17,10 @@
 #include "../../include/isscabac.h"
 #include "cabac_internal.h"
 
+#ifndef ISSCABAC_DEC_PAIR_WAVES_PER_CU
+#define ISSCABAC_DEC_PAIR_WAVES_PER_CU 2  // launches of at most this many waves of streams per CU decode on the wave pair
+#endif
+
 using namespace isscabac;
 
 static thread_local std::string g_create_err;
@@ -179,6 +183,9 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   // whatever the batch's size, the latency instance's regime: 190 contexts 514 -> 542 Gbin/s, 253 contexts 434 -> 483.
   sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY ||
                 (e->tuning == ISSCABAC_TUNE_AUTO && (nctx > 128 || S <= 2ull * (uint64_t)e->num_cus * 4 * 64));
+  // The decoder's helper wave (cabac_pair.hip: k_decode_pair) takes a fifth of the instructions off the decoding wave but not
+  // its chain: same-box sweep 16 Ki streams 0.358 -> 0.306 ms, 64 Ki 0.364 -> 0.363, 128 Ki 0.460 -> 0.486 (profiles/r05)
+  sh->tiny = S <= (uint64_t)e->num_cus * ISSCABAC_DEC_PAIR_WAVES_PER_CU * 64;
   for (int c = 0; c < nctx; c++) {
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     sh->ctx_init[c] = ctx_init[c];

@@ -411,4 +411,346 @@ hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+
+// ================================================================================================
+// The decode kernel for small launches: a decoder wave and a HELPER wave per 64 streams.
+//
+// The decoder's per-bin chain cannot be split -- the state of bin k + 1 follows from the decision of bin k (ref:
+// CABAC/CABAC_ArithmeticDecoder.cpp:87-190) -- but a third of the single wave's instructions are not on it: the ctx tile
+// (global loads, the transposition through LDS), the state addresses of the chunk's 16 bins, the chunk classification, and
+// the output path (unpacking 128 bins of 64 rows and storing them as full 128-byte row segments).  At one or two waves per
+// SIMD a wave issues one instruction per ~2.2 ns whatever its neighbour does, so every instruction the decoding wave does
+// not have to issue is time.  Wave A (helper) prepares, per chunk, the 16 state addresses of every lane (16-bit LDS
+// addresses, two to a dword), the ctx bytes and the chunk's kind in a ring slot, and later stores the bins wave B has
+// left in the (double-buffered) output staging; wave B (decoder) runs k_decode's latency-oriented step on them.  One
+// s_barrier per chunk, as in k_encode_pair.  Bins and status words are identical to k_decode's for every input.
+//
+// LDS of a workgroup (18 448 bytes): [0, 2048) the raw-byte entries | 4 KiB context states | 2 KiB ctx half tile (A) |
+// 2 x 2 KiB output staging (OutBuf) | 2 slots x 3 KiB: addresses of bins 0..7, of bins 8..15, the 16 ctx bytes | kinds
+// ================================================================================================
+#ifndef ISSCABAC_DEC_PAIR
+#define ISSCABAC_DEC_PAIR 1
+#endif
+
+namespace dpair {
+constexpr uint32_t kStates = 2048;
+constexpr uint32_t kTile = kStates + 4096;
+constexpr uint32_t kObuf = kTile + 2048;
+constexpr uint32_t kRing = kObuf + 2 * OutBuf::BYTES;
+constexpr uint32_t kSlotBytes = 3072;
+constexpr uint32_t kKind = kRing + 2 * kSlotBytes;
+constexpr uint32_t kLdsBytes = kKind + 16;
+static_assert(8 * kLdsBytes <= 160 * 1024, "eight workgroups per CU");
+constexpr uint32_t kPlain = 0, kMixed = 1, kGeneral = 2;
+}  // namespace dpair
+
+__global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
+  using namespace dpair;
+  using pairk::lds_u32;
+  using pairk::get_rows;
+  using pairk::put_rows;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0: helper (A), 1: decoder (B)
+  {
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    for (int qb = tid; qb < 256; qb += 128) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin (k_decode)
+      const uint32_t ps = (uint32_t)qb >> 1;
+      const uint32_t sp = c_next.ep[ps >> 1] >> (16 * (ps & 1));
+      tab[2 * qb] = c_lps_rows[ps >> 1];
+      tab[2 * qb + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
+    }
+  }
+  __syncthreads();
+  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+  if (s0 >= a.S) return;
+  const bool valid = s0 + lane < a.S;
+  const uint64_t s = valid ? s0 + lane : a.S - 1;
+  uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
+  n = min(n, a.nbins);
+  const uint32_t nmin = __builtin_amdgcn_readfirstlane(wave_min_u32(n)), nmax = __builtin_amdgcn_readfirstlane(wave_max_u32(n));
+  // every chunk of the rows is written -- zeros past the wave's longest stream --, like k_decode; one barrier per chunk
+  const uint32_t nchunks = (a.nbins + 15u) >> 4;
+  const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  LdsStates stx{smem + kStates + lane * 4};
+
+  if (wib == 0) {
+    // -------------------------------------------------------------------------------------------- helper
+    using DTile = TileT<4>;
+    uint8_t *tile_c = smem + kTile;
+    const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
+    uint8_t *out_w = a.bins_out + s0 * a.pitch;
+    const uint32_t base2 = stx.base32() * 0x00010001u;  // the lane's state base in both halves (LDS addresses stay below 2^16)
+    // 128 bins of every stream out of staging buffer blk & 1 as full 128-byte row segments (k_decode: store_out); chunks from
+    // `nvalid` on were never written by B -- the rows end inside the block -- and read as zeros
+    auto store_block = [&](uint32_t blk, uint32_t nvalid) {
+      uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + kObuf + (blk & 1u) * OutBuf::BYTES);
+      for (uint32_t cz = nvalid; cz < 8; cz++) obuf[OutBuf::idx(cz, lane)] = 0;
+      wave_lds_sync();
+      const uint32_t off = blk * 128u;
+      if (nrows == 64 && off + 128 <= a.pitch) {
+        const uint32_t ln = opaque((uint32_t)lane);
+        const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
+        const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint4 v = OutBuf::unpack(*reinterpret_cast<const lds_u32 *>((uintptr_t)(st_lds ^ (32u * k))));
+          const u32x4 w = {v.x, v.y, v.z, v.w};
+          uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
+          // (s_nop 1: a store of more than 64 bits must not be followed within two wait states by a VALU write of its data)
+          if (kDecNTst) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+          else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        }
+        return;
+      }
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) {
+        const uint32_t row = k * 8 + (lane >> 3), cc = lane & 7;
+        const uint4 v = OutBuf::unpack(obuf[OutBuf::idx(cc, row)]);
+        const uint32_t boff = off + cc * 16;
+        if (row < nrows && boff < a.pitch) {
+          uint8_t *p = out_w + (row * a.pitch + boff);
+          if (kDecNT) nt_store16(p, v);
+          else *reinterpret_cast<uint4 *>(p) = v;
+        }
+      }
+    };
+    const uint32_t nrounds = (a.nbins + DTile::T - 1) / DTile::T;
+    uint4 pc[DTile::NLD];
+    if (nrounds && nmax) DTile::template load<kDecNT>(pc, ctx_w, nrows, a.pitch, 0, lane);
+    wave_lds_sync();
+    uint32_t c = 0;
+    for (uint32_t t = 0; t < nrounds; t++) {
+#pragma unroll
+      for (int h = 0; h < DTile::NP; h++) {
+        const uint32_t pos = t * DTile::T + h * 32;
+        if (pos >= a.nbins) break;
+        const bool live_part = pos < nmax;
+        if (live_part) {
+          DTile::half_to_lds(tile_c, pc, h, lane);
+          wave_lds_sync();
+          if (h == DTile::NP - 1 && (t + 1) * DTile::T < nmax) DTile::template load<kDecNT>(pc, ctx_w, nrows, a.pitch, (t + 1) * DTile::T, lane);
+        }
+        for (int j = 0; j < 2; j++) {
+          const uint32_t i0 = pos + j * 16;
+          if (i0 >= a.nbins) break;
+          if (i0 < nmax) {
+            const uint4 wc = DTile::row_chunk(tile_c, lane, j);
+            const bool full = i0 + 16 <= nmin;
+            const bool hi = chunk_not_plain<1>(wc, 0u);
+            const uint32_t slot = kRing + (c & 1u) * kSlotBytes + lane16;
+            uint32_t kind = kGeneral;
+            if (full && !hi) {
+              kind = kPlain;
+              uint4 p0, p1;  // 16-bit state addresses, bin 2 i in the low half of dword i
+              CtxQuad z = stx.prep4(wc.x);
+              p0.x = z.z01 + base2;
+              p0.y = z.z23 + base2;
+              z = stx.prep4(wc.y);
+              p0.z = z.z01 + base2;
+              p0.w = z.z23 + base2;
+              z = stx.prep4(wc.z);
+              p1.x = z.z01 + base2;
+              p1.y = z.z23 + base2;
+              z = stx.prep4(wc.w);
+              p1.z = z.z01 + base2;
+              p1.w = z.z23 + base2;
+              put_rows(slot, p0);
+              put_rows(slot + 1024u, p1);
+            } else {
+              if (full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) kind = kMixed;
+              put_rows(slot + 2048u, wc);
+            }
+            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kind;
+          }
+          __syncthreads();  // chunk c is in its slot; B has finished chunk c - 1
+          if (c >= 1 && ((c - 1) & 7u) == 7u) store_block((c - 1) >> 3, 8);
+          c++;
+        }
+        if (live_part) wave_lds_sync();
+      }
+    }
+    __syncthreads();  // B has finished the last chunk
+    if (nchunks) store_block((nchunks - 1) >> 3, ((nchunks - 1) & 7u) + 1u);
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- decoder
+  {
+    uint32_t *st32 = reinterpret_cast<uint32_t *>(smem + kStates) + lane;
+    for (uint32_t g = 0; g < 16; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;  // (see k_decode: the whole image)
+  }
+  uint64_t start = a.offsets[s];
+  const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
+  const uint64_t abase = start & ~3ull;
+  const uint32_t skew = (uint32_t)(start - abase);
+  WindowSrc<DevMem> src;
+  src.mem.payload = a.payload;
+  src.mem.total = a.payload_bytes;
+  src.mem.abase = abase;
+  src.mem.lim = a.payload_bytes >= abase + 16 ? (int32_t)min(a.payload_bytes - 16 - abase, (uint64_t)0x7FFFFFFF) : -1;
+  src.len = skew + len;
+  src.start(skew);
+  src.boundary();
+  DecCore d;
+  dec_start(d, src);
+  if (valid && needs_ref_decoder(d.v >> 24) && a.exact_flag) *a.exact_flag = 1u;  // (k_decode_exact takes those streams)
+  DecAbs da = dec_to_abs(d);
+  __syncthreads();  // chunk 0 is there
+  for (uint32_t c = 0; c < nchunks; c++) {
+    const uint32_t i0 = c * 16u, cidx = c & 7u;
+    uint32_t *obuf = reinterpret_cast<uint32_t *>(smem + kObuf + ((c >> 3) & 1u) * OutBuf::BYTES);
+    uint32_t od = 0;  // the chunk's 16 bins packed as they come (OutBuf: bit g of byte b = bin 4 g + b)
+    if (i0 < nmax) {
+      src.boundary();
+      const uint32_t slot = kRing + (c & 1u) * kSlotBytes + lane16;
+      const uint32_t kind = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))));
+      uint32_t oa = 0, ob = 0;
+      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_DEC_PRIO);
+      if (kind == kPlain) {
+        // k_decode's latency-oriented step: a bin's entry is read right behind the decision of the bin before it (its state
+        // may be that bin's successor: forwarded in a register for a repeated context, else loaded two bins ahead)
+        const uint4 p0 = get_rows(slot), p1 = get_rows(slot + 1024u);
+        auto addr_of = [&](int i) {
+          const uint32_t w = word_of(i < 8 ? p0 : p1, (i >> 1) & 3);
+          return (i & 1) ? w >> 16 : w & 0xFFFFu;
+        };
+        uint32_t at_cur = addr_of(0), at_nxt = addr_of(1);
+        const uint32_t q0 = stx.load_at(at_cur);
+        uint32_t qld_nxt = stx.load_at(at_nxt);
+        uint64_t same_nxt;
+        asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_nxt), "v"(at_cur));
+        uint64_t ent = stx.entry_raw(q0);
+        uint32_t psel = 0, psh = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (g == 2) src.ensure(47);
+          dec_topup_abs(da, src);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int i = 4 * g + k;
+            if (k == 0) {  // right behind the top-up: R's leading one is bit 31
+              psel = da.R >> 29;
+              psh = 23u;
+            }
+            const uint32_t nx = dec_bin_nx_abs_at(da, ent, psel, psh);
+            if (i < 15) {
+              uint32_t qn;
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
+              ent = stx.entry_raw(qn);
+            }
+#if ISSCABAC_DEC_LAT_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            stx.store_at(at_cur, nx);
+            uint32_t at_n2 = 0, qld_n2 = 0;
+            if (i < 14) {
+              at_n2 = addr_of(i + 2);
+              qld_n2 = stx.load_at(at_n2);
+            }
+            if (k == 0) put_out_byte<0>(oa, ob, nx);
+            else if (k == 1) put_out_byte<1>(oa, ob, nx);
+            else if (k == 2) put_out_byte<2>(oa, ob, nx);
+            else put_out_byte<3>(oa, ob, nx);
+            if (i < 14) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_n2), "v"(at_nxt));
+            if (k < 3) abs_positions(da.R, psel, psh);
+            at_cur = at_nxt;
+            at_nxt = at_n2;
+            qld_nxt = qld_n2;
+#if ISSCABAC_DEC_LAT_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+          od |= (out_word(oa, ob) & 0x01010101u) << g;
+        }
+      } else {
+        const uint4 wc = get_rows(slot + 2048u);
+        if (kind == kMixed) {
+          // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed_nx_abs), see k_decode
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            if (g == 2) src.ensure(47);
+            const uint32_t cw = word_of(wc, g);
+            dec_topup_abs(da, src);
+            const CtxQuad zs = stx.prep4(cw & 0x3F3F3F3Fu);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const uint32_t ak = stx.addr32_of(zs, k);
+              const uint32_t mbk = byte_bit_mask(cw, k, 7);
+              const uint32_t nx = k == 0 ? dec_bin_mixed_nx_abs<true>(da, mbk, ak, stx.load_at(ak), stx)
+                                         : dec_bin_mixed_nx_abs<false>(da, mbk, ak, stx.load_at(ak), stx);
+              if (k == 0) put_out_byte<0>(oa, ob, nx);
+              else if (k == 1) put_out_byte<1>(oa, ob, nx);
+              else if (k == 2) put_out_byte<2>(oa, ob, nx);
+              else put_out_byte<3>(oa, ob, nx);
+            }
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
+          }
+        } else {
+          // fixed-probability bins, or streams that end inside this chunk: every lane takes its own branch (k_decode)
+          const bool full = i0 + 16 <= nmin;
+          dec_from_abs(d, da);
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            if (g == 2) src.ensure(47);
+            const uint32_t cw = word_of(wc, g);
+            dec_topup_nocheck(d, src);
+            const CtxQuad z = stx.prep4(cw);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              if (k == 3) dec_guard(d, src, 8);
+              uint32_t w = 0;
+              if (full || i0 + 4 * g + k < n) {
+                const uint32_t cb = (cw >> (8 * k)) & 0xFFu;
+                if (is_ctx_byte<1>(cb, 64u)) {
+                  const uint32_t ak = stx.addr32_of(z, k);
+                  w = dec_bin_nx(d, ak, stx.load_at(ak), stx);
+                } else if (cb == kBypass || cb == kProbBase + 50u) {
+                  w = dec_bin_ep(d);
+                } else if (is_prob_ctx_byte<1>(cb) && prob_valid(cb - kProbBase)) {
+                  w = dec_bin_prob(d, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]);
+                }
+              }
+              if (k == 0) put_out_byte<0>(oa, ob, w);
+              else if (k == 1) put_out_byte<1>(oa, ob, w);
+              else if (k == 2) put_out_byte<2>(oa, ob, w);
+              else put_out_byte<3>(oa, ob, w);
+            }
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
+          }
+          da = dec_to_abs(d);
+        }
+      }
+      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    obuf[OutBuf::idx(cidx, lane)] = od;
+    __syncthreads();  // the chunk's bins are in the staging buffer; chunk c + 1 is in its slot
+  }
+  if (valid && a.status) {
+    uint64_t first = a.offsets[s];
+    (void)clip_stream(first, first, a.payload_bytes);
+    const uint32_t sk = (uint32_t)first & 3u;
+    const uint8_t *p = a.payload + first;
+    dec_from_abs(d, da);
+    a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
+  }
+}
+
+bool decode_pair_enabled() { return ISSCABAC_DEC_PAIR != 0; }
+
+hipError_t run_decode_pair(const DecArgs &a, hipStream_t stream) {
+  static int static_lds = -1;  // absolute LDS addresses, as in run_encode_pair
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    const hipError_t err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode_pair));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
+  const uint64_t nblk = (a.S + 63) / 64;
+  hipLaunchKernelGGL(k_decode_pair, dim3((unsigned)nblk), dim3(128), dpair::kLdsBytes, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace isscabac

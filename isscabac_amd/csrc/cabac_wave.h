@@ -559,6 +559,75 @@ struct EncArgs {
   uint32_t ctx_init[64];
 };
 
+struct DevMem {
+  const uint8_t *payload;  // whole payload buffer (wave-uniform)
+  uint64_t total;          // its size in bytes (wave-uniform)
+  uint64_t abase;          // 4-byte aligned offset at or below the stream's first byte
+  int32_t lim;             // largest off for which [abase + off, +16) lies inside the buffer (-1: none), capped at 2^31-1
+  struct alignas(4) Q4 { uint32_t w[4]; };
+  struct Pair { uint64_t lo, hi; };
+  // the last few bytes of the whole payload buffer: never read past its end
+  static __device__ __forceinline__ Pair load16_tail(const uint8_t *payload, uint64_t total, uint64_t at) {
+    Pair r{0, 0};
+#pragma unroll 1
+    for (uint32_t i = 0; i < 16; i++) {
+      const uint64_t b = at + i < total ? payload[at + i] : 0;
+      if (i < 8) r.lo |= b << (8 * i);
+      else r.hi |= b << (8 * (i - 8));
+    }
+    return r;
+  }
+  __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
+#if ISSCABAC_EXP_NOPAYLOAD  // (timing experiment: every lane reads the same few lines)
+    const uint64_t at = off & 0xFFCu;
+#else
+    const uint64_t at = abase + off;
+#endif
+    if ((int32_t)off <= lim) {  // off is far below 2^31 (a stream's payload is bounded by 6/8 of its <= 2^25 bins)
+      const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
+      lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
+      hi = (uint64_t)q.w[2] | ((uint64_t)q.w[3] << 32);
+    } else {
+      const Pair r = load16_tail(payload, total, at);
+      lo = r.lo;
+      hi = r.hi;
+    }
+  }
+};
+
+struct DecArgs {
+  const uint8_t *payload, *ctx;
+  const uint64_t *offsets;
+  const uint32_t *nbins_per_stream;
+  const uint32_t *order;  // as in EncArgs
+  uint8_t *bins_out;
+  uint32_t *status;
+  uint32_t *exact_flag;  // set when a stream of this launch needs k_decode_exact
+  uint64_t S, payload_bytes;
+  uint32_t nbins, pitch, nctx;
+  uint32_t img_bytes;  // as in EncArgs
+  uint32_t ctx_init[64];
+};
+
+#ifndef ISSCABAC_DEC_OCC
+#define ISSCABAC_DEC_OCC 4  // waves per SIMD the decode kernel is register-limited to (4 measured 6% faster than 3)
+#endif
+#ifndef ISSCABAC_DEC_NT
+#define ISSCABAC_DEC_NT 1
+#endif
+#ifndef ISSCABAC_DEC_NOSTORE
+#define ISSCABAC_DEC_NOSTORE 0
+#endif
+#ifndef ISSCABAC_DEC_NT_ST
+#define ISSCABAC_DEC_NT_ST ISSCABAC_DEC_NT
+#endif
+constexpr bool kDecNT = ISSCABAC_DEC_NT != 0;  // decode kernel: ctx loads are streaming
+constexpr bool kDecNTst = ISSCABAC_DEC_NT_ST != 0;  // ... and the bin stores
+
+// LDS of the decode kernel: the raw-byte entries (256 x 8 bytes, cabac_lane.h: dec_bin_out) at 0, then per wave the
+// context states, the round tile and (bucketed launches) the wave's stream ids
+constexpr int kDecTabBytes = 2048;
+
 // the digit flush of the encode kernels: digits leave `low` when some lane could overflow it within the next four bins
 #ifndef ISSCABAC_FLUSH_AT
 #define ISSCABAC_FLUSH_AT 39  // four more bins add at most 22 (context) bits: W stays <= 62
@@ -570,6 +639,8 @@ struct EncArgs {
 // cabac_pair.hip: the encode kernel of small launches (<= 64 contexts, no length bucketing)
 bool encode_pair_enabled();
 hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream);
+bool decode_pair_enabled();
+hipError_t run_decode_pair(const DecArgs &a, hipStream_t stream);
 
 }  // namespace isscabac
 #endif

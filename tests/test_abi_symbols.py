@@ -128,17 +128,46 @@ def test_iss_side_info_container_round_trip(tmp_path):
 
 
 def test_no_instruction_touches_an_lds_read_in_flight():
-    """tools/check_inflight_regs.py on the coder kernels' ISA: the latency-oriented encoder issues its state pass in inline
-    assembly with the waits placed by hand; a copy or spill the compiler put between such a read and its wait would be a
-    race no parity test is sure to catch.  Negative control: the checker does flag a hand-made violation."""
+    """tools/check_inflight_regs.py on the ISA of every .hip file: (A) the latency-oriented encoder issues its state pass in
+    inline assembly with the waits placed by hand -- a copy or spill the compiler put between such a read and its wait
+    would be a race no parity test is sure to catch; (B) the decode kernels issue their wide output stores by hand, and a
+    VALU write of the data registers within two wait states once produced wrong bytes with clean status words; (C) a VALU
+    result written with a destination select must not be read by the very next VALU instruction.  Negative controls: the
+    checker does flag a hand-made violation of each kind."""
     import subprocess
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_inflight_regs as chk
     bad, counts = chk.check("_Zfoo:\n\tds_read_b64 v[4:5], v1 offset:768\n\tv_mov_b32_e32 v9, v5\n\ts_waitcnt lgkmcnt(0)\n")
-    assert len(bad) == 1 and counts == {"_Zfoo": 1}
+    assert len(bad) == 1 and bad[0].startswith("A ") and counts == {"_Zfoo": 1}
     bad, _ = chk.check("_Zfoo:\n\tds_read_b64 v[4:5], v1 offset:768\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v9, v5\n")
     assert not bad
+    # B: the data of a 128-bit store rewritten one wait state later / two wait states later / an LDS store (no such hazard)
+    st = "_Zfoo:\n\tglobal_store_dwordx4 v1, v[4:7], s[2:3] nt\n"
+    bad, _ = chk.check(st + "\tv_and_b32_e32 v6, 1, v9\n")
+    assert len(bad) == 1 and bad[0].startswith("B ")
+    bad, _ = chk.check(st + "\ts_nop 0\n\tv_and_b32_e32 v6, 1, v9\n")
+    assert len(bad) == 1 and bad[0].startswith("B ")
+    assert not chk.check(st + "\ts_nop 1\n\tv_and_b32_e32 v6, 1, v9\n")[0]
+    assert not chk.check(st + "\tv_and_b32_e32 v8, 1, v6\n\tv_mov_b32_e32 v10, v6\n\tv_mov_b32_e32 v6, v1\n")[0]  # reads are fine
+    assert not chk.check("_Zfoo:\n\tglobal_store_dwordx2 v1, v[4:5], s[2:3]\n\tv_mov_b32_e32 v4, v1\n")[0]      # 64 bits: no hazard
+    assert not chk.check("_Zfoo:\n\tds_write_b128 v1, v[4:7]\n\tv_mov_b32_e32 v4, v1\n")[0]
+    assert chk.check.sites["_Zfoo"][1] == 0
+    # C: the byte written by an SDWA move read by the next VALU instruction / one instruction later
+    pw = "_Zfoo:\n\tv_lshrrev_b32_sdwa v3, v8, v9 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+    bad, _ = chk.check(pw + "\tv_cndmask_b32_e64 v4, v5, v3, s[0:1]\n")
+    assert len(bad) == 1 and bad[0].startswith("C ")
+    assert not chk.check(pw + "\ts_nop 0\n\tv_cndmask_b32_e64 v4, v5, v3, s[0:1]\n")[0]
+    assert not chk.check(pw + "\tds_write_b8 v1, v3\n")[0]  # (an LDS instruction is no VALU reader)
+    pres = "_Zfoo:\n\tv_mov_b32_sdwa v3, v9 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0\n\tv_mov_b32_sdwa v3, v8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n"
+    bad, _ = chk.check(pres)  # UNUSED_PRESERVE reads its own destination
+    assert len(bad) == 1 and bad[0].startswith("C ")
+    assert not chk.check("_Zfoo:\n\tv_add_u32_sdwa v3, v8, v9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\tv_mov_b32_e32 v4, v3\n")[0]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "k_encodeILi1ELb1ELb0E" in out.stdout  # the latency-oriented encoder was among the kernels checked
+    # every coder kernel was among the ones checked: the latency-oriented encoder (A), the decode kernels' hand-issued stores
+    # (B: 8 per store pass), the wave-pair kernels, the symbol and handle kernels
+    for name in ("k_encodeILi1ELb1ELb0E", "k_decodeILi1ELb0ELb0E", "k_encode_pair", "k_decode_pair", "k_encode_symbols_trie", "k_stream_enc_bins"):
+        assert name in out.stdout, name
+    line = [l for l in out.stdout.splitlines() if "k_decodeILi1ELb0ELb0E" in l][0]
+    assert int(line.split("LDS reads,")[1].split("wide stores")[0]) >= 8

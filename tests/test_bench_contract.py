@@ -36,10 +36,37 @@ def test_bench_json_line_contract():
     assert c["unit"] == "Gbin/s" and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0 and c["sample"]
     assert c["gpu_streams_checked_byte_exact"] == 4096
     assert d["verified_bit_exact"] is True
+    # encode-only and decode-only rates beside the round trip, from the engine's HIP events
+    k = d["kernels_ms"]
+    bins_per_launch = d["config"]["streams_per_gpu"] * d["config"]["bins_per_stream"] / d["config"]["launches_per_step"]
+    assert abs(d["encode_Gbin_s"] - bins_per_launch / ((k["encode"] + k["scan"] + k["gather"]) * 1e-3) / 1e9) < 1e-6 * d["encode_Gbin_s"]
+    assert abs(d["decode_Gbin_s"] - bins_per_launch / (k["decode"] * 1e-3) / 1e9) < 1e-6 * d["decode_Gbin_s"]
+    assert d["encode_Gbin_s"] > d["value"] and d["decode_Gbin_s"] > d["value"] and "decode" in d["step"]
     # value = bins / wall time, consistent with ms_per_step
     assert d["config"]["streams_total"] == 8192 and d["config"]["launches_per_step"] == 1
     bins_per_step = d["config"]["streams_total"] * d["config"]["bins_per_stream"]
     assert abs(d["value"] - bins_per_step / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_config2_is_encode_only_as_baseline_names_it():
+    """BASELINE.json config 2: "64K streams x 1K bins, 3 contexts, encode-only".  The default step of --workload config2 is
+    encode (kernel + scan + gather) alone; --round-trip times the way back too.  Either way the line carries both rates and
+    the payload has been decoded back and compared once, outside the timed region."""
+    def run(*extra):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config2", "--steps", "3", "--warmup", "1",
+                              "--cpu-seconds", "1"] + list(extra), capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    d = run()
+    assert "encode-only" in d["metric"] and "65536 streams x 1024 bins, 3 contexts" in d["metric"]
+    assert d["step"] == "encode (kernel + scan + gather)" and d["verified_bit_exact"] is True
+    assert d["roofline"]["kernel"] == "k_encode" and d["encode_Gbin_s"] > 0 and d["decode_Gbin_s"] > 0
+    bins = d["config"]["streams_total"] * d["config"]["bins_per_stream"]
+    assert abs(d["value"] - bins / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    assert d["value"] <= d["encode_Gbin_s"] * 1.05  # the timed step is the encode path alone
+    r = run("--round-trip")
+    assert "encode+decode round-trip" in r["metric"] and "decode" in r["step"] and r["value"] < d["value"]
 
 
 def _run_dist_bench(extra_env, tag):
