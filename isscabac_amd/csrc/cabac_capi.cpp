@@ -102,6 +102,7 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->h2d_stream) (void)hipStreamDestroy(e->h2d_stream);
   if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
   if (e->h_total) (void)hipHostFree(e->h_total);
+  if (e->sym_pin) (void)hipHostFree(e->sym_pin);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

@@ -44,6 +44,9 @@ struct isscabac_engine {
   hipEvent_t pin_ev[kPinSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // hand-over points between the copy streams and the compute stream
+  // small symbol batches: one pinned, device-mapped block the kernels read and write directly (cabac_symbols.hip)
+  uint8_t *sym_pin = nullptr;
+  uint64_t sym_pin_bytes = 0;
   // what isscabac_sync has to report about the most recent (async) encode
   uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]
   uint64_t pending_cap = 0;

@@ -961,11 +961,14 @@ int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const 
                                            d_offsets, total_bytes, d_nbins_out, nullptr);
 }
 
-int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
-                                      uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
-                                      const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
-                                      uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out,
-                                      const isscabac_symbol_stats *d_stats) {
+// the encode kernel + the offsets scan + the payload gather of one batch, enqueued on the engine's stream (no synchronisation)
+static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
+                               uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                               uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint32_t *d_nbins_out,
+                               const isscabac_symbol_stats *d_stats) {
+  // a statistics block with nothing asked for is no statistics block: the code-tree kernel serves the call (the host form
+  // always hands one over, and ran the general kernel for that reason alone: config 4 at its real size 0.58 ms per encode)
+  if (d_stats && !d_stats->ctx_hist && !d_stats->ctx_cost && !d_stats->sym_bits && !d_stats->bin_trace) d_stats = nullptr;
   SymEncArgs a;
   a.ctx_hist = d_stats ? d_stats->ctx_hist : nullptr;
   a.ctx_cost = d_stats ? d_stats->ctx_cost : nullptr;
@@ -1012,6 +1015,17 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
+                                      uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                      const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
+                                      uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out,
+                                      const isscabac_symbol_stats *d_stats) {
+  const int rc = enc_symbols_enqueue(e, d_sym, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_payload, payload_cap, d_offsets,
+                                     d_nbins_out, d_stats);
+  if (rc) return rc;
   // the size word comes back through the engine's pinned words (word 1: word 0 may belong to an asynchronous batch encode
   // that is still outstanding) -- a copy into pageable memory is staged by the runtime and costs tens of microseconds
   if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
@@ -1025,10 +1039,10 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   return ISSCABAC_OK;
 }
 
-int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
-                                const uint32_t *d_nsym, uint64_t S, uint32_t nsym, uint32_t pitch,
-                                const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *d_sym_out,
-                                uint32_t *d_status) {
+static int dec_symbols_enqueue(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                               const uint32_t *d_nsym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                               const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *d_sym_out,
+                               uint32_t *d_status) {
   SymDecArgs a;
   uint32_t maxbins = 0;
   int rc = sym_check(e, "isscabac_decode_symbols_dev", S, nsym, pitch, params, ctx_init, nctx, &a.P, a.ctx_init, &maxbins, false);
@@ -1074,9 +1088,38 @@ int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, ui
   if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_decode_symbols)))) return rc;
   hipLaunchKernelGGL(k_decode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
   HIP_TRY(e, hipGetLastError());
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                                const uint32_t *d_nsym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *d_sym_out,
+                                uint32_t *d_status) {
+  const int rc = dec_symbols_enqueue(e, d_payload, payload_bytes, d_offsets, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_sym_out,
+                                     d_status);
+  if (rc) return rc;
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
 }
+
+// ---- small batches through ONE pinned, device-mapped block (config 4 at its real size: 20 columns) -------------------------
+// A call of a few kilobytes is launches and host round trips, not coding: five copies and two synchronisations per encode
+// (profiles/r04/symbol_host_rate.txt).  Below kSymSmallBytes the host forms copy the caller's arrays into a pinned block
+// the kernels read and write DIRECTLY over the link (zero-copy), enqueue their kernels and synchronise once; the results
+// are then ordinary host memory.  No hipMemcpy at all on this path.
+constexpr uint64_t kSymSmallBytes = 1ull << 20;
+static uint8_t *sym_pin_block(isscabac_engine *e, uint64_t bytes) {
+  if (e->sym_pin_bytes >= bytes) return e->sym_pin;
+  if (e->sym_pin) (void)hipHostFree(e->sym_pin);
+  e->sym_pin = nullptr;
+  e->sym_pin_bytes = 0;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocMapped) != hipSuccess) return nullptr;
+  e->sym_pin = static_cast<uint8_t *>(p);
+  e->sym_pin_bytes = bytes;
+  return e->sym_pin;
+}
+static inline uint64_t up64(uint64_t x) { return (x + 63) & ~63ull; }
 
 int isscabac_encode_symbols(isscabac_engine *e, const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym,
                             uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
@@ -1101,6 +1144,38 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   HIP_TRY(e, hipSetDevice(e->device));
   const uint64_t in_bytes = S * pitch, dev_cap = S * isscabac_stream_bound(nsym * maxbins);
   int rc;
+  const bool any_stats = stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits || stats->bin_trace);
+  const uint64_t o_nsym = up64(in_bytes), o_off = o_nsym + up64(S * 4), o_nb = o_off + up64((S + 1) * 8), o_pay = o_nb + up64(S * 4),
+                 small_total = o_pay + up64(dev_cap);
+  if (!any_stats && small_total <= kSymSmallBytes) {
+    uint8_t *pin = sym_pin_block(e, kSymSmallBytes);
+    if (pin) {
+      void *dv = nullptr;
+      HIP_TRY(e, hipHostGetDevicePointer(&dv, pin, 0));
+      uint8_t *d = static_cast<uint8_t *>(dv);
+      memcpy(pin, sym, in_bytes);
+      if (nsym_per_stream) memcpy(pin + o_nsym, nsym_per_stream, S * sizeof(uint32_t));
+      const uint64_t h2d = nsym_per_stream ? o_off : in_bytes;  // [symbols | counts]: one copy
+      if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], o_off))) return rc;
+      uint8_t *din = static_cast<uint8_t *>(e->stage[0]);
+      HIP_TRY(e, hipMemcpyAsync(din, pin, h2d, hipMemcpyHostToDevice, e->stream));
+      rc = enc_symbols_enqueue(e, din, nsym_per_stream ? reinterpret_cast<uint32_t *>(din + o_nsym) : nullptr, S, nsym, pitch, params,
+                               ctx_init, nctx, d + o_pay, dev_cap, reinterpret_cast<uint64_t *>(d + o_off),
+                               reinterpret_cast<uint32_t *>(d + o_nb), nullptr);
+      if (rc) return rc;
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      const uint64_t *off = reinterpret_cast<const uint64_t *>(pin + o_off);
+      const uint64_t total = off[S];
+      if (total_bytes) *total_bytes = total;
+      if (total > payload_cap)
+        return engine_fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_symbols: payload needs %llu bytes, capacity is %llu",
+                           (unsigned long long)total, (unsigned long long)payload_cap);
+      memcpy(payload, pin + o_pay, total);
+      memcpy(offsets, off, (S + 1) * sizeof(uint64_t));
+      if (nbins_out) memcpy(nbins_out, pin + o_nb, S * sizeof(uint32_t));
+      return ISSCABAC_OK;
+    }
+  }
   if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;
   if ((rc = sym_grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
   if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
@@ -1155,6 +1230,30 @@ int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const ui
   HIP_TRY(e, hipSetDevice(e->device));
   const uint64_t out_bytes = S * pitch, total = offsets[S];
   int rc;
+  {
+    const uint64_t o_off = up64(total + 16), o_nsym = o_off + up64((S + 1) * 8), o_out = o_nsym + up64(S * 4), o_st = o_out + up64(out_bytes),
+                   small_total = o_st + up64(S * 4);
+    uint8_t *pin = small_total <= kSymSmallBytes ? sym_pin_block(e, kSymSmallBytes) : nullptr;
+    if (pin) {
+      void *dv = nullptr;
+      HIP_TRY(e, hipHostGetDevicePointer(&dv, pin, 0));
+      uint8_t *d = static_cast<uint8_t *>(dv);
+      memcpy(pin, payload, total);
+      memcpy(pin + o_off, offsets, (S + 1) * sizeof(uint64_t));
+      if (nsym_per_stream) memcpy(pin + o_nsym, nsym_per_stream, S * sizeof(uint32_t));
+      if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], o_out))) return rc;  // [payload | offsets | counts]: one copy
+      uint8_t *din = static_cast<uint8_t *>(e->stage[3]);
+      HIP_TRY(e, hipMemcpyAsync(din, pin, nsym_per_stream ? o_out : o_nsym, hipMemcpyHostToDevice, e->stream));
+      rc = dec_symbols_enqueue(e, din, total, reinterpret_cast<const uint64_t *>(din + o_off),
+                               nsym_per_stream ? reinterpret_cast<const uint32_t *>(din + o_nsym) : nullptr, S, nsym, pitch, params,
+                               ctx_init, nctx, d + o_out, reinterpret_cast<uint32_t *>(d + o_st));
+      if (rc) return rc;
+      HIP_TRY(e, hipStreamSynchronize(e->stream));
+      memcpy(sym_out, pin + o_out, out_bytes);
+      if (status) memcpy(status, pin + o_st, S * sizeof(uint32_t));
+      return ISSCABAC_OK;
+    }
+  }
   if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], out_bytes))) return rc;
   if ((rc = sym_grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
   if ((rc = sym_grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;

@@ -11,7 +11,7 @@ included.  Three routes, beside the CPU on one core:
                (one MEX call per bin) are not part of that figure
 Shapes: W 400 x 20 and H 109 x 20 (ISS.m:32,36) tiled x 16 384 -> 327 680 columns as independent streams, Nq = 8, EG0,
 23 contexts; and config 4 at its real size (40 columns), where a call is launch latency.
-    python tests/perf/symbol_host_rate.py [--tile 16384] [--no-gateway]"""
+    python tests/perf/symbol_host_rate.py [--tile 16384] [--no-gateway] [--real-only]"""
 import os
 import sys
 import time
@@ -38,7 +38,7 @@ if use_gw:
 mex_params = np.array([1.0, 0.0, nq, 1.0, 15.0, 3.0, 0.0])
 
 
-def best_of(fn, n=3):
+def best_of(fn, n=7 if "--real-only" in sys.argv else 3):
     fn()
     t = []
     for _ in range(n):
@@ -55,7 +55,10 @@ L, h = eng._L, eng._h
 u8p, u32p, u64p, u16p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint16)
 P = lambda a, t: a.ctypes.data_as(t)
 
-for rows, cols in ((400, 20 * tile), (109, 20 * tile), (400, 20 * 1024), (400, 20), (109, 20)):
+shapes = ((400, 20 * tile), (109, 20 * tile), (400, 20 * 1024), (400, 20), (109, 20))
+if "--real-only" in sys.argv:  # config 4 at its real size only (a call is launches and host round trips)
+    shapes = ((400, 20), (109, 20))
+for rows, cols in shapes:
     G = np.minimum(rng.exponential(1.2, (min(cols, 4096), rows)).astype(np.int64), nq - 1).astype(np.uint8)
     sym = np.tile(G, (max(1, cols // 4096), 1))  # [streams, rows]: one column per row of this array
     S = sym.shape[0]
