@@ -45,9 +45,12 @@ extern "C" {
 #define ISSCABAC_BYPASS 0xFFu
 #define ISSCABAC_MAX_CTX 255 /* contexts of a batch call (one byte per bin names the context) */
 /* The reference holds up to 999 context models per handle (ref: CABAC/CommonDef.h:56, CABAC_ContextModelsInit.cpp:53,84).
- * The single-stream handle (isscabac_stream_*, what the reference's per-bin commands map to) takes as many; a batch call
- * with more than ISSCABAC_MAX_CTX contexts is refused with ISSCABAC_ERR_ARG (its context indices are bytes). */
+ * The single-stream handle (isscabac_stream_*, what the reference's per-bin commands map to) takes as many; an 8-bit batch
+ * call with more than ISSCABAC_MAX_CTX contexts is refused with ISSCABAC_ERR_ARG (its context indices are bytes) ... */
 #define ISSCABAC_STREAM_MAX_CTX 999
+/* ... and so do the batch calls with 16-bit context indices (isscabac_*_batch16*): 0xFFFF = bypass bin */
+#define ISSCABAC_MAX_CTX16 999
+#define ISSCABAC_BYPASS16 0xFFFFu
 /* Fixed-probability bins (ref: encodeBinProb / decodeBinProb, CABAC_ArithmeticEncoder.cpp:180-243,
  * CABAC_ArithmeticDecoder.cpp:192-286; compiled into the reference only with RWTH_CABAC_FIXED_PROBABILITY, CommonDef.h:50).
  * In a batch call of at most ISSCABAC_PROB_MAX_CTX contexts a ctx byte of ISSCABAC_PROB(p) codes the bin with a fixed
@@ -157,6 +160,29 @@ int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload
                                     uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
                                     uint8_t *d_bins_out, uint32_t *d_status);
 int isscabac_sync(isscabac_engine *e, uint64_t *total_bytes);
+
+/* ---- batches of MORE than 255 contexts: 16-bit context indices ---------------------------------------
+ * The reference's coder holds up to 999 context models (ref: CABAC/CommonDef.h:56, CABAC_ContextModelsInit.cpp:53,84) and
+ * its per-bin commands take the context index as a double (SimpleCABACMex.cpp:223-224, 316).  These calls are the batch
+ * form of that: as isscabac_encode_batch_dev / isscabac_decode_batch_dev, with d_ctx16 / ctx16 = [S * pitch] uint16
+ * context indices (16-byte aligned), ISSCABAC_BYPASS16 (0xFFFF) = bypass bin, 1 <= nctx <= ISSCABAC_MAX_CTX16.  An index
+ * in [nctx, 0xFFFF) is invalid: that stream's result is unspecified (memory-safe), the others are not affected.  No
+ * fixed-probability bins here.  The state image (1 KiB per stream) lives in device memory, so every bin is a dependent
+ * memory round trip: a few Gbin/s, against hundreds for up to 255 contexts -- use the 8-bit calls wherever they apply.
+ * Synchronous. */
+int isscabac_encode_batch16_dev(isscabac_engine *e, const uint8_t *d_bins, const uint16_t *d_ctx16, const uint32_t *d_nbins,
+                                uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes);
+int isscabac_decode_batch16_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                                const uint16_t *d_ctx16, const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out, uint32_t *d_status);
+/* the same on host buffers (plain copies around the device forms) */
+int isscabac_encode_batch16(isscabac_engine *e, const uint8_t *bins, const uint16_t *ctx16, const uint32_t *nbins_per_stream,
+                            uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                            uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes);
+int isscabac_decode_batch16(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint16_t *ctx16,
+                            const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init,
+                            int nctx, uint8_t *bins_out, uint32_t *status);
 
 /* ---- batch coding on host buffers (what a MEX / FFI caller holding host arrays uses) --------------
  * same semantics; the engine stages through its own device buffers (H2D, kernels, D2H).

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # ISSCABAC_LIB selects another build of the same ABI (A/B experiments: tools/ab_bench.py)
 LIB = os.environ.get("ISSCABAC_LIB") or os.path.join(HERE, "lib", "libisscabac_hip.so")
-SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip", "cabac_capi.cpp", "cabac_container.cpp"]
+SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_wide.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip", "cabac_capi.cpp", "cabac_container.cpp"]
 HEADERS = ["cabac_lane.h", "cabac_wave.h", "cabac_symbols.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
 
 

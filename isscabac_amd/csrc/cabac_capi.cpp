@@ -103,6 +103,8 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
   if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->sym_pin) (void)hipHostFree(e->sym_pin);
+  if (e->wide_states) (void)hipFree(e->wide_states);
+  if (e->wide_init) (void)hipFree(e->wide_init);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -368,6 +370,136 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
   return engine_sync(e);
+}
+
+// ---- batches of more than 255 contexts: 16-bit context indices (cabac_wide.hip) -------------------------------------
+static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init,
+                        int nctx) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (S == 0) return fail(e, ISSCABAC_ERR_ARG, "%s: S must be > 0", who);
+  if (pitch == 0 || (pitch & 15u)) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) must be a positive multiple of 16", who, pitch);
+  if (nbins > pitch) return fail(e, ISSCABAC_ERR_ARG, "%s: nbins (%u) exceeds pitch (%u)", who, nbins, pitch);
+  if (pitch > ISSCABAC_MAX_PITCH) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) exceeds %u bins per stream", who, pitch, (unsigned)ISSCABAC_MAX_PITCH);
+  if (nctx < 1 || nctx > ISSCABAC_MAX_CTX16) return fail(e, ISSCABAC_ERR_ARG, "%s: nctx (%d) must be 1..%d", who, nctx, ISSCABAC_MAX_CTX16);
+  if (!ctx_init) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init is null", who);
+  if (S > (1ull << 31)) return fail(e, ISSCABAC_ERR_ARG, "%s: S too large", who);
+  uint8_t init[1024];
+  memset(init, 1, sizeof init);  // contexts the caller did not initialise: the reference's default ContextModel(), (mps 1, state 0)
+  for (int c = 0; c < nctx; c++) {
+    if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
+    init[c] = ctx_init[c];
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  int rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->wide_states), &e->wide_states_bytes, wide_state_bytes(S)))) return rc;
+  if (!e->wide_init) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->wide_init), sizeof init));
+  // (a blocking copy of 1 KiB out of this stack frame: the previous call's kernels have long read theirs -- every wide call synchronises)
+  HIP_TRY(e, hipMemcpyAsync(e->wide_init, init, sizeof init, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_encode_batch16_dev(isscabac_engine *e, const uint8_t *d_bins, const uint16_t *d_ctx16, const uint32_t *d_nbins,
+                                uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                                uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint64_t *total_bytes) {
+  int rc = wide_prepare(e, "isscabac_encode_batch16_dev", S, nbins, pitch, ctx_init, nctx);
+  if (rc) return rc;
+  if (!d_bins || !d_ctx16 || !d_payload || !d_offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16_dev: null buffer");
+  if (misaligned(d_bins) || misaligned(d_ctx16)) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16_dev: bins/ctx must be 16-byte aligned");
+  const uint64_t stride = slot_stride_for(nbins);
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
+  if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  HIP_TRY(e, launch_encode_wide(d_bins, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init, e->wide_states, e->slots, stride,
+                                e->lens, e->stream));
+  HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->h_total + 2, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const uint64_t total = e->h_total[2];
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch16_dev: payload needs %llu bytes, capacity is %llu",
+                (unsigned long long)total, (unsigned long long)payload_cap);
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch16_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                                const uint16_t *d_ctx16, const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch,
+                                const uint8_t *ctx_init, int nctx, uint8_t *d_bins_out, uint32_t *d_status) {
+  int rc = wide_prepare(e, "isscabac_decode_batch16_dev", S, nbins, pitch, ctx_init, nctx);
+  if (rc) return rc;
+  if (!d_payload || !d_offsets || !d_ctx16 || !d_bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16_dev: null buffer");
+  if (misaligned(d_ctx16) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
+    return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
+  HIP_TRY(e, launch_decode_wide(d_payload, payload_bytes, d_offsets, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init,
+                                e->wide_states, d_bins_out, d_status, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+// host-buffer forms: plain copies around the device forms (this path is about the API surface, not about the link)
+int isscabac_encode_batch16(isscabac_engine *e, const uint8_t *bins, const uint16_t *ctx16, const uint32_t *nbins_per_stream, uint64_t S,
+                            uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
+                            uint64_t *offsets, uint64_t *total_bytes) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!bins || !ctx16 || !payload || !offsets || S == 0 || pitch == 0) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16: null buffer or empty batch");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t nb = S * pitch, dev_cap = S * isscabac_stream_bound(nbins);
+  int rc;
+  if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
+  if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], 2 * nb))) return rc;
+  if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], dev_cap))) return rc;
+  if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[0], bins, nb, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx16, 2 * nb, hipMemcpyHostToDevice, e->stream));
+  if (nbins_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  uint64_t total = 0;
+  rc = isscabac_encode_batch16_dev(e, static_cast<uint8_t *>(e->stage[0]), static_cast<uint16_t *>(e->stage[1]),
+                                   nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr, S, nbins, pitch, ctx_init, nctx,
+                                   static_cast<uint8_t *>(e->stage[3]), dev_cap, static_cast<uint64_t *>(e->stage[4]), &total);
+  if (rc) return rc;
+  if (total_bytes) *total_bytes = total;
+  if (total > payload_cap)
+    return fail(e, ISSCABAC_ERR_CAPACITY, "isscabac_encode_batch16: payload needs %llu bytes, capacity is %llu", (unsigned long long)total,
+                (unsigned long long)payload_cap);
+  HIP_TRY(e, hipMemcpyAsync(payload, e->stage[3], total, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(offsets, e->stage[4], (S + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
+}
+
+int isscabac_decode_batch16(isscabac_engine *e, const uint8_t *payload, const uint64_t *offsets, const uint16_t *ctx16,
+                            const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
+                            uint8_t *bins_out, uint32_t *status) {
+  if (!e) return ISSCABAC_ERR_ARG;
+  if (!payload || !offsets || !ctx16 || !bins_out || S == 0 || pitch == 0) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: null buffer or empty batch");
+  for (uint64_t s = 0; s < S; s++)
+    if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
+      return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: offsets not monotone at stream %llu", (unsigned long long)s);
+  HIP_TRY(e, hipSetDevice(e->device));
+  const uint64_t nb = S * pitch, total = offsets[S];
+  int rc;
+  if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
+  if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], 2 * nb))) return rc;
+  if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
+  if ((rc = grow(e, &e->stage[3], &e->stage_bytes[3], total + 16))) return rc;
+  if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
+  HIP_TRY(e, hipMemcpyAsync(e->stage[1], ctx16, 2 * nb, hipMemcpyHostToDevice, e->stream));
+  if (nbins_per_stream) HIP_TRY(e, hipMemcpyAsync(e->stage[2], nbins_per_stream, S * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[3], payload, total, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->stage[4], offsets, (S + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->stage[0], 0, nb, e->stream));  // (columns behind nbins rounded up to 16 are not written by the kernel)
+  rc = isscabac_decode_batch16_dev(e, static_cast<uint8_t *>(e->stage[3]), total, static_cast<uint64_t *>(e->stage[4]),
+                                   static_cast<uint16_t *>(e->stage[1]), nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr,
+                                   S, nbins, pitch, ctx_init, nctx, static_cast<uint8_t *>(e->stage[0]), static_cast<uint32_t *>(e->stage[5]));
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(bins_out, e->stage[0], nb, hipMemcpyDeviceToHost, e->stream));
+  if (status) HIP_TRY(e, hipMemcpyAsync(status, e->stage[5], S * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return ISSCABAC_OK;
 }
 
 // ---- batch coding, host buffers -----------------------------------------------------------------------

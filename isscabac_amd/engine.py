@@ -129,6 +129,14 @@ def _load():
                                         C.c_int, _u8p, _u32p]
     L.isscabac_decode_batch_packed.argtypes = [_vp, _u8p, _u64p, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p,
                                         C.c_int, _u8p, _u32p]
+    _u16p = C.POINTER(C.c_uint16)
+    L.isscabac_encode_batch16.argtypes = [_vp, _u8p, _u16p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int, _u8p, C.c_uint64,
+                                          _u64p, _u64p]
+    L.isscabac_decode_batch16.argtypes = [_vp, _u8p, _u64p, _u16p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int, _u8p, _u32p]
+    L.isscabac_encode_batch16_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int, _vp, C.c_uint64,
+                                              _vp, _u64p]
+    L.isscabac_decode_batch16_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _u8p, C.c_int,
+                                              _vp, _vp]
     L.isscabac_symbol_max_bins.argtypes = [C.POINTER(SymbolParams)]
     L.isscabac_symbol_max_bins.restype = C.c_uint32
     L.isscabac_encode_symbols_dev.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
@@ -432,6 +440,58 @@ class Engine:
                                                   _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size,
                                                   _ptr(bins, _u8p), _ptr(status, _u32p)))
         return (bins if pitch == B else bins[:, :B].copy()), status
+
+    # ---- more than 255 contexts: 16-bit context indices, 0xFFFF = bypass (isscabac_*_batch16, ref: CommonDef.h:56) ----
+    def encode16(self, bins, ctx16, ctx_init, nbins=None):
+        """bins [S, B] uint8, ctx16 [S, B] uint16 (0xFFFF = bypass bin), up to 999 contexts.  Returns (payload, offsets)."""
+        bins = _np(bins, np.uint8)
+        ctx16 = _np(ctx16, np.uint16)
+        assert bins.ndim == 2 and bins.shape == ctx16.shape
+        S, B = bins.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        bins = self._pad_rows(bins, pitch)
+        cp = np.zeros((S, pitch), np.uint16)
+        cp[:, :B] = ctx16
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        cap = S * stream_bound(B)
+        payload, offsets = np.empty(cap, np.uint8), np.zeros(S + 1, np.uint64)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_batch16(self._h, _ptr(bins, _u8p), _ptr(cp, C.POINTER(C.c_uint16)), _ptr(nb, _u32p), S, B,
+                                                    pitch, _ptr(ci, _u8p), ci.size, _ptr(payload, _u8p), cap, _ptr(offsets, _u64p),
+                                                    C.byref(total)))
+        return payload[:int(total.value)].copy(), offsets
+
+    def decode16(self, payload, offsets, ctx16, ctx_init, nbins=None):
+        """Returns (bins uint8[S, B], status uint32[S])."""
+        payload = _np(payload, np.uint8)
+        offsets = _np(offsets, np.uint64)
+        ctx16 = _np(ctx16, np.uint16)
+        S, B = ctx16.shape
+        pitch = max(16, (B + 15) // 16 * 16)
+        cp = np.zeros((S, pitch), np.uint16)
+        cp[:, :B] = ctx16
+        ci = _np(ctx_init, np.uint8)
+        nb = None if nbins is None else _np(nbins, np.uint32)
+        bins, status = np.empty((S, pitch), np.uint8), np.zeros(S, np.uint32)
+        self._check(self._L.isscabac_decode_batch16(self._h, _ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(cp, C.POINTER(C.c_uint16)),
+                                                    _ptr(nb, _u32p), S, B, pitch, _ptr(ci, _u8p), ci.size, _ptr(bins, _u8p),
+                                                    _ptr(status, _u32p)))
+        return bins[:, :B].copy(), status
+
+    def encode16_dev(self, d_bins, d_ctx16, S, nbins, pitch, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0):
+        ci = _np(ctx_init, np.uint8)
+        total = C.c_uint64(0)
+        self._check(self._L.isscabac_encode_batch16_dev(self._h, _vp(d_bins), _vp(d_ctx16), _vp(d_nbins or 0), int(S), int(nbins),
+                                                        int(pitch), _ptr(ci, _u8p), ci.size, _vp(d_payload), int(payload_cap),
+                                                        _vp(d_offsets), C.byref(total)))
+        return int(total.value)
+
+    def decode16_dev(self, d_payload, payload_bytes, d_offsets, d_ctx16, S, nbins, pitch, ctx_init, d_bins_out, d_status=0, d_nbins=0):
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_decode_batch16_dev(self._h, _vp(d_payload), int(payload_bytes), _vp(d_offsets), _vp(d_ctx16),
+                                                        _vp(d_nbins or 0), int(S), int(nbins), int(pitch), _ptr(ci, _u8p), ci.size,
+                                                        _vp(d_bins_out), _vp(d_status or 0)))
 
     # ---- the same with the bins as bits on the host side (an eighth of their bytes over the PCIe link) --------------
     def encode_packed(self, bins_bits, ctx, ctx_init, nbins=None, out=None):

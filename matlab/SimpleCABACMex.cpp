@@ -12,6 +12,8 @@
 //   SimpleCABACMex('encodeBinProb', h, bin, p) / bin = ('decodeBinProb', h, p)       fixed probability p % of a 1 (ref: encodeBinProb)
 //   [payload, offsets] = ('encodeBatch', h, bins, ctx [, nbins])      bins/ctx: B x S uint8, one stream per column,
 //   [bins, status]     = ('decodeBatch', h, payload, offsets, ctx [, nbins])                        ctx 255 = bypass
+//       ctx as a uint16 matrix (65535 = bypass) takes handles of up to 999 contexts -- the reference's limit, CommonDef.h:56 --
+//       through isscabac_encode_batch16 / isscabac_decode_batch16
 //   [payload, offsets] = ('encodeBatchPacked', h, bits, ctx [, nbins])   bits: (ceil(B/16)*2) x S uint8, bin i of a column at
 //   [bits, status]     = ('decodeBatchPacked', h, payload, offsets, ctx [, nbins])      bit i % 8 of byte i / 8
 //   [payload, offsets, nbins]                         = ('encodeSymbols', h, sym, params [, nsym])   sym: R x S uint8 symbols,
@@ -147,6 +149,14 @@ const uint8_t *padded(const uint8_t *a, size_t B, size_t S, uint32_t pitch) {
   if (pitch == B) return a;
   uint8_t *p = scratch((size_t)pitch * S);
   for (size_t s = 0; s < S; s++) memcpy(p + s * pitch, a + s * B, B);
+  return p;
+}
+
+// ... and a B x S uint16 matrix of context indices (the batch commands' form for more than 255 contexts)
+const uint16_t *padded16(const uint16_t *a, size_t B, size_t S, uint32_t pitch) {
+  if (pitch == B) return a;
+  uint16_t *p = (uint16_t *)scratch((size_t)pitch * S * sizeof(uint16_t));
+  for (size_t s = 0; s < S; s++) memcpy(p + s * pitch, a + s * B, B * sizeof(uint16_t));
   return p;
 }
 
@@ -320,21 +330,25 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs < 4 || nrhs > 5) mexErrMsgTxt("Error: encodeBatch needs the handle, bins, ctx and optionally nbins\n");
     const uint8_t *bins = u8_arg(prhs[2], "Error: bins must be a uint8 matrix (one stream per column)\n");
-    const uint8_t *ctx = u8_arg(prhs[3], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const bool wide = mxIsClass(prhs[3], "uint16");  // 16-bit context indices: up to 999 contexts, 65535 = bypass
+    const uint8_t *ctx = wide ? NULL : u8_arg(prhs[3], "Error: ctx must be a uint8 (or, for more than 255 contexts, uint16) matrix (one stream per column)\n");
     const size_t B = mxGetM(prhs[2]), S = mxGetN(prhs[2]);
     if (mxGetM(prhs[3]) != B || mxGetN(prhs[3]) != S || B == 0 || S == 0) mexErrMsgTxt("Error: bins and ctx must have the same size\n");
-    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
+    if (!wide && h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: a uint8 ctx matrix names a context in one byte: at most 255 contexts (pass ctx as uint16)\n");
     const uint32_t *nb = u32_per_stream(nrhs == 5, nrhs == 5 ? prhs[4] : NULL, S, "Error: nbins must be uint32 with one entry per stream\n");
     // MATLAB's B x S column-major matrix is the ABI's stream-major layout; only the row pitch has to be a multiple of 16
     const uint32_t pitch = (uint32_t)((B + 15) / 16 * 16);
     bins = padded(bins, B, S, pitch);
-    ctx = padded(ctx, B, S, pitch);
+    if (!wide) ctx = padded(ctx, B, S, pitch);
     const uint64_t cap = S * isscabac_stream_bound((uint32_t)B);
     uint8_t *payload = scratch(cap);
     uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
     uint64_t total = 0;
     engine();
-    if (g_multi)
+    if (wide)
+      check(isscabac_encode_batch16(g_engine, bins, padded16((const uint16_t *)mxGetData(prhs[3]), B, S, pitch), nb, S, (uint32_t)B, pitch,
+                                    h->ctx_init.data(), (int)h->ctx_init.size(), payload, cap, offsets, &total), "encodeBatch");
+    else if (g_multi)
       check_multi(isscabac_multi_encode_batch(g_multi, bins, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(), (int)h->ctx_init.size(),
                                               payload, cap, offsets, &total), "encodeBatch");
     else
@@ -348,20 +362,24 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 5 || nrhs > 6) mexErrMsgTxt("Error: decodeBatch needs the handle, payload, offsets, ctx and optionally nbins\n");
     const uint8_t *payload = u8_arg(prhs[2], "Error: payload must be uint8\n");
     if (!mxIsClass(prhs[3], "double")) mexErrMsgTxt("Error: offsets must be double\n");
-    const uint8_t *ctx = u8_arg(prhs[4], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const bool wide = mxIsClass(prhs[4], "uint16");
+    const uint8_t *ctx = wide ? NULL : u8_arg(prhs[4], "Error: ctx must be a uint8 (or, for more than 255 contexts, uint16) matrix (one stream per column)\n");
     const size_t B = mxGetM(prhs[4]), S = mxGetN(prhs[4]);
     if (mxGetNumberOfElements(prhs[3]) != S + 1 || B == 0 || S == 0) mexErrMsgTxt("Error: offsets must have one entry per stream plus one\n");
-    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
+    if (!wide && h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: a uint8 ctx matrix names a context in one byte: at most 255 contexts (pass ctx as uint16)\n");
     uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
     for (size_t s = 0; s <= S; s++) offsets[s] = (uint64_t)mxGetPr(prhs[3])[s];
     if (offsets[S] > mxGetNumberOfElements(prhs[2])) mexErrMsgTxt("Error: offsets exceed the payload\n");
     const uint32_t *nb = u32_per_stream(nrhs == 6, nrhs == 6 ? prhs[5] : NULL, S, "Error: nbins must be uint32 with one entry per stream\n");
     const uint32_t pitch = (uint32_t)((B + 15) / 16 * 16);
-    ctx = padded(ctx, B, S, pitch);
+    if (!wide) ctx = padded(ctx, B, S, pitch);
     uint8_t *bins = scratch((size_t)pitch * S);
     uint32_t *status = (uint32_t *)scratch(S * sizeof(uint32_t));
     engine();
-    if (g_multi)
+    if (wide)
+      check(isscabac_decode_batch16(g_engine, payload, offsets, padded16((const uint16_t *)mxGetData(prhs[4]), B, S, pitch), nb, S, (uint32_t)B,
+                                    pitch, h->ctx_init.data(), (int)h->ctx_init.size(), bins, status), "decodeBatch");
+    else if (g_multi)
       check_multi(isscabac_multi_decode_batch(g_multi, payload, offsets, ctx, nb, S, (uint32_t)B, pitch, h->ctx_init.data(),
                                               (int)h->ctx_init.size(), bins, status), "decodeBatch");
     else
@@ -404,10 +422,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 5 || nrhs > 6) mexErrMsgTxt("Error: decodeBatchPacked needs the handle, payload, offsets, ctx and optionally nbins\n");
     const uint8_t *payload = u8_arg(prhs[2], "Error: payload must be uint8\n");
     if (!mxIsClass(prhs[3], "double")) mexErrMsgTxt("Error: offsets must be double\n");
-    const uint8_t *ctx = u8_arg(prhs[4], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const bool wide = mxIsClass(prhs[4], "uint16");
+    const uint8_t *ctx = wide ? NULL : u8_arg(prhs[4], "Error: ctx must be a uint8 (or, for more than 255 contexts, uint16) matrix (one stream per column)\n");
     const size_t B = mxGetM(prhs[4]), S = mxGetN(prhs[4]);
     if (mxGetNumberOfElements(prhs[3]) != S + 1 || B == 0 || S == 0) mexErrMsgTxt("Error: offsets must have one entry per stream plus one\n");
-    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
+    if (!wide && h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: a uint8 ctx matrix names a context in one byte: at most 255 contexts (pass ctx as uint16)\n");
     uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
     for (size_t s = 0; s <= S; s++) offsets[s] = (uint64_t)mxGetPr(prhs[3])[s];
     if (offsets[S] > mxGetNumberOfElements(prhs[2])) mexErrMsgTxt("Error: offsets exceed the payload\n");

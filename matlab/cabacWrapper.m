@@ -131,8 +131,10 @@ classdef cabacWrapper < handle
     end
 
     % ---- batches: B x S uint8 matrices, column s = stream s ------------------------------------------------------
+    % (a uint16 ctx matrix -- 65535 = bypass bin -- takes the up to 999 contexts of the reference's coder, CommonDef.h:56)
     function [payload, offsets] = encodeBatch(obj, bins, ctx, nbins)
-      args = {uint8(bins), uint8(ctx)};
+      if ~isa(ctx, 'uint16'), ctx = uint8(ctx); end
+      args = {uint8(bins), ctx};
       if nargin >= 4
         args{end + 1} = uint32(nbins);
       end
@@ -140,7 +142,8 @@ classdef cabacWrapper < handle
     end
 
     function [bins, status] = decodeBatch(obj, payload, offsets, ctx, nbins)
-      args = {uint8(payload), double(offsets), uint8(ctx)};
+      if ~isa(ctx, 'uint16'), ctx = uint8(ctx); end
+      args = {uint8(payload), double(offsets), ctx};
       if nargin >= 5
         args{end + 1} = uint32(nbins);
       end

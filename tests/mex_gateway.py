@@ -8,8 +8,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "_build", "libmex_gateway.so")
 SRCS = [os.path.join(ROOT, "matlab", "SimpleCABACMex.cpp"), os.path.join(ROOT, "tests", "mexstub", "mex_driver.cpp")]
-DOUBLE, UINT8, UINT32, CHAR = 0, 1, 2, 3
-_DT = {DOUBLE: np.float64, UINT8: np.uint8, UINT32: np.uint32}
+DOUBLE, UINT8, UINT32, CHAR, UINT16 = 0, 1, 2, 3, 4
+_DT = {DOUBLE: np.float64, UINT8: np.uint8, UINT32: np.uint32, UINT16: np.uint16}
 
 
 class MexError(RuntimeError):
@@ -64,6 +64,8 @@ class Gateway:
             cls = UINT8
         elif a.dtype == np.uint32:
             cls = UINT32
+        elif a.dtype == np.uint16:
+            cls = UINT16
         else:
             cls, a = DOUBLE, a.astype(np.float64)
         if a.ndim == 0:

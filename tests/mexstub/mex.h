@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-typedef enum { mxDOUBLE_CLASS, mxUINT8_CLASS, mxUINT32_CLASS, mxCHAR_CLASS } mxClassID;
+typedef enum { mxDOUBLE_CLASS, mxUINT8_CLASS, mxUINT32_CLASS, mxCHAR_CLASS, mxUINT16_CLASS } mxClassID;
 typedef enum { mxREAL } mxComplexity;
 
 struct mxArray {
@@ -37,11 +37,12 @@ void *mxCalloc(size_t n, size_t size);
 void *mxMalloc(size_t n);
 void mxFree(void *p);
 
-inline size_t mx_elsize(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : c == mxUINT32_CLASS ? 4 : 1; }
+inline size_t mx_elsize(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : c == mxUINT32_CLASS ? 4 : c == mxUINT16_CLASS ? 2 : 1; }
 inline bool mxIsClass(const mxArray *a, const char *name) {
   const std::string n(name);
   return (n == "double" && a->cls == mxDOUBLE_CLASS) || (n == "uint8" && a->cls == mxUINT8_CLASS) ||
-         (n == "uint32" && a->cls == mxUINT32_CLASS) || (n == "char" && a->cls == mxCHAR_CLASS);
+         (n == "uint32" && a->cls == mxUINT32_CLASS) || (n == "char" && a->cls == mxCHAR_CLASS) ||
+         (n == "uint16" && a->cls == mxUINT16_CLASS);
 }
 inline bool mxIsDouble(const mxArray *a) { return a->cls == mxDOUBLE_CLASS; }
 inline size_t mxGetM(const mxArray *a) { return a->m; }

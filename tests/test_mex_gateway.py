@@ -181,6 +181,21 @@ def test_more_than_255_contexts_per_bin_commands_only(gw, oracle, tmp_path):
         gw.call("encodeBin", h, 1.0, 999.0)
     with pytest.raises(MexError, match="at most 255 contexts"):
         gw.call("encodeBatch", h, np.zeros((16, 1), np.uint8), np.zeros((16, 1), np.uint8), nlhs=2)
+    # ... and so do the batch commands once ctx is a uint16 matrix (65535 = bypass bin): isscabac_*_batch16
+    S, B = 40, 210
+    c16 = rng.integers(0, C, (B, S)).astype(np.uint16)
+    c16[rng.random((B, S)) < 0.1] = 0xFFFF
+    c16[:5, 0] = [0, 255, 256, 511, 998]
+    bb = rng.integers(0, 2, (B, S)).astype(np.uint8)
+    payload, offsets = gw.call("encodeBatch", h, bb, c16, nlhs=2)
+    init = oracle.init_by_prob(p0)
+    offsets = offsets.ravel().astype(np.uint64)
+    for s in range(S):
+        kind = (c16[:, s] == 0xFFFF).astype(np.uint8)
+        want, _ = oracle.encode_ops(kind.tolist(), bb[:, s].tolist(), np.where(kind == 1, 0, c16[:, s]).tolist(), init)
+        assert payload.ravel()[int(offsets[s]):int(offsets[s + 1])].tobytes() == want.tobytes(), s
+    dec, status = gw.call("decodeBatch", h, payload, offsets.astype(np.float64), c16, nlhs=2)
+    assert (dec == bb).all() and (status == 0).all()
     with pytest.raises(MexError, match="invalid context initialization"):
         gw.call("initByProb", fn, np.full(1000, 0.5), nlhs=1)
     gw.call("delete", h)

@@ -26,7 +26,7 @@ import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIP_SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip"]
+HIP_SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_wide.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip"]
 
 
 def regs_of(tok):
