@@ -49,6 +49,21 @@ static int grow(isscabac_engine *e, void **p, uint64_t *have, uint64_t need) {
   return ISSCABAC_OK;
 }
 
+// the engine's four device words (cabac_internal.h: flag) and its pinned, device-mapped size words, once per engine
+static int ensure_words(isscabac_engine *e) {
+  if (!e->flag) {
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+    HIP_TRY(e, hipMemset(e->flag, 0, 16));
+  }
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocMapped));
+  if (!e->h_total_dev) {  // (the symbol calls may have allocated the block first: cabac_symbols.hip)
+    void *dv = nullptr;
+    HIP_TRY(e, hipHostGetDevicePointer(&dv, e->h_total, 0));
+    e->h_total_dev = static_cast<uint64_t *>(dv);
+  }
+  return ISSCABAC_OK;
+}
+
 extern "C" {
 
 int isscabac_abi_version(void) { return 2; }
@@ -288,7 +303,7 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
-  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  if ((rc = ensure_words(e))) return rc;
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 0, &ps))) return rc;
 
@@ -296,16 +311,22 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
   PROF_MARK(e, ps, 1);
+  // the payload size (offsets[S]) also lands in the engine's pinned word 0, written by the scan kernel itself: the host reads it
+  // after its synchronisation, no copy command in the stream
   if (scan_gather_is_fused(S)) {  // a handful of streams: offsets and payload in one launch (timed as the scan; the gather slot reads ~0)
-    HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
+    HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream, nullptr,
+                                  e->h_total_dev));
     PROF_MARK(e, ps, 2);
+  } else if (scan_gather_is_paired(S, e->flag + 2)) {  // up to 256 Ki streams: two launches instead of four (launch gaps are 5 % of a 64 Ki step)
+    HIP_TRY(e, launch_scan_partial_top(e->lens, S, d_offsets, e->scan_tmp, e->flag + 2, e->h_total_dev, e->stream));
+    PROF_MARK(e, ps, 2);
+    HIP_TRY(e, launch_gather_scan(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
   } else {
-    HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream));
+    HIP_TRY(e, launch_scan(e->lens, S, d_offsets, e->scan_tmp, e->stream, e->h_total_dev));
     PROF_MARK(e, ps, 2);
     HIP_TRY(e, launch_gather(e->slots, stride, e->lens, d_offsets, S, d_payload, payload_cap, e->stream));
   }
   PROF_MARK(e, ps, 3);
-  HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   e->pending_total = true;
   e->pending_cap = payload_cap;
   return ISSCABAC_OK;
@@ -346,19 +367,21 @@ int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload
   if (misaligned(d_ctx) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
   HIP_TRY(e, hipSetDevice(e->device));
-  if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+  if ((rc = ensure_words(e))) return rc;
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 1, &ps))) return rc;
-  HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+  // this call's flag word is zero: the previous call's second kernel left it so (the two words take turns)
+  uint32_t *flag = e->flag + e->flag_turn, *next_flag = e->flag + (e->flag_turn ^ 1);
+  e->flag_turn ^= 1;
   if ((rc = bucket_by_length(e, &sh, d_nbins))) return rc;
   PROF_MARK(e, ps, 0);
-  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag, e->stream));
+  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream));
   PROF_MARK(e, ps, 1);
   // streams that start with 0xFF (corrupt input): the reference's value register overflows on those, and only its own
   // formulation reproduces what it then decodes (cabac_lane.h: RefDec).  The kernel looks at the flag the decode kernel
   // left on the device and returns at once when it is clear, so the host never has to read it.
-  HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, e->flag,
-                                 e->stream));
+  HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream,
+                                 next_flag));
   return ISSCABAC_OK;
 }
 
@@ -410,7 +433,7 @@ int isscabac_encode_batch16_dev(isscabac_engine *e, const uint8_t *d_bins, const
   if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
-  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  if ((rc = ensure_words(e))) return rc;
   HIP_TRY(e, launch_encode_wide(d_bins, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init, e->wide_states, e->slots, stride,
                                 e->lens, e->stream));
   HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
@@ -612,7 +635,7 @@ static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *c
                              e->lens + s0, e->stream));
   }
   HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, dev_cap, e->stream));
-  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  if ((rc = ensure_words(e))) return rc;
   HIP_TRY(e, hipMemcpyAsync(e->h_total, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   const uint64_t total = *e->h_total;
@@ -659,7 +682,7 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
   if ((rc = grow(e, &e->stage[4], &e->stage_bytes[4], (S + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = grow(e, &e->stage[5], &e->stage_bytes[5], S * sizeof(uint32_t)))) return rc;
   if (packed && (rc = grow(e, &e->stage[6], &e->stage_bytes[6], in_bytes / 8))) return rc;
-  if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+  if ((rc = ensure_words(e))) return rc;
   uint8_t *d_out = static_cast<uint8_t *>(e->stage[0]), *d_ctx = static_cast<uint8_t *>(e->stage[1]);
   uint32_t *d_nb = nbins_per_stream ? static_cast<uint32_t *>(e->stage[2]) : nullptr;
   uint8_t *d_payload = static_cast<uint8_t *>(e->stage[3]);
@@ -672,7 +695,7 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
   if ((rc = up.upload(d_payload, payload, total))) return rc;
   if ((rc = up.upload(d_offsets, offsets, (S + 1) * sizeof(uint64_t)))) return rc;
   if (d_nb && (rc = up.upload(d_nb, nbins_per_stream, S * sizeof(uint32_t)))) return rc;
-  HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->flag + 3, 0, sizeof(uint32_t), e->stream));
   const uint64_t G = group_streams(S, pitch);
   for (uint64_t s0 = 0; s0 < S; s0 += G) {
     const uint64_t n = std::min(G, S - s0);
@@ -686,10 +709,10 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
     if ((uint64_t)(nbins + 127u) / 128u * 128u < pitch) HIP_TRY(e, hipMemsetAsync(d_out + s0 * pitch, 0, n * pitch, e->stream));
     // (offsets are positions in the whole payload: the group's kernels get the array from its first stream on)
     HIP_TRY(e, launch_decode(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, d_out + s0 * pitch,
-                             d_status + s0, e->flag, e->stream));
+                             d_status + s0, e->flag + 3, e->stream));
     // streams that start with 0xFF (corrupt input): redone in the reference's own formulation, see isscabac_decode_batch_dev
     HIP_TRY(e, launch_decode_exact(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr,
-                                   d_out + s0 * pitch, d_status + s0, e->flag, e->stream));
+                                   d_out + s0 * pitch, d_status + s0, e->flag + 3, e->stream));
     uint8_t *d_bits = static_cast<uint8_t *>(e->stage[6]);
     if (packed) HIP_TRY(e, launch_pack_bits(d_out + s0 * pitch, d_bits + s0 * (pitch / 8), n, pitch, e->stream));
     HIP_TRY(e, hipEventRecord(e->pipe_ev[1], e->stream));

@@ -32,7 +32,12 @@ struct isscabac_engine {
   uint64_t order_bytes = 0;
   void *order_tmp = nullptr;
   uint64_t order_tmp_cap = 0;
-  uint32_t *flag = nullptr;  // one word: "some stream needs the reference-formulation decoder" (see launch_decode_exact)
+  // four device words, zeroed at creation: [0], [1] "some stream needs the reference-formulation decoder" (launch_decode_exact) of
+  // the device-buffer decode calls, taking turns -- a call's second kernel zeroes the next call's word, no memset per call --,
+  // [2] the ticket of the two-launch offsets scan (k_scan_partial_top), [3] the same flag for the host-buffer and symbol calls
+  uint32_t *flag = nullptr;
+  int flag_turn = 0;
+  uint64_t *h_total_dev = nullptr;  // h_total as the device sees it (pinned, mapped)
   // staging for the host-buffer entry points
   void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // ([6]: bins as bits, packed forms)
   uint64_t stage_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -106,11 +111,20 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
                          uint8_t *d_slots, uint64_t slot_stride, uint32_t *d_lens, hipStream_t stream);
 // lens -> offsets (exclusive scan, S+1 entries); d_tmp needs scan_tmp_bytes(S)
 uint64_t scan_tmp_bytes(uint64_t S);
-hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream);
+// d_host_total (nullable): a pinned, device-mapped word that receives offsets[S] as well -- no copy of it afterwards
+hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream,
+                       uint64_t *d_host_total = nullptr);
+// medium batches (1 Ki < S <= 256 Ki, a ticket word given): scan + gather in two launches instead of four
+bool scan_gather_is_paired(uint64_t S, const uint32_t *d_ticket);
+hipError_t launch_scan_partial_top(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, uint32_t *d_ticket,
+                                   uint64_t *d_host_total, hipStream_t stream);
+hipError_t launch_gather_scan(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 // slots -> tight payload (streams whose range would exceed payload_cap are skipped)
 bool scan_gather_is_fused(uint64_t S);
 hipError_t launch_scan_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
-                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream, uint32_t *d_ticket = nullptr,
+                              uint64_t *d_host_total = nullptr);
 hipError_t launch_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, const uint64_t *d_offsets,
                          uint64_t S, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream);
 // decode: payload/offsets/ctx -> bins (+status)
@@ -123,7 +137,7 @@ hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_
 // returns at once when *d_flag (written by launch_decode on the same stream) is 0
 hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
                                const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
-                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream);
+                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream, uint32_t *d_next_flag = nullptr);
 // ragged batches: stream ids sorted by min(d_nbins[s], nbins), longest first (cabac_order.hip); d_tmp needs order_tmp_bytes(S)
 uint64_t order_tmp_bytes(uint64_t S);
 hipError_t launch_order(const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t *d_order, void *d_tmp, uint64_t tmp_bytes,

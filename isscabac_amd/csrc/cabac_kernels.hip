@@ -892,7 +892,9 @@ struct PrivateStates {
   __device__ uint32_t next_entry(uint32_t q) const { return c_next.e[q >> 2]; }
 };
 
-__global__ void __launch_bounds__(64) k_decode_exact(DecArgs a) {
+__global__ void __launch_bounds__(64) k_decode_exact(DecArgs a, uint32_t *next_flag) {
+  // (the flag word of the NEXT decode call on this engine, nobody's during this one: zeroed here instead of by a memset per call)
+  if (next_flag && blockIdx.x == 0 && threadIdx.x == 0) *next_flag = 0u;
   if (a.exact_flag && *a.exact_flag == 0u) return;  // k_decode saw no such stream: the usual case, a few microseconds
   const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (s >= a.S) return;
@@ -976,7 +978,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_top(uint64_t *bsum, uint6
 }
 
 __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t *lens, uint64_t S, const uint64_t *bsum,
-                                                             uint64_t *offsets) {
+                                                             uint64_t *offsets, uint64_t *host_total) {
   const uint64_t i0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)threadIdx.x * kScanItems;
   uint32_t l[kScanItems];
   uint64_t v = 0;
@@ -991,9 +993,14 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t *len
   for (int k = 0; k < kScanItems; k++) {
     if (i0 + k < S) offsets[i0 + k] = run;
     run += l[k];
-    if (i0 + k + 1 == S) offsets[S] = run;
+    if (i0 + k + 1 == S) {
+      offsets[S] = run;
+      if (host_total) *host_total = run;  // (a pinned, device-mapped word: the caller reads it after its synchronisation, no copy)
+    }
   }
 }
+
+
 
 // ------------------------------------------------------------------------------------------------
 // slots -> tight payload: 16 lanes per stream
@@ -1046,10 +1053,68 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *slots, uint64_t s
   if (s >= S) return;
   gather_stream(slots, slot_stride, s, (uint32_t)gid & (kGatherLps - 1u), lens[s], offsets[s], payload, cap);
 }
+
+// Medium batches (kScanBlock < S <= kScanFusedMax): the offsets scan and the gather in TWO launches instead of four.
+// k_scan_partial_top: every block leaves its sum, the block that arrives last (a ticket) scans the <= 256 sums in place and
+// writes the total; k_gather_scan: a gather block works out the offsets of its 16 streams itself -- the scanned sum of its
+// 1024-stream block + the lengths in front of it, at most 4 KiB read from L2 -- and stores them while it moves the bytes.
+constexpr uint64_t kScanFusedMax = 256ull * 1024;
+__global__ void __launch_bounds__(kScanThreads) k_scan_partial_top(const uint32_t *lens, uint64_t S, uint64_t *bsum, uint32_t nblk,
+                                                                   uint32_t *ticket, uint64_t *offsets_S, uint64_t *host_total) {
+  __shared__ bool s_last;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)threadIdx.x * kScanItems;
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++)
+    if (i0 + k < S) v += lens[i0 + k];
+  uint64_t tot;
+  block_excl_scan_u64(v, &tot);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&bsum[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == nblk - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const uint64_t mine = threadIdx.x < nblk ? __hip_atomic_load(&bsum[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;  // nblk <= 256
+  const uint64_t ex = block_excl_scan_u64(mine, &tot);
+  if (threadIdx.x < nblk) bsum[threadIdx.x] = ex;
+  if (threadIdx.x == 0) {
+    *offsets_S = tot;
+    if (host_total) *host_total = tot;
+    *ticket = 0u;  // for the next call
+  }
+}
+__global__ void __launch_bounds__(256) k_gather_scan(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens, const uint64_t *bsum,
+                                                     uint64_t S, uint64_t *offsets, uint8_t *payload, uint64_t cap) {
+  static_assert(kGatherLps == 16 && kScanBlock % 16 == 0, "a gather block's 16 streams lie inside one scan block");
+  __shared__ uint64_t s_part[4];
+  __shared__ uint32_t s_len[16];
+  const uint64_t first = (uint64_t)blockIdx.x * 16, sblk = first / kScanBlock, lo = sblk * kScanBlock;
+  const uint32_t cnt = (uint32_t)(first - lo);  // lengths in front of this block's streams inside their scan block: a multiple of 16
+  uint64_t v = 0;
+  if (4u * threadIdx.x < cnt) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(lens + lo + 4u * threadIdx.x);
+    v = (uint64_t)q.x + q.y + q.z + q.w;
+  }
+  v = wave_incl_scan_u64(v, threadIdx.x & 63);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = v;
+  const uint64_t s = first + threadIdx.x / 16;
+  const uint32_t li = threadIdx.x & 15u, len = s < S ? lens[s] : 0u;
+  if (li == 0) s_len[threadIdx.x / 16] = len;
+  __syncthreads();
+  uint64_t off = bsum[sblk] + s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  for (uint32_t j = 0; j < threadIdx.x / 16; j++) off += s_len[j];
+  if (s >= S) return;
+  if (li == 0) offsets[s] = off;
+  gather_stream(slots, slot_stride, s, li, len, off, payload, cap);
+}
 // Small batches (S <= kScanBlock: the reference's own use -- a handful of streams per call): offsets scan AND gather in one
 // single-block launch instead of four, the offsets handed from the scan to the gather through LDS
 __global__ void __launch_bounds__(kScanThreads) k_scan_gather_small(const uint8_t *slots, uint64_t slot_stride, const uint32_t *lens,
-                                                                    uint64_t S, uint64_t *offsets, uint8_t *payload, uint64_t cap) {
+                                                                    uint64_t S, uint64_t *offsets, uint8_t *payload, uint64_t cap,
+                                                                    uint64_t *host_total) {
   __shared__ uint64_t soff[kScanBlock + 1];
   const uint32_t i0 = threadIdx.x * kScanItems;
   uint32_t l[kScanItems];
@@ -1069,7 +1134,10 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_gather_small(const uint8_
     }
     run += l[k];
   }
-  if (threadIdx.x == 0) offsets[S] = tot;
+  if (threadIdx.x == 0) {
+    offsets[S] = tot;
+    if (host_total) *host_total = tot;
+  }
   __syncthreads();
   const uint32_t li = threadIdx.x & (kGatherLps - 1u);
   for (uint64_t s = threadIdx.x / kGatherLps; s < S; s += kScanThreads / kGatherLps) gather_stream(slots, slot_stride, s, li, lens[s], soff[s], payload, cap);
@@ -1236,11 +1304,11 @@ static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_pay
 
 hipError_t launch_decode_exact(const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
                                const uint64_t *d_offsets, const uint8_t *d_ctx, const uint32_t *d_nbins, uint8_t *d_bins_out,
-                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream) {
+                               uint32_t *d_status, const uint32_t *d_flag, hipStream_t stream, uint32_t *d_next_flag) {
   DecArgs a;
   fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status,
                 const_cast<uint32_t *>(d_flag));
-  hipLaunchKernelGGL(k_decode_exact, dim3((unsigned)((sh.S + 63) / 64)), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(k_decode_exact, dim3((unsigned)((sh.S + 63) / 64)), dim3(64), 0, stream, a, d_next_flag);
   return hipGetLastError();
 }
 
@@ -1302,25 +1370,45 @@ hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S
 
 uint64_t scan_tmp_bytes(uint64_t S) { return ((S + kScanBlock - 1) / kScanBlock + 1) * sizeof(uint64_t); }
 
-hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream) {
+hipError_t launch_scan(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, hipStream_t stream, uint64_t *d_host_total) {
   const uint64_t nblk = (S + kScanBlock - 1) / kScanBlock;
   uint64_t *bsum = static_cast<uint64_t *>(d_tmp);
   hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nblk), dim3(kScanThreads), 0, stream, d_lens, S, bsum);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanThreads), 0, stream, bsum, nblk);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(kScanThreads), 0, stream, d_lens, S, bsum, d_offsets);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk), dim3(kScanThreads), 0, stream, d_lens, S, bsum, d_offsets, d_host_total);
   return hipGetLastError();
 }
 
 bool scan_gather_is_fused(uint64_t S) { return S <= (uint64_t)kScanBlock; }
+bool scan_gather_is_paired(uint64_t S, const uint32_t *d_ticket) { return d_ticket && S > (uint64_t)kScanBlock && S <= kScanFusedMax; }
+// the two halves of the medium path, for callers that time them apart (scan_gather_is_paired() holds)
+hipError_t launch_scan_partial_top(const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets, void *d_tmp, uint32_t *d_ticket,
+                                   uint64_t *d_host_total, hipStream_t stream) {
+  const uint64_t nblk = (S + kScanBlock - 1) / kScanBlock;
+  hipLaunchKernelGGL(k_scan_partial_top, dim3((unsigned)nblk), dim3(kScanThreads), 0, stream, d_lens, S, static_cast<uint64_t *>(d_tmp),
+                     (uint32_t)nblk, d_ticket, d_offsets + S, d_host_total);
+  return hipGetLastError();
+}
+hipError_t launch_gather_scan(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream) {
+  hipLaunchKernelGGL(k_gather_scan, dim3((unsigned)((S + 15) / 16)), dim3(256), 0, stream, d_slots, slot_stride, d_lens,
+                     static_cast<const uint64_t *>(d_tmp), S, d_offsets, d_payload, payload_cap);
+  return hipGetLastError();
+}
 // lens -> offsets and slots -> payload: one launch for S <= kScanBlock streams, scan (3) + gather (1) otherwise
 hipError_t launch_scan_gather(const uint8_t *d_slots, uint64_t slot_stride, const uint32_t *d_lens, uint64_t S, uint64_t *d_offsets,
-                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream) {
+                              void *d_tmp, uint8_t *d_payload, uint64_t payload_cap, hipStream_t stream, uint32_t *d_ticket,
+                              uint64_t *d_host_total) {
   if (scan_gather_is_fused(S)) {
     hipLaunchKernelGGL(k_scan_gather_small, dim3(1), dim3(kScanThreads), 0, stream, d_slots, slot_stride, d_lens, S, d_offsets, d_payload,
-                       payload_cap);
+                       payload_cap, d_host_total);
     return hipGetLastError();
   }
-  const hipError_t err = launch_scan(d_lens, S, d_offsets, d_tmp, stream);
+  if (scan_gather_is_paired(S, d_ticket)) {
+    const hipError_t e1 = launch_scan_partial_top(d_lens, S, d_offsets, d_tmp, d_ticket, d_host_total, stream);
+    return e1 != hipSuccess ? e1 : launch_gather_scan(d_slots, slot_stride, d_lens, S, d_offsets, d_tmp, d_payload, payload_cap, stream);
+  }
+  const hipError_t err = launch_scan(d_lens, S, d_offsets, d_tmp, stream, d_host_total);
   return err != hipSuccess ? err : launch_gather(d_slots, slot_stride, d_lens, d_offsets, S, d_payload, payload_cap, stream);
 }
 

@@ -431,6 +431,12 @@ hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
 #ifndef ISSCABAC_DEC_PAIR
 #define ISSCABAC_DEC_PAIR 1
 #endif
+#ifndef ISSCABAC_DPAIR_TILE_PAIR
+#define ISSCABAC_DPAIR_TILE_PAIR 0  // the helper's ctx tile by lane pairs (TilePairT)
+#endif
+#ifndef ISSCABAC_DPAIR_PRIO_B
+#define ISSCABAC_DPAIR_PRIO_B 0  // the decoding wave's priority OUTSIDE its chunks (inside: ISSCABAC_DEC_PRIO)
+#endif
 
 namespace dpair {
 constexpr uint32_t kStates = 2048;
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
 
   if (wib == 0) {
     // -------------------------------------------------------------------------------------------- helper
-    using DTile = TileT<4>;
+    using DTile = std::conditional<ISSCABAC_DPAIR_TILE_PAIR != 0, TilePairT<4>, TileT<4>>::type;
     uint8_t *tile_c = smem + kTile;
     const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
     uint8_t *out_w = a.bins_out + s0 * a.pitch;
@@ -597,6 +603,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
   dec_start(d, src);
   if (valid && needs_ref_decoder(d.v >> 24) && a.exact_flag) *a.exact_flag = 1u;  // (k_decode_exact takes those streams)
   DecAbs da = dec_to_abs(d);
+  if (ISSCABAC_DPAIR_PRIO_B) __builtin_amdgcn_s_setprio(ISSCABAC_DPAIR_PRIO_B);
   __syncthreads();  // chunk 0 is there
   for (uint32_t c = 0; c < nchunks; c++) {
     const uint32_t i0 = c * 16u, cidx = c & 7u;
@@ -722,7 +729,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
           da = dec_to_abs(d);
         }
       }
-      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
+      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_DPAIR_PRIO_B);
     }
     obuf[OutBuf::idx(cidx, lane)] = od;
     __syncthreads();  // the chunk's bins are in the staging buffer; chunk c + 1 is in its slot

@@ -1028,7 +1028,7 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
   if (rc) return rc;
   // the size word comes back through the engine's pinned words (word 1: word 0 may belong to an asynchronous batch encode
   // that is still outstanding) -- a copy into pageable memory is staged by the runtime and costs tens of microseconds
-  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocDefault));
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocMapped));
   HIP_TRY(e, hipMemcpyAsync(e->h_total + 1, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   const uint64_t total = e->h_total[1];
@@ -1070,10 +1070,13 @@ static int dec_symbols_enqueue(isscabac_engine *e, const uint8_t *d_payload, uin
     // the code-tree kernel first; whatever it hands over (corrupt streams only) is decoded by the general kernel behind it,
     // which finds the hand-over marks on the device and returns at once when there are none
     if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
-    if (!e->flag) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
-    HIP_TRY(e, hipMemsetAsync(e->flag, 0, sizeof(uint32_t), e->stream));
+    if (!e->flag) {  // (cabac_internal.h: four words, zeroed; word 3 is this path's)
+      HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+      HIP_TRY(e, hipMemset(e->flag, 0, 16));
+    }
+    HIP_TRY(e, hipMemsetAsync(e->flag + 3, 0, sizeof(uint32_t), e->stream));
     a.redo = e->lens;
-    a.redo_any = e->flag;
+    a.redo_any = e->flag + 3;
     ta.a = a;
     const size_t wlds = sym_walk_lds_bytes(ta.trie.nodes, a.nctx, false);
     if (a.P.col_rows != 0 && a.P.selector != 0) {
