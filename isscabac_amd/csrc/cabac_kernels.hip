@@ -490,8 +490,15 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   for (int qb = tid; qb < 256; qb += blockDim.x) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin
     const uint32_t ps = (uint32_t)qb >> 1;
     const uint32_t sp = c_next.ep[ps >> 1] >> (16 * (ps & 1));  // byte 0: successor on the LPS path, byte 1: on the MPS path
+#if ISSCABAC_DEC_TAB_REPL
+    for (int r = 0; r < 4; r++) {
+      tab[8 * qb + 2 * r] = c_lps_rows[ps >> 1];
+      tab[8 * qb + 2 * r + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
+    }
+#else
     tab[2 * qb] = c_lps_rows[ps >> 1];
     tab[2 * qb + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
+#endif
   }
 #endif
   __syncthreads();
@@ -531,6 +538,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
   }
   LdsStates stx{wbase + lane * 4};
+  if (ISSCABAC_DEC_TAB_REPL) stx.rep = ((uint32_t)lane & 3u) << 3;
 
   // payload window
   uint64_t start = a.offsets[s];

@@ -36,6 +36,9 @@ namespace isscabac {
 #ifndef ISSCABAC_ENC_PAIR
 #define ISSCABAC_ENC_PAIR 1
 #endif
+#ifndef ISSCABAC_PAIR_ALT_ROLES
+#define ISSCABAC_PAIR_ALT_ROLES 0  // producer = wave (blockIdx & 1) of the workgroup instead of wave 0: successive workgroups put their
+#endif                             // producers on different SIMDs of the pair they share
 #ifndef ISSCABAC_PAIR_EXP  // timing experiments (wrong output, never in the product build): 1 = B skips its arithmetic, 2 = A skips
 #define ISSCABAC_PAIR_EXP 0  // the state pass, 3 = no barrier between the chunks
 #endif
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
   using namespace pairk;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0: producer (A), 1: consumer (B)
+  const int wib = __builtin_amdgcn_readfirstlane(((tid >> 6) ^ (ISSCABAC_PAIR_ALT_ROLES ? (int)blockIdx.x : 0)) & 1);  // 0: producer (A), 1: consumer (B)
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     const int ps = tid;  // 128 threads, 128 packed states

@@ -441,8 +441,12 @@ __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1
 // ------------------------------------------------------------------------------------------------
 // One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
 // pick, lane l only ever touches bank l % 32.  The tables are byte tables in LDS, read by absolute LDS address.
+#ifndef ISSCABAC_DEC_TAB_REPL
+#define ISSCABAC_DEC_TAB_REPL 0  // k_decode: four bank-partitioned copies of the raw-byte entry table, picked by lane & 3
+#endif
 struct LdsStates {
   uint8_t *base;  // wave's state region + lane * 4
+  uint32_t rep = 0;  // ISSCABAC_DEC_TAB_REPL: (lane & 3) * 8 -- the lane's copy of the decoder's entry table
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
   __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
@@ -498,7 +502,12 @@ struct LdsStates {
     return (uint64_t)row | (uint64_t)sp << 32;
 #else
 
+#if ISSCABAC_DEC_TAB_REPL
+    // entry qb of copy r at qb * 32 + r * 8: copy r only ever touches banks 2 r, 2 r + 1 (mod 8), a quarter of the 64
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)((qb << 5) + rep));
+#else
     return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3));
+#endif
 #endif
   }
   // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
@@ -626,7 +635,7 @@ constexpr bool kDecNTst = ISSCABAC_DEC_NT_ST != 0;  // ... and the bin stores
 
 // LDS of the decode kernel: the raw-byte entries (256 x 8 bytes, cabac_lane.h: dec_bin_out) at 0, then per wave the
 // context states, the round tile and (bucketed launches) the wave's stream ids
-constexpr int kDecTabBytes = 2048;
+constexpr int kDecTabBytes = ISSCABAC_DEC_TAB_REPL ? 8192 : 2048;
 
 // the digit flush of the encode kernels: digits leave `low` when some lane could overflow it within the next four bins
 #ifndef ISSCABAC_FLUSH_AT

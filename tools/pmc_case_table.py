@@ -7,9 +7,9 @@ import sys
 
 d = json.loads(subprocess.check_output([sys.executable, "tools/pmc_summary.py", sys.argv[1]]))
 S, B = int(sys.argv[2]), int(sys.argv[3])
-steps = (S // 64) * B  # wave-bins per launch
+steps = (S // 64) * B  # wave-bins per launch (one wave of streams x bins: the pair kernels run two waves per wave of streams)
 for k, x in d.items():
-    if k.startswith(("k_encode<", "k_decode<")):
+    if k.startswith(("k_encode<", "k_decode<", "k_encode_pair", "k_decode_pair")):
         g = lambda n: x.get(n, float("nan"))
         wc = g("SQ_WAVE_CYCLES")
         print("%-22s per wave-bin: VALU %.1f SALU %.1f LDS %.2f VMEM %.2f | LDS conflict %.0f%% | wave cyc/bin %.0f: active %.0f%% "

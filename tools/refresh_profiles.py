@@ -28,8 +28,8 @@ def update_traffic(summary, note):
 
 if sys.argv[1] == "--traffic-only":  # on the GPU box, between the PMC passes and the bench line (tools/evidence_run.sh)
     update_traffic(sys.argv[2], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build, same evidence run; reads = 2 x FETCH_SIZE "
-                   "(64 B tallied per 128-byte line fill: profiles/r04/fetch_calibration.txt); Infinity Cache hits included: an upper bound "
-                   "of the HBM bytes (see profiles/README.md)")
+                   "(64 B tallied per 128-byte line fill: profiles/r04/fetch_calibration.txt).  This is L2 <-> fabric traffic: fills served by "
+                   "the Infinity Cache are in it, and the HBM's own share cannot be measured with this pool's counters (profiles/r05/hbm_side.txt)")
     sys.exit(0)
 src, rnd = sys.argv[1], sys.argv[2]
 dst = "profiles/%s/" % rnd
@@ -40,8 +40,8 @@ for f in ("pmc_summary.json", "pmc_table.txt", "other_shapes.txt", "s_sweep.txt"
     if os.path.exists(src + "/" + f):
         shutil.copy(src + "/" + f, dst + "final_" + f)
 note = ("profiles/%s/final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; reads = 2 x FETCH_SIZE: the "
-        "counter tallies 64 B per 128-byte line fill, calibrated on known byte counts in profiles/r04/fetch_calibration.txt; the "
-        "fills include those served by the Infinity Cache, so this is an upper bound of the HBM bytes)" % rnd)
+        "counter tallies 64 B per 128-byte line fill, calibrated on known byte counts in profiles/r04/fetch_calibration.txt).  L2 <-> fabric "
+        "traffic: fills served by the Infinity Cache are in it; the HBM's own share is not measurable here (profiles/r05/hbm_side.txt)" % rnd)
 update_traffic(src + "/pmc_summary.json", note)
 b = json.load(open(src + "/bench.json"))
 print("value %.1f Gbin/s" % b["value"], b["kernels_ms"], "frac %.3f" % b["roofline"]["frac"], "cpu %.4f" % b["cpu_baseline"]["value"])
