@@ -556,6 +556,53 @@ CABAC_HD void enc_bin_prob(EncCore &e, uint32_t bin, uint32_t p, uint32_t row) {
   e.W += (int32_t)n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave-pair encoder (cabac_pair.hip: k_encode_pair) splits a bin between two waves: wave A runs the context-state pass
+// and leaves one RECORD per bin, wave B codes the records.  The split is exact because the states follow from bins and
+// contexts alone (ref: CABAC_ArithmeticEncoder.cpp:113-178 reads the state, never the other way round).
+//   record of a context-coded (or fixed-probability) bin: row = the state's rangeTabLps row, m = ~0 if the bin is not the mps
+//   PLAIN / MIXED chunks: a bypass bin is row 0, m 0 (its range passes through untouched) with ext = 1 (its one bit of shift)
+//                         and addm = ~0 if the bin is 1 (`low` gains the range, ref: :250-270)
+//   GENERAL chunks:       the row word itself says what the bin is: kEncRecNone (nothing: past the stream's end or an
+//                         invalid index), kEncRecBypass | bin << 1, or a row (real rows have no zero byte: they are >= 4)
+// enc_rec_t: what A reads off the entry's high word (enc_entry_hi) for a bin: low byte = successor state, bits 16..23 = the
+// flag byte "this bin is not the state's mps" (0x00 / 0xFF).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kEncRecNone = 0u, kEncRecBypass = 1u;
+CABAC_HD uint32_t enc_rec_t(uint32_t entry_hi, uint32_t bin) { return entry_hi >> (8u * bin); }
+CABAC_HD void enc_rec_plain(EncCore &e, EncWordAcc &g, bool first, uint32_t row, uint32_t m) {
+  const uint32_t lps = lps_of(row, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t n = clz32(r) - 23u;
+  g.T = ((first ? 0u : g.T) + (rmps & m)) << n;
+  g.S = (first ? 0u : g.S) + n;
+  e.range = shl16(r, n);
+}
+CABAC_HD void enc_rec_mixed(EncCore &e, EncWordAcc &g, bool first, uint32_t row, uint32_t m, uint32_t ext, uint32_t addm) {
+  const uint32_t lps = lps_of(row, e.range);  // a bypass bin: 0
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);  // ... the range itself
+  const uint32_t n = clz32(r) - 23u;             // ... 0
+  const uint32_t nt = n + ext;
+  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + (e.range & addm);
+  g.S = (first ? 0u : g.S) + nt;
+  e.range = shl16(r, n);
+}
+CABAC_HD void enc_rec_general(EncCore &e, uint32_t row, uint32_t m) {
+  if (row >= 4u) {  // enc_bin_at_mem / enc_bin_prob: the same arithmetic
+    const uint32_t lps = lps_of(row, e.range);
+    const uint32_t rmps = e.range - lps;
+    const uint32_t r = select_mask(m, lps, rmps);
+    const uint32_t n = clz32(r) - 23u;
+    e.low = (e.low + (rmps & m)) << n;
+    e.range = r << n;
+    e.W += (int32_t)n;
+  } else if (row & 1u) {
+    enc_bin_ep(e, row >> 1);
+  }
+}
+
 // one 9-bit lead value through the outstanding-byte logic of writeOut, ref: :388-411
 template <class Sink>
 CABAC_HD void enc_lead(EncCore &e, uint32_t lead, Sink &out) {

@@ -65,8 +65,7 @@ constexpr uint32_t kSlotRows = 4096, kSlotBytes = kSlotRows + 512;
 constexpr uint32_t kLdsBytes = kRing + 2 * kSlotBytes;
 static_assert(kLdsBytes == 19712 && 8 * kLdsBytes <= 160 * 1024, "eight workgroups per CU");
 constexpr uint32_t kPlain = 0, kGeneral = 1, kMixed = 2;
-// a GENERAL record's row word when the bin is no context / fixed-probability bin: real rows have no zero byte
-constexpr uint32_t kRecNone = 0u, kRecBypass = 1u;  // bypass: 1 | bin << 1
+constexpr uint32_t kRecNone = kEncRecNone, kRecBypass = kEncRecBypass;  // (cabac_lane.h: the records and B's steps, shared with the host harness)
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -329,13 +328,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
         for (int k = 0; k < 4; k++) {
           const int i = 4 * g + k;
           const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(i < 8 ? f0 : f1, 16 + (i & 7), 1);  // ~0: the bin is not its state's mps
-          const uint32_t lps = lps_of(word_of(rw, k), e.range);
-          const uint32_t rmps = e.range - lps;
-          const uint32_t r = select_mask(m, lps, rmps);
-          const uint32_t nn = clz32(r) - 23u;
-          acc.T = ((k == 0 ? 0u : acc.T) + (rmps & m)) << nn;
-          acc.S = (k == 0 ? 0u : acc.S) + nn;
-          e.range = shl16(r, nn);
+          enc_rec_plain(e, acc, k == 0, word_of(rw, k), m);
         }
         enc_word_close(e, acc);
         if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
@@ -352,15 +345,8 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
         for (int k = 0; k < 4; k++) {
           const int i = 4 * g + k;
           const uint32_t f = i < 8 ? f0 : f1;
-          const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(f, 16 + (i & 7), 1);
-          const uint32_t lps = lps_of(word_of(rw, k), e.range);
-          const uint32_t rmps = e.range - lps;
-          const uint32_t r = select_mask(m, lps, rmps);
-          const uint32_t nn = clz32(r) - 23u;
-          const uint32_t nt = nn + __builtin_amdgcn_ubfe(f, i & 7, 1);
-          acc.T = (((k == 0 ? 0u : acc.T) + (rmps & m)) << nt) + (e.range & (uint32_t)__builtin_amdgcn_sbfe(f, 8 + (i & 7), 1));
-          acc.S = (k == 0 ? 0u : acc.S) + nt;
-          e.range = shl16(r, nn);
+          enc_rec_mixed(e, acc, k == 0, word_of(rw, k), (uint32_t)__builtin_amdgcn_sbfe(f, 16 + (i & 7), 1), __builtin_amdgcn_ubfe(f, i & 7, 1),
+                        (uint32_t)__builtin_amdgcn_sbfe(f, 8 + (i & 7), 1));
         }
         enc_word_close(e, acc);
         if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
@@ -372,19 +358,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int i = 4 * g + k;
-          const uint32_t row = word_of(rw, k);
-          if (row >= 4u) {  // a context-coded or fixed-probability bin (enc_bin_at_mem / enc_bin_prob: the same arithmetic)
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(i < 8 ? f0 : f1, 16 + (i & 7), 1);
-            const uint32_t lps = lps_of(row, e.range);
-            const uint32_t rmps = e.range - lps;
-            const uint32_t r = select_mask(m, lps, rmps);
-            const uint32_t nn = clz32(r) - 23u;
-            e.low = (e.low + (rmps & m)) << nn;
-            e.range = r << nn;
-            e.W += (int32_t)nn;
-          } else if (row & 1u) {
-            enc_bin_ep(e, row >> 1);
-          }
+          enc_rec_general(e, word_of(rw, k), (uint32_t)__builtin_amdgcn_sbfe(i < 8 ? f0 : f1, 16 + (i & 7), 1));
         }
         if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
       }

@@ -258,6 +258,94 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   return sink.len <= cap ? (long)sink.len : -1;
 }
 
+// The wave-pair encoder (cabac_pair.hip: k_encode_pair) on the host: wave A's record production restated over plain arrays
+// (the device code is LDS plumbing and inline assembly around exactly these rules), wave B's steps THE SAME functions the
+// kernel calls (cabac_lane.h: enc_rec_plain / enc_rec_mixed / enc_rec_general), with the kernel's chunk classification and
+// flush cadence.  nmin: the shortest stream of the lane's wave (a chunk is plain / mixed only if it lies inside every lane's
+// stream; pass n for a uniform batch, 0 to force the general records everywhere).  kinds[3] (nullable) counts the chunks by
+// kind: plain, general, mixed.
+long lane_encode_stream_pair(const uint8_t *bins, const uint8_t *ctx, uint32_t n, uint32_t nmin, const uint8_t *ctx_init, int nctx,
+                             uint8_t *out, size_t cap, uint32_t *kinds) {
+  if (nctx > 64) return -3;  // (the pair serves batches of up to 64 contexts)
+  HostStates st;
+  st.init(ctx_init, nctx);
+  uint8_t dummy = 0;  // the bypass bins' context in mixed chunks: only ever receives the all-zero entry's successor
+  HostSink sink{out, 0, cap};
+  EncCore e;
+  enc_start(e);
+  for (uint32_t i0 = 0; i0 < n; i0 += 16) {
+    uint8_t cb[16] = {0}, bb[16] = {0};
+    for (uint32_t k = 0; k < 16 && i0 + k < n; k++) {
+      cb[k] = ctx[i0 + k];
+      bb[k] = bins[i0 + k] & 1u;
+    }
+    const bool full = i0 + 16 <= nmin;
+    bool hi = false, odd = false;  // chunk_not_plain<1>: some byte >= 64; odd_high_bytes: bit 7 set without being 0xFF
+    for (int k = 0; k < 16; k++) {
+      hi |= (cb[k] & 0xC0u) != 0;
+      odd |= (cb[k] & 0x80u) && cb[k] != 0xFFu;
+    }
+    uint32_t row[16], m[16], ext[16] = {0}, addm[16] = {0};
+    int kind;
+    if (full && (!hi || !odd)) {
+      kind = hi ? 2 : 0;
+      for (int k = 0; k < 16; k++) {
+        const bool byp = hi && (cb[k] & 0x80u);
+        // A's lookup: the state byte (a bypass bin: the dummy's, or-ed with 0xFE -> the all-zero entry of state 63)
+        const uint32_t q = byp ? (dummy | 0xFEu) : st.load(cb[k] & 0x3Fu);
+        const uint64_t ent = st.entry_mem(q);
+        const uint32_t t = enc_rec_t((uint32_t)(ent >> 32), bb[k]);
+        if (byp) dummy = (uint8_t)t;
+        else st.store(cb[k] & 0x3Fu, t);
+        row[k] = (uint32_t)ent;
+        m[k] = (t & 0x00010000u) ? ~0u : 0u;
+        ext[k] = byp ? 1u : 0u;
+        addm[k] = (byp && bb[k]) ? ~0u : 0u;
+      }
+    } else {
+      kind = 1;
+      for (uint32_t k = 0; k < 16; k++) {
+        row[k] = kEncRecNone;
+        m[k] = 0;
+        if (!(full || i0 + k < n)) continue;
+        const uint32_t c = cb[k];
+        if (c < 64u) {
+          const uint64_t ent = st.entry_mem(st.load(c));
+          const uint32_t t = enc_rec_t((uint32_t)(ent >> 32), bb[k]);
+          st.store(c, t);
+          row[k] = (uint32_t)ent;
+          m[k] = (t & 0x00010000u) ? ~0u : 0u;
+        } else if (c == kBypass || c == kProbBase + 50u) {
+          row[k] = kEncRecBypass | (uint32_t)bb[k] << 1;
+        } else if (is_prob_byte(c) && prob_valid(c - kProbBase)) {
+          row[k] = kProbRow[prob_row_index(c - kProbBase)];
+          m[k] = bb[k] != (c - kProbBase > 50u ? 1u : 0u) ? ~0u : 0u;
+        }
+      }
+    }
+    if (kinds) kinds[kind]++;
+    // wave B
+    for (int g = 0; g < 4; g++) {
+      EncWordAcc acc{0, 0};
+      for (int k = 0; k < 4; k++) {
+        const int i = 4 * g + k;
+        if (kind == 0) enc_rec_plain(e, acc, k == 0, row[i], m[i]);
+        else if (kind == 2) enc_rec_mixed(e, acc, k == 0, row[i], m[i], ext[i], addm[i]);
+        else enc_rec_general(e, row[i], m[i]);
+      }
+      if (kind != 1) {
+        if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
+        enc_word_close(e, acc);
+      }
+      if (e.W >= 39) enc_flush16_wave(e, sink);
+      if (e.W > 62) return -2;
+    }
+  }
+  enc_flush16(e, sink);
+  enc_finish16(e, sink);
+  return sink.len <= cap ? (long)sink.len : -1;
+}
+
 // the stream's payload is buf[start, start+len) inside a buffer of `total` bytes.
 // chunk = bins per boundary() (kernel: 16), group = bins per top-up (kernel: 4)
 uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx,

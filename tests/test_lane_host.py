@@ -26,6 +26,8 @@ def lane():
     L.lane_encode_stream.restype = C.c_long
     L.lane_encode_stream.argtypes = [u8p, u8p, C.c_uint32, u8p, C.c_int, C.c_int, u8p, C.c_size_t, u8p,
                                      C.POINTER(C.c_int)]
+    L.lane_encode_stream_pair.restype = C.c_long
+    L.lane_encode_stream_pair.argtypes = [u8p, u8p, C.c_uint32, C.c_uint32, u8p, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.lane_decode_stream.restype = C.c_uint32
     L.lane_decode_stream.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_int,
                                      C.c_int, u8p, u8p, C.POINTER(C.c_uint32)]
@@ -425,3 +427,51 @@ def test_fixed_probability_bins_match_the_reference(lane):
         for group in (4, 2, 3, 5, 6):
             dec, st, dfin, _ = lane_decode(lane, unhex(s["payload"]), ctx, init, pad_front=2, pad_back=3, group=group)
             assert st == 0 and (dec == bins).all() and dfin.tobytes().hex() == s["ctx_final"], (s["name"], group)
+
+
+def lane_encode_pair(L, bins, ctx, init, nmin=None):
+    """the wave-pair encoder's record production + consumption (lane_harness.cpp: lane_encode_stream_pair)"""
+    bins, ctx, init = (np.ascontiguousarray(a, np.uint8) for a in (bins, ctx, init))
+    out = np.zeros((6 * bins.size + 9 + 7) // 8 + 64, np.uint8)
+    kinds = (C.c_uint32 * 3)()
+    n = L.lane_encode_stream_pair(_p(bins), _p(ctx), bins.size, bins.size if nmin is None else nmin, _p(init), init.size, _p(out),
+                                  out.size, kinds)
+    assert n >= 0, n
+    return out[:n], list(kinds)
+
+
+def test_pair_encoder_records_and_consumer_steps_equal_the_oracle(lane, oracle, golden):
+    """k_encode_pair's split on the host: wave A's records (context-state pass, dummy context for bypass bins, general
+    classification) and wave B's steps -- the very functions the kernel calls -- give the oracle's bytes on every golden
+    stream of at most 64 contexts and on fuzzed plain, mixed, ragged and fixed-probability streams."""
+    done = 0
+    for s in golden["streams"]:
+        if len(s["ctx_init_a"]) > 64:
+            continue
+        for nmin in (None, 0):  # the kernel's classification, and every chunk through the general records
+            out, _ = lane_encode_pair(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], nmin)
+            assert out.tobytes() == bytes(s["payload_a"]), s["name"]
+        done += 1
+    assert done >= 10
+    rng = np.random.default_rng(77)
+    seen = [0, 0, 0]
+    for it in range(300):
+        nctx = int(rng.choice([1, 3, 23, 64]))
+        n = int(rng.choice([0, 1, 15, 16, 17, 64, 333, 1000]))
+        init = rng.integers(0, 126, nctx).astype(np.uint8)
+        ctx = rng.integers(0, nctx, n).astype(np.uint8)
+        mode = it % 4
+        if mode >= 1:
+            ctx[rng.random(n) < (0.5 if mode == 1 else 0.05)] = 0xFF
+        if mode == 3 and n:  # fixed-probability bins send their chunks through the general records
+            where = rng.random(n) < 0.1
+            ctx[where] = (155 + rng.choice([1, 10, 30, 45, 50, 55, 70, 99], int(where.sum()))).astype(np.uint8)
+        skew = rng.random(nctx + 1) ** int(rng.integers(1, 5))
+        bins = (rng.random(n) < skew[np.minimum(ctx, nctx)]).astype(np.uint8)
+        want = oracle.encode_stream(bins, ctx, init)
+        nmin = n if it % 5 else int(rng.integers(0, n + 1))  # a shorter neighbour: the tail goes through the general records
+        got, kinds = lane_encode_pair(lane, bins, ctx, init, nmin)
+        assert got.tobytes() == want.tobytes(), (it, nctx, n, mode)
+        seen = [a + b for a, b in zip(seen, kinds)]
+    assert all(k > 50 for k in seen), seen  # plain, general and mixed chunks all ran
+    assert lane.lane_word_shift_max() <= 22
