@@ -746,9 +746,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                 const int i = 4 * g + k;
                 if (k == 0) {  // right behind the top-up: R's leading one is bit 31
                   psel = da.R >> 29;
-                  psh = 23u;
+                  psh = ISSCABAC_DEC_LAT_MAD ? 0xFF800000u : 23u;  // the comparison point, or (ISSCABAC_DEC_LAT_MAD) -(1 << it)
                 }
-                const uint32_t nx = dec_bin_nx_abs_at(da, ent, psel, psh);
+                const uint32_t nx = ISSCABAC_DEC_LAT_MAD ? dec_bin_nx_abs_at_mad(da, ent, psel, psh) : dec_bin_nx_abs_at(da, ent, psel, psh);
                 if (i < 15) {
                   uint32_t qn;
                   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
@@ -769,7 +769,10 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                 else if (k == 2) put_out_byte<2>(oa, ob, nx);
                 else put_out_byte<3>(oa, ob, nx);
                 if (i < 14) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_n2), "v"(at_nxt));
-                if (k < 3) abs_positions(da.R, psel, psh);
+                if (k < 3) {
+              if (ISSCABAC_DEC_LAT_MAD) abs_positions_neg(da.R, psel, psh);
+              else abs_positions(da.R, psel, psh);
+            }
                 at_cur = at_nxt;
                 at_nxt = at_n2;
                 qld_nxt = qld_n2;

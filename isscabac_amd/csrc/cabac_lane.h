@@ -1178,6 +1178,44 @@ CABAC_HD uint32_t dec_bin_nx_abs_at(DecAbs &a, uint64_t ent, uint32_t sel, uint3
 #endif
   return nx;
 }
+// The same with the LPS term subtracted by ONE multiply-add: (range - LPS) << sh = R - LPS * 2^sh = R + LPS * negp with
+// negp = -(1 << sh) (fits the signed 24-bit operand of v_mad_i32_i24: sh <= 23), so that the chain from the entry's arrival to
+// the decision is perm -> mad -> sub-with-borrow instead of perm -> shift -> sub -> sub-with-borrow; LPS << sh itself (the
+// new R on the LPS path) is R - that, beside the chain.  negp is worked out with the positions, in the entry read's shadow.
+#ifndef ISSCABAC_DEC_LAT_MAD
+#define ISSCABAC_DEC_LAT_MAD 0
+#endif
+CABAC_HD void abs_positions_neg(uint32_t R, uint32_t &sel, uint32_t &negp) {
+  const uint32_t t = 29u - clz32(R);  // sh + 6
+  sel = R >> t;
+  negp = ~0u << (t - 6u);
+}
+CABAC_HD uint32_t dec_bin_nx_abs_at_mad(DecAbs &a, uint64_t ent, uint32_t sel, uint32_t negp) {
+  const uint32_t lps = lps_col((uint32_t)ent, sel);
+  uint32_t rmps, nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(rmps) : "v"(lps), "v"(negp), "v"(a.R));
+  const uint32_t lpss = a.R - rmps;
+  uint32_t diff, r;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(a.v), "v"(rmps), "v"((uint32_t)(ent >> 32)), "v"(lpss)
+      : "vcc");
+  a.v = diff;
+  a.R = r;
+#else
+  rmps = a.R + lps * negp;
+  const uint32_t lpss = a.R - rmps;
+  const bool mps_path = a.v < rmps;
+  nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
+  a.R = mps_path ? rmps : lpss;
+  a.v = mps_path ? a.v : a.v - rmps;
+#endif
+  return nx;
+}
 template <bool FIRST>
 CABAC_HD uint32_t dec_bin_nx_abs_ent(DecAbs &a, uint64_t ent) {
   uint32_t sel = a.R >> 29, sh = 23u;
