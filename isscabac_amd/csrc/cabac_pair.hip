@@ -408,6 +408,9 @@ hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
 #ifndef ISSCABAC_DEC_PAIR
 #define ISSCABAC_DEC_PAIR 1
 #endif
+#ifndef ISSCABAC_DPAIR_ALT_ROLES
+#define ISSCABAC_DPAIR_ALT_ROLES 0  // helper = wave (blockIdx & 1) of the workgroup instead of wave 0
+#endif
 #ifndef ISSCABAC_DPAIR_TILE_PAIR
 #define ISSCABAC_DPAIR_TILE_PAIR 0  // the helper's ctx tile by lane pairs (TilePairT)
 #endif
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
   using pairk::put_rows;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0: helper (A), 1: decoder (B)
+  const int wib = __builtin_amdgcn_readfirstlane(((tid >> 6) ^ (ISSCABAC_DPAIR_ALT_ROLES ? (int)blockIdx.x : 0)) & 1);  // 0: helper (A), 1: decoder (B)
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     for (int qb = tid; qb < 256; qb += 128) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin (k_decode)
