@@ -271,6 +271,18 @@ typedef struct isscabac_symbol_stats {
   uint32_t *bin_trace;
   uint32_t bin_trace_pitch;
 } isscabac_symbol_stats;
+/* Asynchronous forms (as isscabac_encode_batch_dev_async / isscabac_decode_batch_dev_async): the calls only enqueue on the
+ * engine's stream, so that symbol batch after symbol batch -- or encode -> decode -- runs with no host wait in between;
+ * isscabac_sync() waits and reports the payload size / a capacity overflow of the most recent asynchronous encode (batch or
+ * symbol).  payload_bytes of the decode only bounds its memory accesses (the buffer's capacity will do). */
+int isscabac_encode_symbols_dev_async(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
+                                      uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,
+                                      const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
+                                      uint64_t *d_offsets, uint32_t *d_nbins_out);
+int isscabac_decode_symbols_dev_async(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes,
+                                      const uint64_t *d_offsets, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
+                                      uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
+                                      int nctx, uint8_t *d_sym_out, uint32_t *d_status);
 /* as isscabac_encode_symbols_dev, d_stats->* are device pointers */
 int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S,
                                       uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params,

@@ -56,6 +56,7 @@ struct isscabac_engine {
   // small symbol batches: one pinned, device-mapped block the kernels read and write directly (cabac_symbols.hip)
   uint8_t *sym_pin = nullptr;
   uint64_t sym_pin_bytes = 0;
+  size_t sym_cnt_lds = 0;  // dynamic LDS granted to the statistics kernel so far (cabac_symbols.hip: k_encode_symbols<true>)
   // what isscabac_sync has to report about the most recent (async) encode
   uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]
   uint64_t pending_cap = 0;

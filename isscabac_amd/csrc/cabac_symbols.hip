@@ -145,6 +145,10 @@ __device__ __forceinline__ void sym_init_common(uint8_t *smem, uint32_t *&tab, u
   wbase = smem + tab_bytes + (tid >> 6) * wave_bytes;
 }
 
+// LDSCNT: the two per-context counters of the statistics live in the LDS behind the waves' regions, [counter][context][lane]
+// 32-bit words, and go out once at the end -- counted in global memory every bin waits for its own read-modify-write
+// (config 4 at its real size: 0.93 ms per encode with the statistics against 0.16 without)
+template <bool LDSCNT>
 __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -178,9 +182,15 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   uint32_t *hist = a.ctx_hist ? a.ctx_hist + s * ISSCABAC_STAT_CTX : nullptr;
   uint32_t *cost = a.ctx_cost ? a.ctx_cost + s * ISSCABAC_STAT_CTX : nullptr;
   uint16_t *hbits = a.sym_bits ? a.sym_bits + s * a.pitch : nullptr;
-  for (uint32_t c = 0; c < ISSCABAC_STAT_CTX; c++) {
-    if (hist) hist[c] = 0;
-    if (cost) cost[c] = 0;
+  uint32_t *cnt = nullptr;
+  if constexpr (LDSCNT) {
+    cnt = reinterpret_cast<uint32_t *>(smem + kSymTab + kSymWaves * kSymWaveBytes + (tid >> 6) * (a.nctx * 512u)) + lane;
+    for (uint32_t c = 0; c < 2 * a.nctx; c++) cnt[c * 64] = 0;
+  } else {
+    for (uint32_t c = 0; c < ISSCABAC_STAT_CTX; c++) {
+      if (hist) hist[c] = 0;
+      if (cost) cost[c] = 0;
+    }
   }
   uint32_t sym_start = 0;
   while (w.idx < n_my) {
@@ -210,8 +220,15 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
     if (want_stats) enc_flush(e, sink);
     else if (CABAC_WAVE_ANY(e.W >= 39)) enc_flush(e, sink);
     nbins++;
-    if (hist) hist[c]++;
-    if (cost) cost[c] += 8u * (sink.pos - before);
+    if constexpr (LDSCNT) {
+      if (c < a.nctx) {
+        cnt[c * 64]++;
+        cnt[(a.nctx + c) * 64] += 8u * (sink.pos - before);
+      }
+    } else {
+      if (hist) hist[c]++;
+      if (cost) cost[c] += 8u * (sink.pos - before);
+    }
     if (w.n == w.cur.len) {
       if (hbits) hbits[w.idx] = (uint16_t)(8u * (sink.pos - sym_start));
       w.next_symbol(a.P);
@@ -221,6 +238,12 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   }
   if (hbits)
     for (uint32_t i = n_my; i < a.nsym; i++) hbits[i] = 0;
+  if constexpr (LDSCNT) {
+    for (uint32_t c = 0; c < ISSCABAC_STAT_CTX; c++) {
+      if (hist) hist[c] = c < a.nctx ? cnt[c * 64] : 0u;
+      if (cost) cost[c] = c < a.nctx ? cnt[(a.nctx + c) * 64] : 0u;
+    }
+  }
   enc_finish(e, sink);
   sink.close();
   a.lens[s] = sink.pos;
@@ -962,10 +985,26 @@ int isscabac_encode_symbols_dev(isscabac_engine *e, const uint8_t *d_sym, const 
 }
 
 // the encode kernel + the offsets scan + the payload gather of one batch, enqueued on the engine's stream (no synchronisation)
+// the engine's four device words and pinned size words (cabac_internal.h: flag, h_total), as cabac_capi.cpp sets them up
+static int sym_ensure_words(isscabac_engine *e) {
+  if (!e->flag) {
+    HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
+    HIP_TRY(e, hipMemset(e->flag, 0, 16));
+  }
+  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocMapped));
+  if (!e->h_total_dev) {
+    void *dv = nullptr;
+    HIP_TRY(e, hipHostGetDevicePointer(&dv, e->h_total, 0));
+    e->h_total_dev = static_cast<uint64_t *>(dv);
+  }
+  return ISSCABAC_OK;
+}
+
+// (host_word: which of the engine's pinned size words receives offsets[S], written by the scan kernel itself; < 0: none)
 static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
                                uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
                                uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint32_t *d_nbins_out,
-                               const isscabac_symbol_stats *d_stats) {
+                               const isscabac_symbol_stats *d_stats, int host_word = -1) {
   // a statistics block with nothing asked for is no statistics block: the code-tree kernel serves the call (the host form
   // always hands one over, and ran the general kernel for that reason alone: config 4 at its real size 0.58 ms per encode)
   if (d_stats && !d_stats->ctx_hist && !d_stats->ctx_cost && !d_stats->sym_bits && !d_stats->bin_trace) d_stats = nullptr;
@@ -1010,11 +1049,30 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
       hipLaunchKernelGGL(k_encode_symbols_trie<false>, dim3((unsigned)nblk), dim3(256), wlds, e->stream, ta);
     }
   } else {
-    if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols)))) return rc;
-    hipLaunchKernelGGL(k_encode_symbols, dim3((unsigned)nblk), dim3(256), kSymTab + kSymWaves * kSymWaveBytes, e->stream, a);
+    // counters in the LDS when some are asked for and the device grants the room (at most 64 contexts: 150 KiB of its 160)
+    const size_t base_lds = kSymTab + kSymWaves * kSymWaveBytes, cnt_lds = base_lds + (size_t)kSymWaves * a.nctx * 512u;
+    bool lds_cnt = (a.ctx_hist || a.ctx_cost) && a.nctx <= ISSCABAC_STAT_CTX;
+    if (lds_cnt && cnt_lds > e->sym_cnt_lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_symbols<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)cnt_lds) == hipSuccess)
+        e->sym_cnt_lds = cnt_lds;
+      else {
+        (void)hipGetLastError();
+        lds_cnt = false;
+      }
+    }
+    if (lds_cnt) {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols<true>)))) return rc;
+      hipLaunchKernelGGL(k_encode_symbols<true>, dim3((unsigned)nblk), dim3(256), cnt_lds, e->stream, a);
+    } else {
+      if ((rc = sym_check_no_static_lds(e, reinterpret_cast<const void *>(&k_encode_symbols<false>)))) return rc;
+      hipLaunchKernelGGL(k_encode_symbols<false>, dim3((unsigned)nblk), dim3(256), base_lds, e->stream, a);
+    }
   }
   HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
+  if ((rc = sym_ensure_words(e))) return rc;
+  HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream, e->flag + 2,
+                                host_word >= 0 ? e->h_total_dev + host_word : nullptr));
   return ISSCABAC_OK;
 }
 
@@ -1023,13 +1081,11 @@ int isscabac_encode_symbols_stats_dev(isscabac_engine *e, const uint8_t *d_sym, 
                                       const uint8_t *ctx_init, int nctx, uint8_t *d_payload, uint64_t payload_cap,
                                       uint64_t *d_offsets, uint64_t *total_bytes, uint32_t *d_nbins_out,
                                       const isscabac_symbol_stats *d_stats) {
+  // the size word comes back through the engine's pinned words, written by the scan kernel (word 1: word 0 may belong to an
+  // asynchronous encode that is still outstanding): no copy command, one synchronisation
   const int rc = enc_symbols_enqueue(e, d_sym, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_payload, payload_cap, d_offsets,
-                                     d_nbins_out, d_stats);
+                                     d_nbins_out, d_stats, 1);
   if (rc) return rc;
-  // the size word comes back through the engine's pinned words (word 1: word 0 may belong to an asynchronous batch encode
-  // that is still outstanding) -- a copy into pageable memory is staged by the runtime and costs tens of microseconds
-  if (!e->h_total) HIP_TRY(e, hipHostMalloc(reinterpret_cast<void **>(&e->h_total), 64, hipHostMallocMapped));
-  HIP_TRY(e, hipMemcpyAsync(e->h_total + 1, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   const uint64_t total = e->h_total[1];
   if (total_bytes) *total_bytes = total;
@@ -1070,10 +1126,7 @@ static int dec_symbols_enqueue(isscabac_engine *e, const uint8_t *d_payload, uin
     // the code-tree kernel first; whatever it hands over (corrupt streams only) is decoded by the general kernel behind it,
     // which finds the hand-over marks on the device and returns at once when there are none
     if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
-    if (!e->flag) {  // (cabac_internal.h: four words, zeroed; word 3 is this path's)
-      HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->flag), 16));
-      HIP_TRY(e, hipMemset(e->flag, 0, 16));
-    }
+    if ((rc = sym_ensure_words(e))) return rc;  // (cabac_internal.h: four words, zeroed; word 3 is this path's)
     HIP_TRY(e, hipMemsetAsync(e->flag + 3, 0, sizeof(uint32_t), e->stream));
     a.redo = e->lens;
     a.redo_any = e->flag + 3;
@@ -1092,6 +1145,25 @@ static int dec_symbols_enqueue(isscabac_engine *e, const uint8_t *d_payload, uin
   hipLaunchKernelGGL(k_decode_symbols, dim3((unsigned)nblk), dim3(256), lds, e->stream, a);
   HIP_TRY(e, hipGetLastError());
   return ISSCABAC_OK;
+}
+
+// Asynchronous forms, as isscabac_encode_batch_dev_async / isscabac_decode_batch_dev_async: only enqueue on the engine's stream;
+// isscabac_sync() waits and reports the payload size and a capacity overflow of the most recent asynchronous encode
+int isscabac_encode_symbols_dev_async(isscabac_engine *e, const uint8_t *d_sym, const uint32_t *d_nsym, uint64_t S, uint32_t nsym,
+                                      uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx,
+                                      uint8_t *d_payload, uint64_t payload_cap, uint64_t *d_offsets, uint32_t *d_nbins_out) {
+  const int rc = enc_symbols_enqueue(e, d_sym, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_payload, payload_cap, d_offsets,
+                                     d_nbins_out, nullptr, 0);
+  if (rc) return rc;
+  e->pending_total = true;
+  e->pending_cap = payload_cap;
+  return ISSCABAC_OK;
+}
+int isscabac_decode_symbols_dev_async(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
+                                      const uint32_t *d_nsym, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                      const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *d_sym_out,
+                                      uint32_t *d_status) {
+  return dec_symbols_enqueue(e, d_payload, payload_bytes, d_offsets, d_nsym, S, nsym, pitch, params, ctx_init, nctx, d_sym_out, d_status);
 }
 
 int isscabac_decode_symbols_dev(isscabac_engine *e, const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets,
@@ -1148,9 +1220,14 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   const uint64_t in_bytes = S * pitch, dev_cap = S * isscabac_stream_bound(nsym * maxbins);
   int rc;
   const bool any_stats = stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits || stats->bin_trace);
+  // (the statistics come back through the block too -- the kernel counts in device memory, a read-modify-write per bin is no
+  // work for the link, and ONE copy brings [hist | cost | bits] over; a per-bin trace is a debugging output of any size and
+  // takes the general route)
+  const uint64_t st_h = S * ISSCABAC_STAT_CTX * sizeof(uint32_t), st_b = S * pitch * sizeof(uint16_t);
   const uint64_t o_nsym = up64(in_bytes), o_off = o_nsym + up64(S * 4), o_nb = o_off + up64((S + 1) * 8), o_pay = o_nb + up64(S * 4),
-                 small_total = o_pay + up64(dev_cap);
-  if (!any_stats && small_total <= kSymSmallBytes) {
+                 o_hist = o_pay + up64(dev_cap), o_cost = o_hist + (any_stats ? up64(st_h) : 0),
+                 o_bits = o_cost + (any_stats ? up64(st_h) : 0), small_total = o_bits + (any_stats ? up64(st_b) : 0);
+  if (!(stats && stats->bin_trace) && small_total <= kSymSmallBytes) {
     uint8_t *pin = sym_pin_block(e, kSymSmallBytes);
     if (pin) {
       void *dv = nullptr;
@@ -1162,11 +1239,23 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
       if ((rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], o_off))) return rc;
       uint8_t *din = static_cast<uint8_t *>(e->stage[0]);
       HIP_TRY(e, hipMemcpyAsync(din, pin, h2d, hipMemcpyHostToDevice, e->stream));
+      isscabac_symbol_stats pst = {nullptr, nullptr, nullptr, nullptr, 0};
+      if (any_stats) {
+        if ((rc = sym_grow(e, &e->stage[1], &e->stage_bytes[1], small_total - o_hist))) return rc;
+        uint8_t *b = static_cast<uint8_t *>(e->stage[1]);
+        if (stats->ctx_hist) pst.ctx_hist = reinterpret_cast<uint32_t *>(b);
+        if (stats->ctx_cost) pst.ctx_cost = reinterpret_cast<uint32_t *>(b + (o_cost - o_hist));
+        if (stats->sym_bits) pst.sym_bits = reinterpret_cast<uint16_t *>(b + (o_bits - o_hist));
+      }
       rc = enc_symbols_enqueue(e, din, nsym_per_stream ? reinterpret_cast<uint32_t *>(din + o_nsym) : nullptr, S, nsym, pitch, params,
                                ctx_init, nctx, d + o_pay, dev_cap, reinterpret_cast<uint64_t *>(d + o_off),
-                               reinterpret_cast<uint32_t *>(d + o_nb), nullptr);
+                               reinterpret_cast<uint32_t *>(d + o_nb), any_stats ? &pst : nullptr);
       if (rc) return rc;
+      if (any_stats) HIP_TRY(e, hipMemcpyAsync(pin + o_hist, e->stage[1], small_total - o_hist, hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(e, hipStreamSynchronize(e->stream));
+      if (pst.ctx_hist) memcpy(stats->ctx_hist, pin + o_hist, st_h);
+      if (pst.ctx_cost) memcpy(stats->ctx_cost, pin + o_cost, st_h);
+      if (pst.sym_bits) memcpy(stats->sym_bits, pin + o_bits, st_b);
       const uint64_t *off = reinterpret_cast<const uint64_t *>(pin + o_off);
       const uint64_t total = off[S];
       if (total_bytes) *total_bytes = total;

@@ -141,6 +141,10 @@ def _load():
     L.isscabac_symbol_max_bins.restype = C.c_uint32
     L.isscabac_encode_symbols_dev.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
                                               _u8p, C.c_int, _vp, C.c_uint64, _vp, _u64p, _vp]
+    L.isscabac_encode_symbols_dev_async.argtypes = [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
+                                                    _u8p, C.c_int, _vp, C.c_uint64, _vp, _vp]
+    L.isscabac_decode_symbols_dev_async.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                    C.POINTER(SymbolParams), _u8p, C.c_int, _vp, _vp]
     L.isscabac_decode_symbols_dev.argtypes = [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32,
                                               C.POINTER(SymbolParams), _u8p, C.c_int, _vp, _vp]
     L.isscabac_encode_symbols.argtypes = [_vp, _u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams),
@@ -607,6 +611,22 @@ class Engine:
                                                     R, pitch, C.byref(params), _ptr(ci, _u8p), ci.size, _ptr(out, _u8p),
                                                     _ptr(status, _u32p)))
         return out[:, :R].copy(), status
+
+    def encode_symbols_dev_async(self, d_sym, S, R, pitch, params, ctx_init, d_payload, payload_cap, d_offsets, d_nbins=0,
+                                 d_nsym=0):
+        """Enqueue only (device pointers as integers); sync() returns the payload size.  Steps chain with no host wait."""
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_encode_symbols_dev_async(self._h, _vp(d_sym), _vp(d_nsym or 0), S, R, pitch, C.byref(params),
+                                                              _ptr(ci, _u8p), ci.size, _vp(d_payload), payload_cap,
+                                                              _vp(d_offsets), _vp(d_nbins or 0)))
+
+    def decode_symbols_dev_async(self, d_payload, payload_bytes, d_offsets, S, R, pitch, params, ctx_init, d_sym_out, d_status=0,
+                                 d_nsym=0):
+        """payload_bytes: the buffer's extent when the size is not on the host yet (streams are cut by the offsets)."""
+        ci = _np(ctx_init, np.uint8)
+        self._check(self._L.isscabac_decode_symbols_dev_async(self._h, _vp(d_payload), payload_bytes, _vp(d_offsets),
+                                                              _vp(d_nsym or 0), S, R, pitch, C.byref(params), _ptr(ci, _u8p),
+                                                              ci.size, _vp(d_sym_out), _vp(d_status or 0)))
 
     def iss_init_context_model(self, sym, params):
         """Empirical p(0) of the ISS contexts over all columns (ref: +coder/cabacInitContextModel.m).
