@@ -118,7 +118,6 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->d2h_stream) (void)hipStreamDestroy(e->d2h_stream);
   if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->sym_pin) (void)hipHostFree(e->sym_pin);
-  if (e->wide_states) (void)hipFree(e->wide_states);
   if (e->wide_init) (void)hipFree(e->wide_init);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -413,8 +412,6 @@ static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_
     init[c] = ctx_init[c];
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  int rc;
-  if ((rc = grow(e, reinterpret_cast<void **>(&e->wide_states), &e->wide_states_bytes, wide_state_bytes(S)))) return rc;
   if (!e->wide_init) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->wide_init), sizeof init));
   // (a blocking copy of 1 KiB out of this stack frame: the previous call's kernels have long read theirs -- every wide call synchronises)
   HIP_TRY(e, hipMemcpyAsync(e->wide_init, init, sizeof init, hipMemcpyHostToDevice, e->stream));
@@ -434,7 +431,7 @@ int isscabac_encode_batch16_dev(isscabac_engine *e, const uint8_t *d_bins, const
   if ((rc = grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
   if ((rc = grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(S)))) return rc;
   if ((rc = ensure_words(e))) return rc;
-  HIP_TRY(e, launch_encode_wide(d_bins, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init, e->wide_states, e->slots, stride,
+  HIP_TRY(e, launch_encode_wide(d_bins, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init, e->slots, stride,
                                 e->lens, e->stream));
   HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->h_total + 2, d_offsets + S, sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
@@ -456,7 +453,7 @@ int isscabac_decode_batch16_dev(isscabac_engine *e, const uint8_t *d_payload, ui
   if (misaligned(d_ctx16) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
   HIP_TRY(e, launch_decode_wide(d_payload, payload_bytes, d_offsets, d_ctx16, d_nbins, S, nbins, pitch, (uint32_t)nctx, e->wide_init,
-                                e->wide_states, d_bins_out, d_status, e->stream));
+                                d_bins_out, d_status, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
 }

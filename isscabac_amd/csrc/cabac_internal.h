@@ -49,9 +49,7 @@ struct isscabac_engine {
   hipEvent_t pin_ev[kPinSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
   hipEvent_t pipe_ev[2] = {nullptr, nullptr};  // hand-over points between the copy streams and the compute stream
-  // batches of more than 255 contexts (cabac_wide.hip): the streams' state images and the 1 024 initial states
-  uint8_t *wide_states = nullptr;
-  uint64_t wide_states_bytes = 0;
+  // batches of more than 255 contexts (cabac_wide.hip): the 1 024 initial states
   uint8_t *wide_init = nullptr;
   // small symbol batches: one pinned, device-mapped block the kernels read and write directly (cabac_symbols.hip)
   uint8_t *sym_pin = nullptr;
@@ -146,14 +144,13 @@ hipError_t launch_order(const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uin
 // bins as bits <-> bins as bytes (rows of pitch / 8 and pitch bytes), for the packed host-buffer entry points
 hipError_t launch_unpack_bits(const uint8_t *d_packed, uint8_t *d_bins, uint64_t S, uint32_t pitch, hipStream_t stream);
 hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S, uint32_t pitch, hipStream_t stream);
-// batches of more than 255 contexts: 16-bit context indices, the state image in device scratch (cabac_wide.hip)
-uint64_t wide_state_bytes(uint64_t S);
+// batches of more than 255 contexts: 16-bit context indices, one wave per workgroup with the state image in its LDS (cabac_wide.hip)
 hipError_t launch_encode_wide(const uint8_t *d_bins, const uint16_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins,
-                              uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_states, uint8_t *d_slots,
-                              uint64_t slot_stride, uint32_t *d_lens, hipStream_t stream);
+                              uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_slots, uint64_t slot_stride,
+                              uint32_t *d_lens, hipStream_t stream);
 hipError_t launch_decode_wide(const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets, const uint16_t *d_ctx,
                               const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx,
-                              const uint8_t *d_ctx_init, uint8_t *d_states, uint8_t *d_bins_out, uint32_t *d_status, hipStream_t stream);
+                              const uint8_t *d_ctx_init, uint8_t *d_bins_out, uint32_t *d_status, hipStream_t stream);
 // synthetic workload generator
 hipError_t launch_synth(uint32_t seed, uint64_t s0, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx, int ep_half,
                         uint8_t *d_bins, uint8_t *d_ctx, hipStream_t stream);

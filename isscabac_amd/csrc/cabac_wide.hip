@@ -2,81 +2,152 @@
 // 999 context models the reference holds per coder (ref: CABAC/CommonDef.h:56, CABAC_ContextModelsInit.cpp:53,84; the
 // per-bin commands index them with a double, SimpleCABACMex.cpp:223-224).  gfx950, wave64.
 //
-// Same mapping as the other batch kernels -- one lane = one bitstream, the per-bin arithmetic of cabac_lane.h -- but the
-// state image of 1 024 bytes per stream does not fit the LDS (64 KiB per wave), so it lives in an engine-owned scratch in
-// device memory, [wave][context][lane] (a wave's 64 KiB stay L2-resident while it runs), and the tables are read from
-// constant memory.  Every bin is a dependent memory round trip: this path exists for completeness of the API against the
-// reference, its rate is on record in DESIGN.md; batches of up to 255 contexts never come here.
+// Same mapping as the other batch kernels -- one lane = one bitstream, the per-bin arithmetic of cabac_lane.h -- with the
+// state image of the batch's own size in the LDS: 256 bytes per four contexts and wave, at (ctx / 4) * 256 + lane * 4 +
+// ctx % 4 like the narrow kernels' (lane l only touches bank l % 32), so 999 contexts are 64 000 bytes per wave.  A
+// workgroup is ONE wave -- with the two tables and the encoder's output staging exactly 64 KiB at 999 contexts, two
+// workgroups per CU; 500 contexts leave room for four -- and a bin is two dependent LDS round trips (state, then row +
+// successors) instead of the three dependent device-memory round trips of the first version, whose image lived in a
+// device scratch (31-39 Gbin/s, profiles/r05/wide_rate.txt).  Input rows are read per lane, 16 bins a piece, one piece
+// ahead.  Batches of up to 255 contexts never come here.
 #include "cabac_wave.h"
 
 namespace isscabac {
 
-constexpr uint32_t kWideCtx = 1024;          // context rows of a wave's image (indices are checked against nctx first)
+// (the initialisation array on the device holds 1 024 packed states; indices are checked against nctx)
 constexpr uint32_t kWideBypass = 0xFFFFu;
+// LDS of a workgroup (dynamic, no static __shared__): [0, 256) rangeTabLps rows by state, [256, 512) next-state entries,
+// [512, 512 + image) the wave's state image, then (encoder) 16 bytes of output staging per lane
+constexpr uint32_t kWideTab = 512, kWideStage = 1024;
+__host__ __device__ constexpr uint32_t wide_image_bytes(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
 
-// States policy over the scratch image: load_at / store_at by context index
-struct GlobalStates {
-  uint8_t *img;  // this wave's image + lane
-  __device__ __forceinline__ uint32_t load_at(uint32_t c) const { return img[(size_t)c * 64]; }
-  __device__ __forceinline__ void store_at(uint32_t c, uint32_t q) const { img[(size_t)c * 64] = (uint8_t)q; }
+// States policy over the LDS image: load_at / store_at by context index
+struct WideStates {
+  uint8_t *img;          // the image + lane * 4
+  const uint32_t *tab;   // the two tables
+  __device__ __forceinline__ uint8_t *at(uint32_t c) const { return img + (((c & ~3u) << 6) | (c & 3u)); }
+  __device__ __forceinline__ uint32_t load_at(uint32_t c) const { return *at(c); }
+  __device__ __forceinline__ void store_at(uint32_t c, uint32_t q) const { *at(c) = (uint8_t)q; }
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return load_at(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t q) const { store_at(c, q); }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return c_lps_rows[q >> 2]; }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return c_next.e[q >> 2]; }
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return tab[q >> 2]; }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return tab[64 + (q >> 2)]; }
 };
+
+// The same image with the state of the NEXT bin requested one bin ahead (ISSCABAC_WIDE_FWD): the read is issued before the
+// current bin's store -- LDS operations complete in order, so it sees every store but that one -- and the current bin's
+// successor is forwarded in a register when the next bin names the same context.  A bin's chain is then one LDS round trip
+// (row + successors of its state) instead of two.
+#ifndef ISSCABAC_WIDE_FWD
+#define ISSCABAC_WIDE_FWD 1
+#endif
+struct WideFwdStates : WideStates {
+  uint32_t last_c, last_q, pre_q, cur_q;
+  __device__ __forceinline__ WideFwdStates(const WideStates &b) : WideStates(b), last_c(~0u), last_q(0), pre_q(0), cur_q(0) {}
+  __device__ __forceinline__ void request(uint32_t c) { pre_q = *at(c); }  // c must be a valid index
+  __device__ __forceinline__ void begin(uint32_t c) { cur_q = c == last_c ? last_q : pre_q; }  // before the next request()
+  __device__ __forceinline__ uint32_t load_at(uint32_t) const { return cur_q; }
+  __device__ __forceinline__ void store_at(uint32_t c, uint32_t q) {
+    *at(c) = (uint8_t)q;
+    last_c = c;
+    last_q = q & 0xFFu;
+  }
+};
+// context of bin k of a 16-bin piece held as two uint4 of 16-bit indices
+__device__ __forceinline__ uint32_t wide_ctx_of(const uint4 &c0, const uint4 &c1, int k) {
+  const uint32_t cw = word_of(k < 8 ? c0 : c1, (k >> 1) & 3);
+  return (k & 1) ? cw >> 16 : cw & 0xFFFFu;
+}
 
 struct WideEncArgs {
   const uint8_t *bins;
   const uint16_t *ctx;
   const uint32_t *nbins_per_stream;
-  uint8_t *slots, *states;
+  uint8_t *slots;
   uint32_t *lens;
-  const uint8_t *ctx_init;  // device, kWideCtx packed states (mps | state << 1)
+  const uint8_t *ctx_init;  // device, 1 024 packed states (mps | state << 1)
   uint64_t S, slot_stride;
   uint32_t nbins, pitch, nctx;
 };
 
-__device__ __forceinline__ void wide_init_states(uint8_t *img, const uint8_t *ctx_init, int lane) {
-  // (the whole image: a context the caller did not initialise is the reference's default ContextModel())
-  for (uint32_t c = 0; c < kWideCtx; c++) img[(size_t)c * 64] = (uint8_t)((ctx_init[c] & 0x7Fu) << 1);
+// tables and this wave's image; returns the policy.  ctx_init holds 1 024 bytes, so the rounded-up tail is in bounds
+__device__ __forceinline__ WideStates wide_setup(uint8_t *smem, const uint8_t *ctx_init, uint32_t nctx, int lane) {
+  uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+  tab[lane] = c_lps_rows[lane];
+  tab[64 + lane] = c_next.e[lane];
+  uint32_t *img32 = reinterpret_cast<uint32_t *>(smem + kWideTab) + lane;
+  const uint32_t *init32 = reinterpret_cast<const uint32_t *>(ctx_init);
+  for (uint32_t g = 0; g < (nctx + 3u) / 4u; g++) img32[g * 64] = (init32[g] & 0x7F7F7F7Fu) << 1;  // four contexts a word
+  __syncthreads();  // (one wave: orders the table writes before the other lanes' reads)
+  return WideStates{smem + kWideTab + lane * 4, tab};
 }
 
-__global__ void __launch_bounds__(256) k_encode_wide(WideEncArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[4 * 64 * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t w = (uint64_t)blockIdx.x * 4 + wv, s0 = w * 64;
-  if (s0 >= a.S) return;
+__global__ void __launch_bounds__(64) k_encode_wide(WideEncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
   const bool valid = s0 + lane < a.S;
   const uint64_t s = valid ? s0 + lane : a.S - 1;
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = valid ? min(n, a.nbins) : 0u;
-  GlobalStates st{a.states + w * (uint64_t)(kWideCtx * 64) + lane};
-  wide_init_states(st.img, a.ctx_init, lane);
+  WideStates st = wide_setup(smem, a.ctx_init, a.nctx, lane);
   EncCore e;
   enc_start(e);
   SlotSink sink;
-  sink.stage = stage + (wv * 64 + lane) * 16;
+  sink.stage = smem + kWideTab + wide_image_bytes(a.nctx) + lane * 16;
   sink.slots = a.slots + s0 * a.slot_stride;
   sink.mine = (uint32_t)(s - s0) * (uint32_t)a.slot_stride;
   sink.pos = 0;
   sink.on = valid;
   const uint8_t *brow = a.bins + s * a.pitch;
   const uint16_t *crow = a.ctx + s * a.pitch;
+  // pitch is a multiple of 16: a piece lies inside the row; the next one is requested before this one is coded
+  uint4 wb = make_uint4(0, 0, 0, 0), c0 = wb, c1 = wb;
+  if (n) {
+    wb = *reinterpret_cast<const uint4 *>(brow);
+    c0 = *reinterpret_cast<const uint4 *>(crow);
+    c1 = *reinterpret_cast<const uint4 *>(crow + 8);
+  }
+#if ISSCABAC_WIDE_FWD
+  WideFwdStates fs(st);
+  const uint32_t cmax = a.nctx - 1;
+  uint32_t cn = wide_ctx_of(c0, c1, 0);
+  fs.request(min(cn, cmax));  // (a bypass marker or an invalid index reads some valid row; the value is not used)
+#endif
 #pragma unroll 1
   for (uint32_t i0 = 0; i0 < n; i0 += 16) {
-    const uint4 wb = *reinterpret_cast<const uint4 *>(brow + i0);  // pitch is a multiple of 16: the piece lies inside the row
-    const uint4 c0 = *reinterpret_cast<const uint4 *>(crow + i0), c1 = *reinterpret_cast<const uint4 *>(crow + i0 + 8);
+    uint4 nwb = wb, nc0 = c0, nc1 = c1;
+    if (i0 + 16 < n) {
+      nwb = *reinterpret_cast<const uint4 *>(brow + i0 + 16);
+      nc0 = *reinterpret_cast<const uint4 *>(crow + i0 + 16);
+      nc1 = *reinterpret_cast<const uint4 *>(crow + i0 + 24);
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
+#if ISSCABAC_WIDE_FWD
+      const uint32_t c = cn;
+      cn = k < 15 ? wide_ctx_of(c0, c1, k + 1) : wide_ctx_of(nc0, nc1, 0);
+      fs.begin(c);
+      fs.request(min(cn, cmax));
       if (i0 + k < n) {
         const uint32_t bin = byte_of(wb, k) & 1u;
-        const uint32_t cw = word_of(k < 8 ? c0 : c1, (k >> 1) & 3), c = (k & 1) ? cw >> 16 : cw & 0xFFFFu;
+        if (c == kWideBypass) enc_bin_ep(e, bin);
+        else if (c < a.nctx) enc_bin_at(e, BinB1{bin << 1}, c, fs);
+      }
+#else
+      if (i0 + k < n) {
+        const uint32_t bin = byte_of(wb, k) & 1u;
+        const uint32_t c = wide_ctx_of(c0, c1, k);
         if (c == kWideBypass) enc_bin_ep(e, bin);
         else if (c < a.nctx) enc_bin_at(e, BinB1{bin << 1}, c, st);
         // (any other value is invalid: skipped, that stream's result is unspecified, include/isscabac.h)
       }
+#endif
       if ((k & 3) == 3) enc_flush16(e, sink);  // (keeps W below 29 + 4 x 6)
     }
+    wb = nwb;
+    c0 = nc0;
+    c1 = nc1;
   }
   enc_flush16(e, sink);
   enc_finish16(e, sink);
@@ -89,23 +160,22 @@ struct WideDecArgs {
   const uint16_t *ctx;
   const uint64_t *offsets;
   const uint32_t *nbins_per_stream;
-  uint8_t *bins_out, *states;
+  uint8_t *bins_out;
   uint32_t *status;
   const uint8_t *ctx_init;
   uint64_t S, payload_bytes;
   uint32_t nbins, pitch, nctx;
 };
 
-__global__ void __launch_bounds__(256) k_decode_wide(WideDecArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t w = (uint64_t)blockIdx.x * 4 + wv, s0 = w * 64;
-  if (s0 >= a.S) return;
+__global__ void __launch_bounds__(64) k_decode_wide(WideDecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
   const bool valid = s0 + lane < a.S;
   const uint64_t s = valid ? s0 + lane : a.S - 1;
   uint32_t n = a.nbins_per_stream ? a.nbins_per_stream[s] : a.nbins;
   n = min(n, a.nbins);
-  GlobalStates st{a.states + w * (uint64_t)(kWideCtx * 64) + lane};
-  wide_init_states(st.img, a.ctx_init, lane);
+  WideStates st = wide_setup(smem, a.ctx_init, a.nctx, lane);
   if (!valid) return;  // (no cross-lane operation below)
   uint64_t start = a.offsets[s];
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
@@ -142,29 +212,57 @@ __global__ void __launch_bounds__(256) k_decode_wide(WideDecArgs a) {
   src.boundary();
   DecCore d;
   dec_start(d, src);
+  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+  if (n) {
+    c0 = *reinterpret_cast<const uint4 *>(crow);
+    c1 = *reinterpret_cast<const uint4 *>(crow + 8);
+  }
+#if ISSCABAC_WIDE_FWD
+  WideFwdStates fs(st);
+  const uint32_t cmax = a.nctx - 1;
+  uint32_t cn = wide_ctx_of(c0, c1, 0);
+  fs.request(min(cn, cmax));
+#endif
 #pragma unroll 1
   for (uint32_t i0 = 0; i0 < nrow; i0 += 16) {
     uint4 ob = make_uint4(0, 0, 0, 0);
+    uint4 nc0 = c0, nc1 = c1;
+    if (i0 + 16 < n) {  // the next piece of contexts, requested before this one is decoded
+      nc0 = *reinterpret_cast<const uint4 *>(crow + i0 + 16);
+      nc1 = *reinterpret_cast<const uint4 *>(crow + i0 + 24);
+    }
     if (i0 < n) {
       if (i0) src.boundary();  // adopt the piece requested a chunk ago, re-base, request the next
-      const uint4 c0 = *reinterpret_cast<const uint4 *>(crow + i0), c1 = *reinterpret_cast<const uint4 *>(crow + i0 + 8);
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         uint32_t bin = 0;
+#if ISSCABAC_WIDE_FWD
+        const uint32_t c = cn;
+        cn = k < 15 ? wide_ctx_of(c0, c1, k + 1) : wide_ctx_of(nc0, nc1, 0);
+        fs.begin(c);
+        fs.request(min(cn, cmax));
+#else
+        const uint32_t c = wide_ctx_of(c0, c1, k);
+#endif
         if (i0 + k < n) {
-          const uint32_t cw = word_of(k < 8 ? c0 : c1, (k >> 1) & 3), c = (k & 1) ? cw >> 16 : cw & 0xFFFFu;
           if (c == kWideBypass) {
             if (d.sh < 8) dec_topup(d, src);
             bin = dec_bin_ep(d);
           } else if (c < a.nctx) {
             if (d.sh < 13) dec_topup(d, src);  // a context bin needs sh >= 7 and takes at most 6 bits
+#if ISSCABAC_WIDE_FWD
+            bin = (dec_bin_at_b1(d, c, fs) >> 1) & 1u;
+#else
             bin = (dec_bin_at_b1(d, c, st) >> 1) & 1u;
+#endif
           }
         }
         set_word(ob, k >> 2, word_of(ob, k >> 2) | bin << (8 * (k & 3)));
       }
     }
     *reinterpret_cast<uint4 *>(orow + i0) = ob;
+    c0 = nc0;
+    c1 = nc1;
   }
   if (a.status) {
     const uint32_t sk = (uint32_t)start & 3u;
@@ -173,22 +271,23 @@ __global__ void __launch_bounds__(256) k_decode_wide(WideDecArgs a) {
   }
 }
 
+// dynamic LDS of a workgroup; above 64 KiB (never: 999 contexts are exactly 64 KiB with the staging) the attribute would be needed
+static size_t wide_lds_bytes(uint32_t nctx, bool encoder) { return kWideTab + wide_image_bytes(nctx) + (encoder ? kWideStage : 0u); }
+
 hipError_t launch_encode_wide(const uint8_t *d_bins, const uint16_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins,
-                              uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_states, uint8_t *d_slots,
-                              uint64_t slot_stride, uint32_t *d_lens, hipStream_t stream) {
-  WideEncArgs a{d_bins, d_ctx, d_nbins, d_slots, d_states, d_lens, d_ctx_init, S, slot_stride, nbins, pitch, nctx};
-  hipLaunchKernelGGL(k_encode_wide, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, a);
+                              uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_slots, uint64_t slot_stride,
+                              uint32_t *d_lens, hipStream_t stream) {
+  WideEncArgs a{d_bins, d_ctx, d_nbins, d_slots, d_lens, d_ctx_init, S, slot_stride, nbins, pitch, nctx};
+  hipLaunchKernelGGL(k_encode_wide, dim3((unsigned)((S + 63) / 64)), dim3(64), wide_lds_bytes(nctx, true), stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_decode_wide(const uint8_t *d_payload, uint64_t payload_bytes, const uint64_t *d_offsets, const uint16_t *d_ctx,
                               const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx,
-                              const uint8_t *d_ctx_init, uint8_t *d_states, uint8_t *d_bins_out, uint32_t *d_status, hipStream_t stream) {
-  WideDecArgs a{d_payload, d_ctx, d_offsets, d_nbins, d_bins_out, d_states, d_status, d_ctx_init, S, payload_bytes, nbins, pitch, nctx};
-  hipLaunchKernelGGL(k_decode_wide, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, a);
+                              const uint8_t *d_ctx_init, uint8_t *d_bins_out, uint32_t *d_status, hipStream_t stream) {
+  WideDecArgs a{d_payload, d_ctx, d_offsets, d_nbins, d_bins_out, d_status, d_ctx_init, S, payload_bytes, nbins, pitch, nctx};
+  hipLaunchKernelGGL(k_decode_wide, dim3((unsigned)((S + 63) / 64)), dim3(64), wide_lds_bytes(nctx, false), stream, a);
   return hipGetLastError();
 }
-
-uint64_t wide_state_bytes(uint64_t S) { return ((S + 63) / 64) * (uint64_t)(kWideCtx * 64); }
 
 }  // namespace isscabac
