@@ -12,11 +12,19 @@
 // call observes (bytes written so far, decoded bins, the status word) comes back through a pinned host mailbox the
 // kernel writes: an encodeBin + getNumBits pair costs one launch and one stream synchronisation, no copies.
 //
+// Calls that need an answer at once -- decodeBin, and getNumBits behind a few queued encodeBin -- are served by a LIVE
+// kernel: one lane that holds the coder in registers and polls a request word in the pinned mailbox, so that such a call is
+// one write over the link and one word back instead of a kernel launch and a stream synchronisation (10 -> 3-4 us).  It leaves
+// by itself after a millisecond without requests and is started again by the next call; everything else (start, finish, long
+// calls, traces) stops it first and runs as ordinary launches on the engine's stream.
+//
 // With tracing on, every op leaves a 4-byte record on the device: getEncoderStats / getDecoderStats of the reference's
 // Windows build (ref: SimpleCABACMex.cpp:356-466, ContextModel.cpp:126-134) are computed from those records.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -52,7 +60,15 @@ struct StreamMailbox {
   uint32_t enc_bytes;
   uint32_t status;
   uint8_t bins[64];  // decoded bins of a short call
+  // the live kernel's words (coherent host memory: every access crosses the link)
+  uint64_t req;      // host -> device: seq (bits 0..31) | command << 32 | n << 36 | bin[0] << 44 | op[0] << 48
+  uint64_t done;     // device -> host: seq | answer << 32 (decode, n = 1: the bin; encode: bytes written so far)
+  uint32_t exited;   // device -> host: the kernel's last word
+  uint32_t pad;
+  uint16_t op[32];   // request payload of a call with n > 1
+  uint8_t bin[32];
 };
+constexpr uint32_t kLiveDec = 1, kLiveEnc = 2, kLiveQuit = 3, kLiveMaxOps = 32;
 
 // ops of a short call travel by value
 constexpr uint32_t kInlineOps = 32;
@@ -71,6 +87,40 @@ struct GlobalStates {
   __device__ uint32_t lps_row(uint32_t v) const { return s_lps_rows[v >> 2]; }
   __device__ uint32_t next_entry(uint32_t v) const { return s_next.e[v >> 2]; }
 };
+// The same with the handle's 1 000 states and the tables staged in the LDS for the length of a kernel (ops in bulk and the live
+// kernel): a bin is LDS round trips instead of three dependent trips to device memory (0.46 -> 0.1-0.2 us per queued bin)
+struct StagedStates {
+  uint8_t *q;
+  const uint32_t *rows, *next, *prob;
+  __device__ uint32_t load(uint32_t c) const { return q[c]; }
+  __device__ void store(uint32_t c, uint32_t v) const { q[c] = (uint8_t)v; }
+  __device__ uint32_t addr(uint32_t c) const { return c; }
+  __device__ uint32_t load_at(uint32_t a) const { return q[a]; }
+  __device__ void store_at(uint32_t a, uint32_t v) const { q[a] = (uint8_t)v; }
+  __device__ uint32_t lps_row(uint32_t v) const { return rows[v >> 2]; }
+  __device__ uint32_t next_entry(uint32_t v) const { return next[v >> 2]; }
+  __device__ uint32_t prob_row(uint32_t p) const { return prob[prob_row_index(p)]; }
+};
+struct StageLds {
+  uint32_t rows[64], next[64], prob[52];
+  uint8_t q[1024];
+};
+// all threads of the workgroup: stage one side's states + the tables / write the states back
+__device__ __forceinline__ StagedStates stage_in(StageLds &l, const uint8_t *q_dev) {
+  for (int t = threadIdx.x; t < 64; t += blockDim.x) {
+    l.rows[t] = s_lps_rows[t];
+    l.next[t] = s_next.e[t];
+    if (t < 49) l.prob[t] = s_prob_rows[t];
+  }
+  for (int t = threadIdx.x; t < kStreamCtx; t += blockDim.x) l.q[t] = q_dev[t];
+  __syncthreads();
+  return StagedStates{l.q, l.rows, l.next, l.prob};
+}
+__device__ __forceinline__ void stage_out(const StageLds &l, uint8_t *q_dev) {
+  __syncthreads();
+  for (int t = threadIdx.x; t < kStreamCtx; t += blockDim.x) q_dev[t] = l.q[t];
+}
+
 struct GlobalSink {
   uint8_t *buf;
   uint32_t pos;
@@ -96,14 +146,18 @@ __global__ void k_stream_enc_start(StreamDev *st, StreamMailbox *mb) {
   mb->enc_bytes = 0;
 }
 
-__device__ __forceinline__ void stream_enc_op(EncCore &e, GlobalStates &cs, GlobalSink &sink, uint32_t op, uint32_t bin,
+__device__ __forceinline__ uint32_t prob_row_of(const GlobalStates &, uint32_t p) { return s_prob_rows[prob_row_index(p)]; }
+__device__ __forceinline__ uint32_t prob_row_of(const StagedStates &cs, uint32_t p) { return cs.prob_row(p); }
+
+template <class States>
+__device__ __forceinline__ void stream_enc_op(EncCore &e, States &cs, GlobalSink &sink, uint32_t op, uint32_t bin,
                                               uint32_t *trace) {
   uint32_t rec = 0;
   if (op == ISSCABAC_OP_BYPASS || op == ISSCABAC_OP_PROB(50)) {
     enc_bin_ep(e, bin);
   } else if (op & 0x8000u) {
     const uint32_t p = op & 0x7Fu;
-    enc_bin_prob(e, bin, p, s_prob_rows[prob_row_index(p)]);
+    enc_bin_prob(e, bin, p, prob_row_of(cs, p));
   } else {
     const uint32_t q0 = cs.load(op);
     enc_bin(e, bin << 1, op, cs);
@@ -115,14 +169,37 @@ __device__ __forceinline__ void stream_enc_op(EncCore &e, GlobalStates &cs, Glob
 
 __global__ void k_stream_enc_bins(StreamDev *st, StreamMailbox *mb, const uint8_t *bins, const uint16_t *ops, uint32_t n,
                                   uint8_t *out, uint32_t *trace) {
-  if (threadIdx.x != 0) return;
-  EncCore e = st->enc;
-  GlobalStates cs{st->q_enc};
-  GlobalSink sink{out, st->enc_bytes};
-  for (uint32_t i = 0; i < n; i++) stream_enc_op(e, cs, sink, ops[i], bins[i] & 1u, trace ? trace + i : nullptr);
-  st->enc = e;
-  st->enc_bytes = sink.pos;
-  mb->enc_bytes = sink.pos;
+  __shared__ StageLds lds;
+  StagedStates cs = stage_in(lds, st->q_enc);
+  if (threadIdx.x == 0) {
+    EncCore e = st->enc;
+    GlobalSink sink{out, st->enc_bytes};
+    // eight ops at a time, the next eight requested before these are coded (a lone lane waits out every load otherwise)
+    uint32_t o[8], b[8], no[8], nb[8];
+    for (int j = 0; j < 8; j++) {
+      const uint32_t idx = min((uint32_t)j, n - 1);
+      o[j] = ops[idx];
+      b[j] = bins[idx];
+    }
+    for (uint32_t i = 0; i < n; i += 8) {
+      for (int j = 0; j < 8; j++) {
+        const uint32_t idx = min(i + 8 + j, n - 1);
+        no[j] = ops[idx];
+        nb[j] = bins[idx];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (i + j < n) stream_enc_op(e, cs, sink, o[j], b[j] & 1u, trace ? trace + i + j : nullptr);
+      for (int j = 0; j < 8; j++) {
+        o[j] = no[j];
+        b[j] = nb[j];
+      }
+    }
+    st->enc = e;
+    st->enc_bytes = sink.pos;
+    mb->enc_bytes = sink.pos;
+  }
+  stage_out(lds, st->q_enc);
 }
 __global__ void k_stream_enc_bins_inline(StreamDev *st, StreamMailbox *mb, InlineOps io, uint32_t n, uint8_t *out,
                                          uint32_t *trace) {
@@ -157,13 +234,14 @@ __global__ void k_stream_dec_start(StreamDev *st, const uint8_t *payload, uint32
   st->dec_len = len;
 }
 
-__device__ __forceinline__ uint32_t stream_dec_op(RefDec &d, GlobalStates &cs, RefReader &rd, uint32_t op, uint32_t *trace) {
+template <class States>
+__device__ __forceinline__ uint32_t stream_dec_op(RefDec &d, States &cs, RefReader &rd, uint32_t op, uint32_t *trace) {
   uint32_t bin, rec = 0;
   if (op == ISSCABAC_OP_BYPASS || op == ISSCABAC_OP_PROB(50)) {
     bin = ref_dec_bin_ep(d, rd);
   } else if (op & 0x8000u) {
     const uint32_t p = op & 0x7Fu;
-    bin = ref_dec_bin_prob(d, p, s_prob_rows[prob_row_index(p)], rd);
+    bin = ref_dec_bin_prob(d, p, prob_row_of(cs, p), rd);
   } else {
     const uint32_t q0 = cs.load(op);
     bin = ref_dec_bin(d, op, cs, rd);
@@ -175,14 +253,25 @@ __device__ __forceinline__ uint32_t stream_dec_op(RefDec &d, GlobalStates &cs, R
 
 __global__ void k_stream_dec_bins(StreamDev *st, const uint8_t *payload, const uint16_t *ops, uint32_t n, uint8_t *bins_out,
                                   uint32_t *trace) {
-  if (threadIdx.x != 0) return;
-  RefDec d = st->dec;
-  GlobalStates cs{st->q_dec};
-  RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
-  for (uint32_t i = 0; i < n; i++) bins_out[i] = (uint8_t)stream_dec_op(d, cs, rd, ops[i], trace ? trace + i : nullptr);
-  st->dec = d;
-  st->dec_pos = rd.nread;
-  st->dec_last = rd.last;
+  __shared__ StageLds lds;
+  StagedStates cs = stage_in(lds, st->q_dec);
+  if (threadIdx.x == 0) {
+    RefDec d = st->dec;
+    RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
+    uint32_t o[8], no[8];
+    for (int j = 0; j < 8; j++) o[j] = ops[min((uint32_t)j, n - 1)];
+    for (uint32_t i = 0; i < n; i += 8) {
+      for (int j = 0; j < 8; j++) no[j] = ops[min(i + 8 + j, n - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (i + j < n) bins_out[i + j] = (uint8_t)stream_dec_op(d, cs, rd, o[j], trace ? trace + i + j : nullptr);
+      for (int j = 0; j < 8; j++) o[j] = no[j];
+    }
+    st->dec = d;
+    st->dec_pos = rd.nread;
+    st->dec_last = rd.last;
+  }
+  stage_out(lds, st->q_dec);
 }
 __global__ void k_stream_dec_bins_inline(StreamDev *st, StreamMailbox *mb, const uint8_t *payload, InlineOps io, uint32_t n,
                                          uint32_t *trace) {
@@ -202,6 +291,73 @@ __global__ void k_stream_dec_finish(StreamDev *st, StreamMailbox *mb, const uint
   RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
   mb->status = ref_dec_finish(d, rd, st->dec_len);
   st->dec = d;
+}
+
+// The live kernel.  `last` = the sequence number of the last request served before it started.  Leaving: it writes the coder
+// back, then `exited`; a request that arrives while it leaves is either served on its last look at the request word or left
+// for the next kernel -- the host tells the two apart by `done` (cabac_stream.hip: live_call).
+__global__ void k_stream_live(StreamDev *st, StreamMailbox *mb, const uint8_t *payload, uint8_t *out, uint32_t *tr_enc,
+                              uint32_t *tr_dec /* the next free trace record of either side, or null */, uint32_t last,
+                              uint64_t idle_ticks) {
+  __shared__ StageLds lds_e, lds_d;  // (one wave: the other lanes only help to stage the states in)
+  StagedStates ce = stage_in(lds_e, st->q_enc), cd = stage_in(lds_d, st->q_dec);
+  if (threadIdx.x != 0) return;
+  EncCore e = st->enc;
+  GlobalSink sink{out, st->enc_bytes};
+  RefDec d = st->dec;
+  RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
+  uint64_t t0 = wall_clock64();
+  bool leaving = false;
+  for (uint32_t it = 0; it < (1u << 24); it++) {  // (the count is a backstop for the clock)
+    const uint64_t r = __hip_atomic_load(&mb->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t seq = (uint32_t)r;
+    if (seq != last) {
+      const uint32_t cmd = (uint32_t)(r >> 32) & 0xFu, n = (uint32_t)(r >> 36) & 0xFFu;
+      uint64_t reply = seq;
+      if (cmd == kLiveDec) {
+        if (n == 1) {
+          reply |= (uint64_t)stream_dec_op(d, cd, rd, (uint32_t)(r >> 48), tr_dec ? tr_dec++ : nullptr) << 32;
+        } else {
+          for (uint32_t i = 0; i < n; i++) {
+            const uint32_t op = *reinterpret_cast<volatile uint16_t *>(&mb->op[i]);
+            *reinterpret_cast<volatile uint8_t *>(&mb->bins[i]) = (uint8_t)stream_dec_op(d, cd, rd, op, tr_dec ? tr_dec++ : nullptr);
+          }
+        }
+      } else if (cmd == kLiveEnc) {
+        if (n == 1) {
+          stream_enc_op(e, ce, sink, (uint32_t)(r >> 48), (uint32_t)(r >> 44) & 1u, tr_enc ? tr_enc++ : nullptr);
+        } else {
+          for (uint32_t i = 0; i < n; i++) {
+            const uint32_t op = *reinterpret_cast<volatile uint16_t *>(&mb->op[i]);
+            const uint32_t bin = *reinterpret_cast<volatile uint8_t *>(&mb->bin[i]);
+            stream_enc_op(e, ce, sink, op, bin & 1u, tr_enc ? tr_enc++ : nullptr);
+          }
+        }
+        reply |= (uint64_t)sink.pos << 32;
+      } else {
+        leaving = true;
+      }
+      __threadfence_system();
+      __hip_atomic_store(&mb->done, reply, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      last = seq;
+      if (leaving) break;
+      t0 = wall_clock64();
+      continue;
+    }
+    if (leaving) break;  // looked once more after deciding to leave: nothing came
+    if (wall_clock64() - t0 > idle_ticks) leaving = true;
+  }
+  for (int t = 0; t < kStreamCtx / 4; t++) {
+    reinterpret_cast<uint32_t *>(st->q_enc)[t] = reinterpret_cast<const uint32_t *>(lds_e.q)[t];
+    reinterpret_cast<uint32_t *>(st->q_dec)[t] = reinterpret_cast<const uint32_t *>(lds_d.q)[t];
+  }
+  st->enc = e;
+  st->enc_bytes = sink.pos;
+  st->dec = d;
+  st->dec_pos = rd.nread;
+  st->dec_last = rd.last;
+  __threadfence_system();
+  __hip_atomic_store(&mb->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace isscabac
@@ -233,6 +389,12 @@ struct isscabac_stream {
   bool tracing = false;
   uint8_t *d_trace[2] = {nullptr, nullptr};
   uint64_t trace_cap[2] = {0, 0};
+  // the live kernel (see the top of this file)
+  bool live_on = true;        // ISSCABAC_STREAM_LIVE=0 switches it off
+  bool live = false;          // a live kernel has been started and not yet been seen to leave
+  hipStream_t live_stream = nullptr;
+  uint32_t live_seq = 0;
+  uint64_t idle_ticks = 100000;  // one millisecond of wall_clock64()
 };
 
 static int stream_grow(isscabac_engine *e, uint8_t **p, uint64_t *cap, uint64_t need, uint64_t keep) {
@@ -261,15 +423,106 @@ static int trace_room(isscabac_stream *s, int side, uint64_t have, uint64_t n, u
   return ISSCABAC_OK;
 }
 
+// ---- the live kernel's host side ---------------------------------------------------------------------------------------------
+static inline uint64_t mb_load64(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline uint32_t mb_load32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+
+static int live_launch(isscabac_stream *s) {
+  isscabac_engine *e = s->e;
+  __atomic_store_n(&s->mb->exited, 0u, __ATOMIC_RELEASE);
+  uint32_t *tr_enc = s->tracing && s->d_trace[0] ? reinterpret_cast<uint32_t *>(s->d_trace[0]) + s->bins_total : nullptr;
+  uint32_t *tr_dec = s->tracing && s->d_trace[1] ? reinterpret_cast<uint32_t *>(s->d_trace[1]) + s->dec_total : nullptr;
+  hipLaunchKernelGGL(k_stream_live, dim3(1), dim3(64), 0, s->live_stream, s->st, s->d_mb, s->d_payload, s->d_out, tr_enc, tr_dec,
+                     (uint32_t)mb_load64(&s->mb->done), s->idle_ticks);
+  HIP_TRY(e, hipGetLastError());
+  s->live = true;
+  return ISSCABAC_OK;
+}
+
+// post one request and wait for its answer (the whole `done` word); starts the kernel when there is none
+static int live_call(isscabac_stream *s, uint32_t cmd, uint32_t n, const uint16_t *ops, const uint8_t *bins, uint64_t *answer) {
+  isscabac_engine *e = s->e;
+  StreamMailbox *mb = s->mb;
+  if (n > 1) {
+    memcpy(mb->op, ops, n * sizeof(uint16_t));
+    if (bins) memcpy(mb->bin, bins, n);
+  }
+  const uint32_t seq = ++s->live_seq;
+  const uint64_t word = (uint64_t)seq | (uint64_t)cmd << 32 | (uint64_t)n << 36 | (uint64_t)(bins && n ? bins[0] & 1u : 0u) << 44 |
+                        (uint64_t)(ops && n ? ops[0] : 0u) << 48;
+  __atomic_store_n(&mb->req, word, __ATOMIC_RELEASE);
+  if (s->live && mb_load32(&mb->exited)) s->live = false;  // it left since the last call (its write-back is behind that word)
+  int rc;
+  if (!s->live && (rc = live_launch(s))) return rc;
+  std::chrono::steady_clock::time_point t_start;
+  for (uint64_t spins = 0;; spins++) {
+    uint64_t d = mb_load64(&mb->done);
+    if ((uint32_t)d == seq) {
+      *answer = d;
+      return ISSCABAC_OK;
+    }
+    if (mb_load32(&mb->exited)) {
+      // the kernel left; did it serve this request on its way out?
+      d = mb_load64(&mb->done);
+      if ((uint32_t)d == seq) {
+        *answer = d;
+        s->live = false;
+        return ISSCABAC_OK;
+      }
+      if ((rc = live_launch(s))) return rc;  // no: the next kernel finds the request word waiting
+    }
+    if ((spins & 0xFFFFu) == 0xFFFFu) {
+      // (a kernel that has not answered for seconds: report it instead of spinning for ever)
+      const auto t_now = std::chrono::steady_clock::now();
+      if (spins == 0xFFFFu) t_start = t_now;
+      else if (std::chrono::duration<double>(t_now - t_start).count() > 5.0)
+        return engine_fail(e, ISSCABAC_ERR_HIP, "per-bin handle: the live kernel does not answer");
+    }
+  }
+}
+
+// make the live kernel leave and wait until it has: afterwards the coder state is in device memory again
+static int live_stop(isscabac_stream *s) {
+  if (!s->live) return ISSCABAC_OK;
+  isscabac_engine *e = s->e;
+  if (!mb_load32(&s->mb->exited)) {
+    uint64_t a;
+    const int rc = live_call(s, kLiveQuit, 0, nullptr, nullptr, &a);
+    if (rc) return rc;
+  }
+  HIP_TRY(e, hipStreamSynchronize(s->live_stream));
+  s->live = false;
+  return ISSCABAC_OK;
+}
+
 // code the queued ops on the device; leaves the stream synchronised and the mailbox current
 static int stream_flush_pending(isscabac_stream *s) {
   isscabac_engine *e = s->e;
   const uint64_t n = s->pend_bins.size();
-  if (n == 0) {
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (n && n <= kLiveMaxOps && s->live_on) {
+    // room for the bytes and the trace records first: the live kernel holds the buffers' addresses, so it leaves before they move
+    const uint64_t need_out = isscabac_stream_bound((uint32_t)std::min<uint64_t>(s->bins_total + n, 0xFFFFFFF0ull)) + 16;
+    int rc;
+    if (s->out_cap < need_out || (s->tracing && s->trace_cap[0] < 4 * (s->bins_total + n))) {
+      uint32_t *tr;
+      if ((rc = live_stop(s)) || (rc = stream_grow(e, &s->d_out, &s->out_cap, need_out, s->mb->enc_bytes)) ||
+          (rc = trace_room(s, 0, s->bins_total, n, &tr)))
+        return rc;
+    }
+    uint64_t a;
+    if ((rc = live_call(s, kLiveEnc, (uint32_t)n, s->pend_ops.data(), s->pend_bins.data(), &a))) return rc;
+    s->mb->enc_bytes = (uint32_t)(a >> 32);
+    s->bins_total += n;
+    s->pend_bins.clear();
+    s->pend_ops.clear();
+    return ISSCABAC_OK;
+  }
+  if (n == 0) {  // (the mailbox's byte count is current either way)
+    if (!s->live) HIP_TRY(e, hipStreamSynchronize(e->stream));
     return ISSCABAC_OK;
   }
   int rc;
+  if ((rc = live_stop(s))) return rc;
   // the mailbox holds the byte count of everything coded so far (the stream is synchronised between calls)
   if ((rc = stream_grow(e, &s->d_out, &s->out_cap, isscabac_stream_bound((uint32_t)std::min<uint64_t>(s->bins_total + n, 0xFFFFFFF0ull)) + 16,
                         s->mb->enc_bytes)))
@@ -340,13 +593,21 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
   hipError_t err;
   if ((err = hipMalloc(reinterpret_cast<void **>(&s->st), sizeof(StreamDev))) != hipSuccess ||
       (err = hipMalloc(reinterpret_cast<void **>(&s->d_init), kStreamCtx)) != hipSuccess ||
-      (err = hipHostMalloc(reinterpret_cast<void **>(&s->mb), sizeof(StreamMailbox), hipHostMallocMapped)) != hipSuccess ||
+      (err = hipHostMalloc(reinterpret_cast<void **>(&s->mb), sizeof(StreamMailbox), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+      (err = hipStreamCreateWithFlags(&s->live_stream, hipStreamNonBlocking)) != hipSuccess ||
       (err = hipHostGetDevicePointer(reinterpret_cast<void **>(&s->d_mb), s->mb, 0)) != hipSuccess ||
       (err = hipMemcpyAsync(s->d_init, init, kStreamCtx, hipMemcpyHostToDevice, e->stream)) != hipSuccess) {
     isscabac_stream_close(s);
     return engine_fail(e, ISSCABAC_ERR_HIP, "isscabac_stream_open: %s", hipGetErrorString(err));
   }
   memset(s->mb, 0, sizeof(StreamMailbox));
+  {
+    const char *env = getenv("ISSCABAC_STREAM_LIVE");
+    s->live_on = !(env && env[0] == '0');
+    int khz = 0;  // wall_clock64() ticks per millisecond
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) == hipSuccess && khz > 0) s->idle_ticks = (uint64_t)khz;
+    else (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(k_stream_reset, dim3(1), dim3(256), 0, e->stream, s->st, s->d_init);
   if ((err = hipStreamSynchronize(e->stream)) != hipSuccess) {
     isscabac_stream_close(s);
@@ -359,7 +620,9 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
 void isscabac_stream_close(isscabac_stream *s) {
   if (!s) return;
   (void)hipSetDevice(s->e->device);
+  (void)live_stop(s);
   (void)hipStreamSynchronize(s->e->stream);
+  if (s->live_stream) (void)hipStreamDestroy(s->live_stream);
   for (void *p : {(void *)s->st, (void *)s->d_init, (void *)s->d_out, (void *)s->d_io, (void *)s->d_payload,
                   (void *)s->d_trace[0], (void *)s->d_trace[1]})
     if (p) (void)hipFree(p);
@@ -371,6 +634,7 @@ int isscabac_stream_set_trace(isscabac_stream *s, int enabled) {
   if (!s) return ISSCABAC_ERR_ARG;
   if (s->encoding || s->decoding)
     return engine_fail(s->e, ISSCABAC_ERR_STATE, "isscabac_stream_set_trace: switch tracing before encodeStart / decodeStart");
+  if (const int rc = live_stop(s)) return rc;
   s->tracing = enabled != 0;
   return ISSCABAC_OK;
 }
@@ -380,6 +644,7 @@ int isscabac_stream_encode_start(isscabac_stream *s) {
   isscabac_engine *e = s->e;
   if (s->encoding) return engine_fail(e, ISSCABAC_ERR_STATE, "encodeStart: the bitstream is already open for writing");  // ref asserts, CABAC_BitstreamFile.cpp:52
   HIP_TRY(e, hipSetDevice(e->device));
+  if (const int rc = live_stop(s)) return rc;
   hipLaunchKernelGGL(k_stream_enc_start, dim3(1), dim3(1), 0, e->stream, s->st, s->d_mb);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -412,6 +677,11 @@ int isscabac_stream_encode_ops(isscabac_stream *s, const uint8_t *bins, const ui
 int isscabac_stream_encode_bins(isscabac_stream *s, const uint8_t *bins, const uint8_t *ctx, uint32_t n) {
   if (!s) return ISSCABAC_ERR_ARG;
   if (n && !ctx) return engine_fail(s->e, ISSCABAC_ERR_ARG, "encodeBin: null buffer");
+  if (n <= kInlineOps) {  // (the per-bin callers: no heap traffic)
+    uint16_t small[kInlineOps];
+    for (uint32_t i = 0; i < n; i++) op_from_u8(s, ctx[i], &small[i]);
+    return isscabac_stream_encode_ops(s, bins, small, n);
+  }
   std::vector<uint16_t> ops(n);
   for (uint32_t i = 0; i < n; i++) op_from_u8(s, ctx[i], &ops[i]);
   return isscabac_stream_encode_ops(s, bins, ops.data(), n);
@@ -435,6 +705,7 @@ int isscabac_stream_encode_finish(isscabac_stream *s, uint8_t *out, uint64_t cap
   if (!s->enc_done) {
     int rc = stream_flush_pending(s);
     if (rc) return rc;
+    if ((rc = live_stop(s))) return rc;
     if ((rc = stream_grow(e, &s->d_out, &s->out_cap, isscabac_stream_bound((uint32_t)std::min<uint64_t>(s->bins_total, 0xFFFFFFF0ull)) + 16,
                           s->mb->enc_bytes)))
       return rc;
@@ -458,7 +729,9 @@ int isscabac_stream_decode_start(isscabac_stream *s, const uint8_t *payload, uin
   if (!payload && nbytes) return engine_fail(e, ISSCABAC_ERR_ARG, "decodeStart: null payload");
   if (nbytes > 0xFFFFFFF0ull) return engine_fail(e, ISSCABAC_ERR_ARG, "decodeStart: payload too large");
   HIP_TRY(e, hipSetDevice(e->device));
-  int rc = stream_grow(e, &s->d_payload, &s->payload_cap, nbytes + 16, 0);
+  int rc = live_stop(s);
+  if (rc) return rc;
+  rc = stream_grow(e, &s->d_payload, &s->payload_cap, nbytes + 16, 0);
   if (rc) return rc;
   if (nbytes) HIP_TRY(e, hipMemcpyAsync(s->d_payload, payload, nbytes, hipMemcpyHostToDevice, e->stream));
   s->payload_len = nbytes;
@@ -479,9 +752,23 @@ int isscabac_stream_decode_ops(isscabac_stream *s, const uint16_t *ops, uint32_t
   for (uint32_t i = 0; i < n; i++)
     if (const char *why = op_problem(s, ops[i])) return engine_fail(e, ISSCABAC_ERR_ARG, "%s (op 0x%04X, %d contexts)", why, ops[i], s->nctx);
   HIP_TRY(e, hipSetDevice(e->device));
+  if (n <= kLiveMaxOps && s->live_on) {
+    int rc;
+    if (s->tracing && s->trace_cap[1] < 4 * (s->dec_total + n)) {
+      uint32_t *tr;
+      if ((rc = live_stop(s)) || (rc = trace_room(s, 1, s->dec_total, n, &tr))) return rc;
+    }
+    uint64_t a;
+    if ((rc = live_call(s, kLiveDec, n, ops, nullptr, &a))) return rc;
+    if (n == 1) bins_out[0] = (uint8_t)(a >> 32);
+    else memcpy(bins_out, s->mb->bins, n);
+    s->dec_total += n;
+    return ISSCABAC_OK;
+  }
   uint32_t *tr;
-  int rc = trace_room(s, 1, s->dec_total, n, &tr);
+  int rc = live_stop(s);
   if (rc) return rc;
+  if ((rc = trace_room(s, 1, s->dec_total, n, &tr))) return rc;
   if (n <= kInlineOps) {
     InlineOps io;
     memcpy(io.op, ops, n * sizeof(uint16_t));
@@ -505,6 +792,11 @@ int isscabac_stream_decode_ops(isscabac_stream *s, const uint16_t *ops, uint32_t
 int isscabac_stream_decode_bins(isscabac_stream *s, const uint8_t *ctx, uint32_t n, uint8_t *bins_out) {
   if (!s) return ISSCABAC_ERR_ARG;
   if (n && !ctx) return engine_fail(s->e, ISSCABAC_ERR_ARG, "decodeBin: null buffer");
+  if (n <= kInlineOps) {
+    uint16_t small[kInlineOps];
+    for (uint32_t i = 0; i < n; i++) op_from_u8(s, ctx[i], &small[i]);
+    return isscabac_stream_decode_ops(s, small, n, bins_out);
+  }
   std::vector<uint16_t> ops(n);
   for (uint32_t i = 0; i < n; i++) op_from_u8(s, ctx[i], &ops[i]);
   return isscabac_stream_decode_ops(s, ops.data(), n, bins_out);
@@ -515,6 +807,7 @@ int isscabac_stream_decode_finish(isscabac_stream *s, uint32_t *status) {
   isscabac_engine *e = s->e;
   if (!s->decoding) return engine_fail(e, ISSCABAC_ERR_STATE, "decodeFinish before decodeStart");
   HIP_TRY(e, hipSetDevice(e->device));
+  if (const int rc = live_stop(s)) return rc;
   hipLaunchKernelGGL(k_stream_dec_finish, dim3(1), dim3(64), 0, e->stream, s->st, s->d_mb, s->d_payload);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -566,6 +859,7 @@ int isscabac_stream_get_stats(isscabac_stream *s, int decoder, int ctx, uint8_t 
     const int rc = stream_flush_pending(s);
     if (rc) return rc;
   }
+  if (const int rc = live_stop(s)) return rc;  // (its records reach device memory for a copy engine when it has left)
   const uint64_t n = decoder ? s->dec_total : s->bins_total;
   std::vector<uint32_t> rec(n);
   if (n) {

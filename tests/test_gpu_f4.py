@@ -242,3 +242,59 @@ def test_tr_and_fl32_binarisers_encode_like_the_oracle(engine, oracle, method, k
             assert int(nbins[s]) == want_nb
         with pytest.raises(EngineError):  # no end-of-symbol rule in the reference: not decodable there either
             engine.decode_symbols(payload, offsets, R, params, init)
+
+
+@pytest.mark.parametrize("live", ["1", "0"])
+@pytest.mark.parametrize("tracing", [False, True])
+def test_handle_short_calls_with_and_without_the_live_kernel(engine, oracle, live, tracing, monkeypatch):
+    """decodeBin, and getNumBits behind a few queued encodeBin, are served by the handle's live kernel (one lane polling the
+    mailbox; ISSCABAC_STREAM_LIVE=0 = a launch per call): the same bytes, byte counts, bins, traces and status either way.
+    Calls of every size are mixed -- short ones go through the live kernel, long ones stop it and launch -- and the handle
+    is left alone for longer than the kernel's idle time in between, so that it leaves and is started again."""
+    import time
+    from isscabac_amd import Stream
+    monkeypatch.setenv("ISSCABAC_STREAM_LIVE", live)
+    rng = np.random.default_rng(int(live) * 2 + int(tracing))
+    nctx, n = 40, 3000
+    ctx = rng.integers(0, nctx, n).astype(np.uint8)
+    ctx[rng.random(n) < 0.15] = 0xFF
+    p = rng.random(nctx)
+    bins = np.where(ctx == 0xFF, rng.integers(0, 2, n), rng.random(n) < p[np.minimum(ctx, nctx - 1)]).astype(np.uint8)
+    init = rng.integers(0, 126, nctx).astype(np.uint8)
+    want = oracle.encode_stream(bins, ctx, init)
+    st = Stream(engine, init)
+    st.set_trace(tracing)
+    st.encode_start()
+    i, bits = 0, []
+    sizes = [1, 1, 2, 1, 7, 32, 33, 1, 1, 100, 1, 5, 1, 1, 64, 1]
+    k = 0
+    while i < n:
+        m = min(sizes[k % len(sizes)], n - i)
+        st.encode_bins(bins[i:i + m], ctx[i:i + m])
+        i += m
+        bits.append((i, st.num_bits()))
+        if k % 23 == 5:
+            time.sleep(0.004)  # the live kernel leaves after a millisecond without requests
+        k += 1
+    for upto, b in bits[::7]:  # getNumBits after a prefix == 8 x the bytes the oracle has written for that prefix
+        assert b == oracle.encode_stream(bins[:upto], ctx[:upto], init, want_final=True)[1], upto
+    payload = st.encode_finish()
+    assert payload.tobytes() == want.tobytes()
+    st.decode_start(payload)
+    got, i, k = [], 0, 0
+    while i < n:
+        m = min(sizes[(k + 3) % len(sizes)], n - i)
+        got.append(st.decode_bins(ctx[i:i + m]))
+        i += m
+        if k % 29 == 4:
+            time.sleep(0.004)
+        k += 1
+    assert (np.concatenate(got) == bins).all()
+    assert st.decode_finish() == 0
+    if tracing:
+        cc = int(ctx[ctx != 0xFF][0])
+        for side in (False, True):
+            got_t, got_x = st.get_stats(cc, decoder=side)
+            want_t, want_x = oracle.trace_stats(bins, ctx, init, cc, decoder=side)
+            assert got_t.tobytes() == want_t.tobytes() and (got_x == want_x).all(), side
+    st.close()
