@@ -40,7 +40,7 @@ namespace isscabac {
 #define ISSCABAC_PAIR_ALT_ROLES 0  // producer = wave (blockIdx & 1) of the workgroup instead of wave 0: successive workgroups put their
 #endif                             // producers on different SIMDs of the pair they share
 #ifndef ISSCABAC_PAIR_EXP  // timing experiments (wrong output, never in the product build): 1 = B skips its arithmetic, 2 = A skips
-#define ISSCABAC_PAIR_EXP 0  // the state pass, 3 = no barrier between the chunks
+#define ISSCABAC_PAIR_EXP 0  // the state pass, 3 = no barrier between the chunks, 5 = A without the forwarding (no chain: every lookup on the state read ahead)
 #endif
 #ifndef ISSCABAC_PAIR_TILE_PAIR
 #define ISSCABAC_PAIR_TILE_PAIR 1  // A's input tiles by lane pairs (TilePairT: two full-wave LDS stores per part instead of four half-active ones)
@@ -136,6 +136,35 @@ __device__ __forceinline__ void pair_state_pass(const LdsStates &stx, const uint
     }
   };
   uint4 rw;
+  if (ISSCABAC_PAIR_EXP == 5) {
+    // timing only (wrong for repeated contexts): the pass two deep in flight and without forwarding -- what a chain-free
+    // producer would cost
+    uint32_t ats[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const CtxQuad zz = quad_of(g);
+#pragma unroll
+      for (int k = 0; k < 4; k++) ats[4 * g + k] = stx.addr32_of(zz, k);
+    }
+    uint32_t qa = stx.load_at(ats[0]), qb = stx.load_at(ats[1]);
+    uint64_t ent_cur = entry_of(qa, two);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      uint32_t qc = 0;
+      uint64_t ent_next = 0;
+      if (k + 2 < 16) qc = stx.load_at(ats[k + 2]);
+      if (k + 1 < 16) ent_next = entry_of(qb, two);
+      const uint32_t tk = pair_next_of_k(k, word_of(wb, k >> 2) << 3, (uint32_t)(ent_cur >> 32));
+      stx.store_at(ats[k], tk);
+      if (k < 8) f0 |= tk & flag_bit(k);
+      else f1 |= tk & flag_bit(k);
+      set_word(rw, k & 3, (uint32_t)ent_cur);
+      if ((k & 3) == 3) put_rows(rows_at + (k >> 2) * 1024u, rw);
+      ent_cur = ent_next;
+      qb = qc;
+    }
+    return;
+  }
   CtxQuad z = quad_of(0);
   uint32_t at = stx.addr32_of(z, 0), at_prev = 0;
   uint32_t qld = stx.load_at(at);
