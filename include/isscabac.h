@@ -168,7 +168,7 @@ int isscabac_sync(isscabac_engine *e, uint64_t *total_bytes);
  * context indices (16-byte aligned), ISSCABAC_BYPASS16 (0xFFFF) = bypass bin, 1 <= nctx <= ISSCABAC_MAX_CTX16.  An index
  * in [nctx, 0xFFFF) is invalid: that stream's result is unspecified (memory-safe), the others are not affected.  No
  * fixed-probability bins here.  The state image (256 bytes per four contexts and 64 streams) lives in the LDS of a one-wave
- * workgroup: 150 Gbin/s per direction at 999 contexts, 450 at 256, against 1 400 for up to 64 contexts -- use the 8-bit
+ * workgroup: 270 Gbin/s per direction at 999 contexts, 450-670 at 256, against 1 400 for up to 64 contexts -- use the 8-bit
  * calls wherever they apply.  Synchronous. */
 int isscabac_encode_batch16_dev(isscabac_engine *e, const uint8_t *d_bins, const uint16_t *d_ctx16, const uint32_t *d_nbins,
                                 uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,

@@ -56,6 +56,33 @@ def test_batch16_bytes_and_bins_equal_the_reference(eng, nctx):
         assert (dec[s, :nb[s]] == bins[s, :nb[s]]).all() and (dec[s, nb[s]:] == 0).all()
 
 
+@pytest.mark.parametrize("S,nctx,ep", [(1, 999, 0.05), (3, 256, 0.05), (65, 300, 0.01), (2, 999, 0.0), (130, 999, 0.002)])
+def test_batch16_pieces_switch_between_the_straight_and_the_branching_path(eng, S, nctx, ep):
+    """A piece of 16 bins in which every lane codes 16 context bins runs straight-line code, any other one per-lane branches
+    (cabac_wide.hip).  Few streams with a sparse sprinkle of bypass bins make successive pieces alternate between the two --
+    the bin behind a straight piece may be a bypass bin, an invalid index or the stream's end -- where a full wave with
+    bypass bins never leaves the branching path and one without never enters it."""
+    rng = np.random.default_rng(S * 1000 + nctx)
+    B = 1000
+    ctx16 = rng.integers(0, nctx, (S, B)).astype(np.uint16)
+    ctx16[rng.random((S, B)) < ep] = 0xFFFF
+    ctx16[:, 16::160] = 0xFFFF                               # the first bin of a piece behind a straight one
+    ctx16[0, 40:44] = ctx16[0, 39]                           # a run across the word boundary
+    p1 = rng.random(nctx + 1)
+    bins = (rng.random((S, B)) < p1[np.minimum(ctx16, nctx)]).astype(np.uint8)
+    init = rng.integers(0, 126, nctx).astype(np.uint8)
+    nb = np.full(S, B, np.uint32)
+    nb[-1] = 16 * 37 + 5                                     # one stream ends inside a piece
+    payload, offsets = eng.encode16(bins, ctx16, init, nb)
+    coder, want = _oracle_streams(bins, ctx16, init, nb)
+    for s in range(S):
+        assert payload[int(offsets[s]):int(offsets[s + 1])].tobytes() == want[s].tobytes(), s
+    dec, status = eng.decode16(payload, offsets, ctx16, init, nb)
+    assert (status == 0).all()
+    for s in range(S):
+        assert (dec[s, :nb[s]] == bins[s, :nb[s]]).all() and (dec[s, nb[s]:] == 0).all()
+
+
 def test_batch16_corrupted_payloads_decode_like_the_reference(eng):
     from oracle import pyoracle
     rng = np.random.default_rng(5)
