@@ -748,12 +748,22 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                   psel = da.R >> 29;
                   psh = ISSCABAC_DEC_LAT_MAD ? 0xFF800000u : 23u;  // the comparison point, or (ISSCABAC_DEC_LAT_MAD) -(1 << it)
                 }
+#if ISSCABAC_DEC_LAT_EXP
+                // timing only (wrong for a repeated context): the next bin's entry requested BEFORE this bin's decision, by the
+                // state read ahead -- what a perfect speculation of the decoder's state fetch could reach
+                uint64_t ent_n = 0;
+                if (i < 15) ent_n = stx.entry_raw(qld_nxt);
+#endif
                 const uint32_t nx = ISSCABAC_DEC_LAT_MAD ? dec_bin_nx_abs_at_mad(da, ent, psel, psh) : dec_bin_nx_abs_at(da, ent, psel, psh);
+#if ISSCABAC_DEC_LAT_EXP
+                ent = ent_n;
+#else
                 if (i < 15) {
                   uint32_t qn;
                   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
                   ent = stx.entry_raw(qn);
                 }
+#endif
 #if ISSCABAC_DEC_LAT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -1182,6 +1182,9 @@ CABAC_HD uint32_t dec_bin_nx_abs_at(DecAbs &a, uint64_t ent, uint32_t sel, uint3
 // negp = -(1 << sh) (fits the signed 24-bit operand of v_mad_i32_i24: sh <= 23), so that the chain from the entry's arrival to
 // the decision is perm -> mad -> sub-with-borrow instead of perm -> shift -> sub -> sub-with-borrow; LPS << sh itself (the
 // new R on the LPS path) is R - that, beside the chain.  negp is worked out with the positions, in the entry read's shadow.
+#ifndef ISSCABAC_DEC_LAT_EXP
+#define ISSCABAC_DEC_LAT_EXP 0  // timing experiment (wrong bins, never in the product build): k_decode<.., LAT, ..> without the forwarding
+#endif
 #ifndef ISSCABAC_DEC_LAT_MAD
 #define ISSCABAC_DEC_LAT_MAD 0
 #endif
