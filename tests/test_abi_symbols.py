@@ -49,6 +49,24 @@ def test_engine_fails_loudly_without_gpu():
         ia.Engine(0)
 
 
+def test_native_programs_compile_against_the_header_and_fail_loudly_without_gpu(tmp_path):
+    """examples/simple_cabac.cpp and tests/perf/per_bin_native.cpp use the C ABI from compiled code: they must build against
+    include/isscabac.h + the library as they are, and -- the product has no CPU coding path -- stop with the engine's error
+    where there is no GPU (on a GPU box tests/test_gpu_parity.py runs the example to its known answer)"""
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "isscabac_amd", "lib")
+    for src in (os.path.join(root, "examples", "simple_cabac.cpp"), os.path.join(root, "tests", "perf", "per_bin_native.cpp")):
+        exe = str(tmp_path / os.path.basename(src)[:-4])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", lib,
+                               "-lisscabac_hip", "-Wl,-rpath," + lib, "-Wl,--allow-shlib-undefined"])
+        if not torch.cuda.is_available():
+            env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+            out = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120, env=env)
+            assert out.returncode != 0 and "isscabac_create" in out.stderr, out.stdout + out.stderr
+
+
 def test_stream_file_container_round_trip(oracle, tmp_path):
     """one-file-per-stream <-> packed payload+offsets through the C ABI; the files are what the reference
     writes.  Host-only calls: they run without a GPU."""

@@ -1068,3 +1068,18 @@ def test_kernel_time_series_reports_no_truncation_for_a_short_run(engine):
     s = engine.kernel_ms_samples()
     assert len(s["encode"]) == 3 and len(s["scan"]) == 3 and all(v == 0 for v in engine.kernel_ms_samples_dropped().values())
     engine.set_profiling(False)
+
+
+def test_the_native_example_program(tmp_path):
+    """examples/simple_cabac.cpp: the reference's stand-alone driver sequence (ref: CABAC/SimpleCABAC.cpp:63-103) through the C
+    ABI from a compiled program -- per-bin handle and batch call -- must give AB B1 2F 09 and decode back (exit code 0)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "simple_cabac")
+    lib = os.path.join(root, "isscabac_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "simple_cabac.cpp"),
+                           "-o", exe, "-L", lib, "-lisscabac_hip", "-Wl,-rpath," + lib, "-Wl,--allow-shlib-undefined"])
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "4 bytes: AB B1 2F 09" in out.stdout and "AB B1 2F 09 and back" in out.stdout
