@@ -35,8 +35,11 @@ struct WideStates {
   __device__ __forceinline__ void store_at(uint32_t c, uint32_t q) const { *at(c) = (uint8_t)q; }
   __device__ __forceinline__ uint32_t load(uint32_t c) const { return load_at(c); }
   __device__ __forceinline__ void store(uint32_t c, uint32_t q) const { store_at(c, q); }
-  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return tab[q >> 2]; }
-  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return tab[64 + (q >> 2)]; }
+  // (by absolute LDS address -- the tables start at LDS 0, no static __shared__ in these kernels: checked at the launch -- so
+  // that the address is ONE instruction on the bin-to-bin chain and the second table's offset folds into the read)
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  __device__ __forceinline__ uint32_t lps_row(uint32_t q) const { return *reinterpret_cast<const lds_u32 *>((uintptr_t)(q & 0xFCu)); }
+  __device__ __forceinline__ uint32_t next_entry(uint32_t q) const { return *reinterpret_cast<const lds_u32 *>((uintptr_t)(256u + (q & 0xFCu))); }
 };
 
 // The same image with the state of the NEXT bin requested one bin ahead: the read is issued before the
@@ -63,8 +66,8 @@ __device__ __forceinline__ uint32_t wide_ctx_of(const uint4 &c0, const uint4 &c1
 
 // The encoder's policy: the single-lookup step (one 8-byte entry per bin: row + successors by bin + LPS flags) on the same image
 struct WideEncStates {
-  uint8_t *img;         // the image + lane * 4
-  const uint8_t *tab8;  // 128 x 8 bytes
+  uint8_t *img;   // the image + lane * 4
+  uint32_t two;   // the constant 2 in a register (the SDWA shift's first operand)
   uint32_t last_c, last_q, pre_q, cur_q;
   __device__ __forceinline__ uint8_t *at(uint32_t c) const { return img + (((c & ~3u) << 6) | (c & 3u)); }
   __device__ __forceinline__ void request(uint32_t c) { pre_q = *at(c); }
@@ -73,9 +76,15 @@ struct WideEncStates {
   __device__ __forceinline__ void store_at(uint32_t c, uint32_t t) {
     *at(c) = (uint8_t)t;
     last_c = c;
-    last_q = t & 0xFFu;
+    last_q = t;  // (only its low byte is the state: entry_mem reads byte 0)
   }
-  __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const uint64_t *>(tab8 + ((q & 0xFEu) << 2)); }
+  // the entry of the doubled state in the LOW BYTE of q, at LDS address (q >> 1) * 8 = byte 0 of q << 2 -- one SDWA shift on the
+  // bin-to-bin chain; the table starts at LDS address 0 (no static __shared__ in this kernel: checked at the launch)
+  __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(two), "v"(q));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)a);
+  }
 };
 // Bin policy of enc_bin_row_acc for one bin in a register
 struct WideBin {
@@ -139,7 +148,7 @@ __global__ void __launch_bounds__(64) k_encode_wide(WideEncArgs a) {
     for (uint32_t g = 0; g < (a.nctx + 3u) / 4u; g++) img32[g * 64] = (init32[g] & 0x7F7F7F7Fu) << 1;  // four contexts a word
   }
   __syncthreads();
-  WideEncStates fs{smem + kWideEncTab + lane * 4, smem, ~0u, 0u, 0u, 0u};
+  WideEncStates fs{smem + kWideEncTab + lane * 4, opaque(2u), ~0u, 0u, 0u, 0u};
   EncCore e;
   enc_start(e);
   SlotSink sink;
@@ -359,6 +368,14 @@ hipError_t launch_encode_wide(const uint8_t *d_bins, const uint16_t *d_ctx, cons
                               uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_slots, uint64_t slot_stride,
                               uint32_t *d_lens, hipStream_t stream) {
   WideEncArgs a{d_bins, d_ctx, d_nbins, d_slots, d_lens, d_ctx_init, S, slot_stride, nbins, pitch, nctx};
+  static int static_lds = -1;  // absolute LDS addresses in the kernel: its dynamic LDS must start at 0
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    const hipError_t err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_encode_wide));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
   static bool granted[64] = {};  // per device: 999 contexts need 66 048 bytes, above the 64 KiB a kernel gets without asking
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -376,6 +393,14 @@ hipError_t launch_decode_wide(const uint8_t *d_payload, uint64_t payload_bytes, 
                               const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uint32_t pitch, uint32_t nctx,
                               const uint8_t *d_ctx_init, uint8_t *d_bins_out, uint32_t *d_status, hipStream_t stream) {
   WideDecArgs a{d_payload, d_ctx, d_offsets, d_nbins, d_bins_out, d_status, d_ctx_init, S, payload_bytes, nbins, pitch, nctx};
+  static int static_lds = -1;  // absolute LDS addresses in the kernel: its dynamic LDS must start at 0
+  if (static_lds < 0) {
+    hipFuncAttributes fa;
+    const hipError_t err = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_decode_wide));
+    if (err != hipSuccess) return err;
+    static_lds = (int)fa.sharedSizeBytes;
+  }
+  if (static_lds != 0) return hipErrorInvalidConfiguration;
   hipLaunchKernelGGL(k_decode_wide, dim3((unsigned)((S + 63) / 64)), dim3(64), wide_lds_bytes(nctx, false), stream, a);
   return hipGetLastError();
 }
