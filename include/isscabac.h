@@ -325,7 +325,7 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
  * the reference's exact write-out cadence, so getNumBits between bins reports what the reference reports.  encodeBin
  * queues on the host; calls that need an answer at once (decodeBin, getNumBits behind up to 32 queued bins) are served
  * by a live kernel polling a pinned mailbox -- about 2.3 us per call, against 12.6 us for a launch and a synchronisation
- * (ISSCABAC_STREAM_LIVE=0 switches it off); it leaves after 1 ms without requests.  This is the compatibility path
+ * (ISSCABAC_STREAM_LIVE=0 switches it off); it leaves after 200 us without requests, and at once when anything else is enqueued for the engine.  This is the compatibility path
  * (cabacWrapper.encodeBin / decodeBin one bin at a time, context chosen by the caller from already decoded bins);
  * throughput lives in the batch calls.  A handle is not thread safe.
  *

@@ -296,7 +296,7 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   if (rc) return rc;
   if (!d_bins || !d_ctx || !d_payload || !d_offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch_dev: null buffer");
   if (misaligned(d_bins) || misaligned(d_ctx)) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch_dev: bins/ctx must be 16-byte aligned");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t stride = slot_stride_for(nbins);
   // (growing the scratch frees the old one, which waits for the device: only the first call of a size pays that)
   if ((rc = grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
@@ -333,7 +333,7 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
 
 int isscabac_sync(isscabac_engine *e, uint64_t *total_bytes) {
   if (!e) return ISSCABAC_ERR_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const int rc = engine_sync(e);
   if (rc) return rc;
   if (e->pending_total) {
@@ -365,7 +365,7 @@ int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload
   if (!d_payload || !d_offsets || !d_ctx || !d_bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: null buffer");
   if (misaligned(d_ctx) || misaligned(d_bins_out) || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch_dev: ctx/bins_out must be 16-byte aligned, payload 4-byte aligned");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   if ((rc = ensure_words(e))) return rc;
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 1, &ps))) return rc;
@@ -390,7 +390,7 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
   const int rc = isscabac_decode_batch_dev_async(e, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, S, nbins, pitch,
                                                  ctx_init, nctx, d_bins_out, d_status);
   if (rc) return rc;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   return engine_sync(e);
 }
 
@@ -411,7 +411,7 @@ static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     init[c] = ctx_init[c];
   }
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   if (!e->wide_init) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->wide_init), sizeof init));
   // (a blocking copy of 1 KiB out of this stack frame: the previous call's kernels have long read theirs -- every wide call synchronises)
   HIP_TRY(e, hipMemcpyAsync(e->wide_init, init, sizeof init, hipMemcpyHostToDevice, e->stream));
@@ -464,7 +464,7 @@ int isscabac_encode_batch16(isscabac_engine *e, const uint8_t *bins, const uint1
                             uint64_t *offsets, uint64_t *total_bytes) {
   if (!e) return ISSCABAC_ERR_ARG;
   if (!bins || !ctx16 || !payload || !offsets || S == 0 || pitch == 0) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16: null buffer or empty batch");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t nb = S * pitch, dev_cap = S * isscabac_stream_bound(nbins);
   int rc;
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
@@ -498,7 +498,7 @@ int isscabac_decode_batch16(isscabac_engine *e, const uint8_t *payload, const ui
   for (uint64_t s = 0; s < S; s++)
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
       return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: offsets not monotone at stream %llu", (unsigned long long)s);
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t nb = S * pitch, total = offsets[S];
   int rc;
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
@@ -590,7 +590,7 @@ static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *c
   int rc = check_shape(e, who, S, nbins, pitch, ctx_init, nctx, &sh);
   if (rc) return rc;
   if (!bins || !ctx || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "%s: null buffer", who);
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch;
   // worst-case payload on device so that the gather can never overflow; copy back only what is used
@@ -669,7 +669,7 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
   for (uint64_t s = 0; s < S; s++)
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
       return fail(e, ISSCABAC_ERR_ARG, "%s: offsets not monotone at stream %llu", who, (unsigned long long)s);
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   if ((rc = pipe_init(e))) return rc;
   const uint64_t in_bytes = S * pitch, total = offsets[S];
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], in_bytes))) return rc;  // decoded bins
@@ -745,7 +745,7 @@ int isscabac_set_profiling(isscabac_engine *e, int enabled) {
 int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]) {
   if (!e || !ms) return ISSCABAC_ERR_ARG;
   if (e->prof_count) {
-    HIP_TRY(e, hipSetDevice(e->device));
+    ENGINE_ENTER(e);
     const int rc = engine_sync(e);
     if (rc) return rc;
   }
@@ -756,7 +756,7 @@ int isscabac_last_kernel_ms(isscabac_engine *e, float ms[4]) {
 int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4]) {
   if (!e || !ms) return ISSCABAC_ERR_ARG;
   if (e->prof_count) {
-    HIP_TRY(e, hipSetDevice(e->device));
+    ENGINE_ENTER(e);
     const int rc = engine_sync(e);
     if (rc) return rc;
   }
@@ -772,7 +772,7 @@ int isscabac_kernel_ms_mean(isscabac_engine *e, float ms[4], uint32_t launches[4
 int isscabac_kernel_ms_samples(isscabac_engine *e, int slot, float *ms, uint32_t cap, uint32_t *count) {
   if (!e || slot < 0 || slot > 3 || !count || (cap && !ms)) return ISSCABAC_ERR_ARG;
   if (e->prof_count) {
-    HIP_TRY(e, hipSetDevice(e->device));
+    ENGINE_ENTER(e);
     const int rc = engine_sync(e);
     if (rc) return rc;
   }
@@ -796,7 +796,7 @@ int isscabac_synth_fill_dev(isscabac_engine *e, uint32_t seed, uint64_t s0, uint
   if (!d_bins || !d_ctx || S == 0 || pitch == 0 || (pitch & 15u) || nbins > pitch || nctx < 1 || nctx > ISSCABAC_MAX_CTX ||
       misaligned(d_bins) || misaligned(d_ctx))
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_synth_fill_dev: bad argument");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   HIP_TRY(e, launch_synth(seed, s0, S, nbins, pitch, nctx, ep_half, d_bins, d_ctx, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
@@ -804,21 +804,21 @@ int isscabac_synth_fill_dev(isscabac_engine *e, uint32_t seed, uint64_t s0, uint
 
 int isscabac_dev_alloc(isscabac_engine *e, uint64_t bytes, void **d_ptr) {
   if (!e || !d_ptr) return ISSCABAC_ERR_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   HIP_TRY(e, hipMalloc(d_ptr, bytes ? bytes : 16));
   return ISSCABAC_OK;
 }
 
 int isscabac_dev_free(isscabac_engine *e, void *d_ptr) {
   if (!e) return ISSCABAC_ERR_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   HIP_TRY(e, hipFree(d_ptr));
   return ISSCABAC_OK;
 }
 
 int isscabac_copy_h2d(isscabac_engine *e, void *d_dst, const void *h_src, uint64_t bytes) {
   if (!e) return ISSCABAC_ERR_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   HIP_TRY(e, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;
@@ -826,7 +826,7 @@ int isscabac_copy_h2d(isscabac_engine *e, void *d_dst, const void *h_src, uint64
 
 int isscabac_copy_d2h(isscabac_engine *e, void *h_dst, const void *d_src, uint64_t bytes) {
   if (!e) return ISSCABAC_ERR_ARG;
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   HIP_TRY(e, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return ISSCABAC_OK;

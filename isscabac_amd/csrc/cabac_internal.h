@@ -54,6 +54,9 @@ struct isscabac_engine {
   // small symbol batches: one pinned, device-mapped block the kernels read and write directly (cabac_symbols.hip)
   uint8_t *sym_pin = nullptr;
   uint64_t sym_pin_bytes = 0;
+  // per-bin handles opened on this engine (cabac_stream.hip): their live kernels are stopped before anything else is
+  // launched for the engine -- a polling kernel must never stand in front of another kernel in a hardware queue
+  std::vector<isscabac_stream *> handles;
   size_t sym_cnt_lds = 0;  // dynamic LDS granted to the statistics kernel so far (cabac_symbols.hip: k_encode_symbols<true>)
   // what isscabac_sync has to report about the most recent (async) encode
   uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]
@@ -144,6 +147,18 @@ hipError_t launch_order(const uint32_t *d_nbins, uint64_t S, uint32_t nbins, uin
 // bins as bits <-> bins as bytes (rows of pitch / 8 and pitch bytes), for the packed host-buffer entry points
 hipError_t launch_unpack_bits(const uint8_t *d_packed, uint8_t *d_bins, uint64_t S, uint32_t pitch, hipStream_t stream);
 hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S, uint32_t pitch, hipStream_t stream);
+// per-bin handles (cabac_stream.hip): make the live kernels of the engine's handles (all but `except`) leave and wait until they have
+int engine_quiesce_live(isscabac_engine *e, isscabac_stream *except);
+// first statement of every entry point that enqueues work for an engine
+#define ENGINE_ENTER(e)                                             \
+  do {                                                              \
+    HIP_TRY(e, hipSetDevice((e)->device));                          \
+    if (!(e)->handles.empty()) {                                    \
+      const int rcq_ = isscabac::engine_quiesce_live((e), nullptr); \
+      if (rcq_) return rcq_;                                        \
+    }                                                               \
+  } while (0)
+
 // batches of more than 255 contexts: 16-bit context indices, one wave per workgroup with the state image in its LDS (cabac_wide.hip)
 hipError_t launch_encode_wide(const uint8_t *d_bins, const uint16_t *d_ctx, const uint32_t *d_nbins, uint64_t S, uint32_t nbins,
                               uint32_t pitch, uint32_t nctx, const uint8_t *d_ctx_init, uint8_t *d_slots, uint64_t slot_stride,

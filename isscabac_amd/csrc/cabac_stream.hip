@@ -15,7 +15,7 @@
 // Calls that need an answer at once -- decodeBin, and getNumBits behind a few queued encodeBin -- are served by a LIVE
 // kernel: one lane that holds the coder in registers and polls a request word in the pinned mailbox, so that such a call is
 // one write over the link and one word back instead of a kernel launch and a stream synchronisation (10 -> 3-4 us).  It leaves
-// by itself after a millisecond without requests and is started again by the next call; everything else (start, finish, long
+// by itself after 200 us without requests and is started again by the next call; everything else (start, finish, long
 // calls, traces) stops it first and runs as ordinary launches on the engine's stream.
 //
 // With tracing on, every op leaves a 4-byte record on the device: getEncoderStats / getDecoderStats of the reference's
@@ -394,7 +394,7 @@ struct isscabac_stream {
   bool live = false;          // a live kernel has been started and not yet been seen to leave
   hipStream_t live_stream = nullptr;
   uint32_t live_seq = 0;
-  uint64_t idle_ticks = 100000;  // one millisecond of wall_clock64()
+  uint64_t idle_ticks = 20000;  // 200 us of wall_clock64() at 100 MHz (set from the device's clock rate at open)
 };
 
 static int stream_grow(isscabac_engine *e, uint8_t **p, uint64_t *cap, uint64_t need, uint64_t keep) {
@@ -427,6 +427,7 @@ static int trace_room(isscabac_stream *s, int side, uint64_t have, uint64_t n, u
 static inline uint64_t mb_load64(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static inline uint32_t mb_load32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
+static int quiesce_others(isscabac_stream *s);
 static int live_launch(isscabac_stream *s) {
   isscabac_engine *e = s->e;
   __atomic_store_n(&s->mb->exited, 0u, __ATOMIC_RELEASE);
@@ -453,7 +454,7 @@ static int live_call(isscabac_stream *s, uint32_t cmd, uint32_t n, const uint16_
   __atomic_store_n(&mb->req, word, __ATOMIC_RELEASE);
   if (s->live && mb_load32(&mb->exited)) s->live = false;  // it left since the last call (its write-back is behind that word)
   int rc;
-  if (!s->live && (rc = live_launch(s))) return rc;
+  if (!s->live && ((rc = quiesce_others(s)) || (rc = live_launch(s)))) return rc;
   std::chrono::steady_clock::time_point t_start;
   for (uint64_t spins = 0;; spins++) {
     uint64_t d = mb_load64(&mb->done);
@@ -469,7 +470,7 @@ static int live_call(isscabac_stream *s, uint32_t cmd, uint32_t n, const uint16_
         s->live = false;
         return ISSCABAC_OK;
       }
-      if ((rc = live_launch(s))) return rc;  // no: the next kernel finds the request word waiting
+      if ((rc = quiesce_others(s)) || (rc = live_launch(s))) return rc;  // no: the next kernel finds the request word waiting
     }
     if ((spins & 0xFFFFu) == 0xFFFFu) {
       // (a kernel that has not answered for seconds: report it instead of spinning for ever)
@@ -482,7 +483,20 @@ static int live_call(isscabac_stream *s, uint32_t cmd, uint32_t n, const uint16_
 }
 
 // make the live kernel leave and wait until it has: afterwards the coder state is in device memory again
+static int live_stop_self(isscabac_stream *s);
+// ... and, since every caller goes on to launch on the engine's stream, the other handles' live kernels too
 static int live_stop(isscabac_stream *s) {
+  const int rc = live_stop_self(s);
+  if (rc) return rc;
+  if (s->e->handles.size() > 1)
+    for (isscabac_stream *h : s->e->handles)
+      if (h != s && h->live) {
+        const int rc2 = live_stop_self(h);
+        if (rc2) return rc2;
+      }
+  return ISSCABAC_OK;
+}
+static int live_stop_self(isscabac_stream *s) {
   if (!s->live) return ISSCABAC_OK;
   isscabac_engine *e = s->e;
   if (!mb_load32(&s->mb->exited)) {
@@ -493,6 +507,14 @@ static int live_stop(isscabac_stream *s) {
   HIP_TRY(e, hipStreamSynchronize(s->live_stream));
   s->live = false;
   return ISSCABAC_OK;
+}
+
+// A polling kernel must never stand in front of another kernel: the runtime maps streams onto a few hardware queues, and a
+// kernel queued behind a live one waits until that one leaves by itself (measured: four handles decoding in turn 500 us per
+// call, a batch call right behind a decodeBin 1 ms; tools/live_interleave.py).  So whatever is enqueued for an engine -- a
+// batch call, another handle's kernels -- first makes the live kernels of the engine's handles leave.
+static int quiesce_others(isscabac_stream *s) {
+  return s->e->handles.size() > 1 ? engine_quiesce_live(s->e, s) : ISSCABAC_OK;
 }
 
 // code the queued ops on the device; leaves the stream synchronised and the mailbox current
@@ -573,6 +595,17 @@ static const char *op_problem(const isscabac_stream *s, uint16_t op) {
   return op < (unsigned)s->nctx ? nullptr : "Error: invalid context index";
 }
 
+namespace isscabac {
+int engine_quiesce_live(isscabac_engine *e, isscabac_stream *except) {
+  for (isscabac_stream *h : e->handles)
+    if (h != except && h->live) {
+      const int rc = live_stop_self(h);
+      if (rc) return rc;
+    }
+  return ISSCABAC_OK;
+}
+}  // namespace isscabac
+
 extern "C" {
 
 int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, isscabac_stream **out) {
@@ -605,7 +638,7 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
     const char *env = getenv("ISSCABAC_STREAM_LIVE");
     s->live_on = !(env && env[0] == '0');
     int khz = 0;  // wall_clock64() ticks per millisecond
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) == hipSuccess && khz > 0) s->idle_ticks = (uint64_t)khz;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) == hipSuccess && khz > 0) s->idle_ticks = (uint64_t)khz / 5;  // 200 us
     else (void)hipGetLastError();
   }
   hipLaunchKernelGGL(k_stream_reset, dim3(1), dim3(256), 0, e->stream, s->st, s->d_init);
@@ -613,6 +646,7 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
     isscabac_stream_close(s);
     return engine_fail(e, ISSCABAC_ERR_HIP, "isscabac_stream_open: %s", hipGetErrorString(err));
   }
+  e->handles.push_back(s);
   *out = s;
   return ISSCABAC_OK;
 }
@@ -621,6 +655,10 @@ void isscabac_stream_close(isscabac_stream *s) {
   if (!s) return;
   (void)hipSetDevice(s->e->device);
   (void)live_stop(s);
+  {
+    auto &hs = s->e->handles;
+    hs.erase(std::remove(hs.begin(), hs.end(), s), hs.end());
+  }
   (void)hipStreamSynchronize(s->e->stream);
   if (s->live_stream) (void)hipStreamDestroy(s->live_stream);
   for (void *p : {(void *)s->st, (void *)s->d_init, (void *)s->d_out, (void *)s->d_io, (void *)s->d_payload,

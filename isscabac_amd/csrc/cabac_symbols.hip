@@ -914,7 +914,7 @@ int isscabac_iss_init_context_model_dev(isscabac_engine *e, const uint8_t *d_sym
   SymParams P{p->binarization, p->k, p->nq, 1u, p->iss_types, p->nlbp, 0u};
   const uint32_t mb = max_bins_of(P);
   if (mb == 0 || mb > 32) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model_dev: nq = %u not supported", p->nq);
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   int rc = sym_grow(e, &e->scan_tmp, &e->scan_tmp_bytes, kMaxStat * sizeof(unsigned long long));
   if (rc) return rc;
   unsigned long long *d_counts = static_cast<unsigned long long *>(e->scan_tmp);
@@ -933,7 +933,7 @@ int isscabac_iss_init_context_model(isscabac_engine *e, const uint8_t *sym, uint
                                     const isscabac_symbol_params *p, double *p0_out, uint8_t *p0_bytes_out) {
   if (!e) return ISSCABAC_ERR_ARG;
   if (!sym || S == 0 || pitch == 0) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_iss_init_context_model: bad argument");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   int rc = sym_grow(e, &e->stage[0], &e->stage_bytes[0], S * pitch);
   if (rc) return rc;
   HIP_TRY(e, hipMemcpyAsync(e->stage[0], sym, S * pitch, hipMemcpyHostToDevice, e->stream));
@@ -1021,7 +1021,7 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
   if (rc) return rc;
   if (!d_sym || !d_payload || !d_offsets || (reinterpret_cast<uintptr_t>(d_sym) & 15u))
     return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols_dev: null or misaligned buffer");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t stride = slot_stride_for(nsym * maxbins);
   if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;
@@ -1105,7 +1105,7 @@ static int dec_symbols_enqueue(isscabac_engine *e, const uint8_t *d_payload, uin
   if (rc) return rc;
   if (!d_payload || !d_offsets || !d_sym_out || (reinterpret_cast<uintptr_t>(d_payload) & 3u))
     return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols_dev: null or misaligned buffer");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   a.payload = d_payload;
   a.offsets = d_offsets;
   a.nsym_per_stream = d_nsym;
@@ -1216,7 +1216,7 @@ int isscabac_encode_symbols_stats(isscabac_engine *e, const uint8_t *sym, const 
   if (!sym || !payload || !offsets || !params) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols: null buffer");
   const uint32_t maxbins = isscabac_symbol_max_bins(params);
   if (maxbins == 0 || S == 0 || pitch == 0) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols: unsupported parameters");
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t in_bytes = S * pitch, dev_cap = S * isscabac_stream_bound(nsym * maxbins);
   int rc;
   const bool any_stats = stats && (stats->ctx_hist || stats->ctx_cost || stats->sym_bits || stats->bin_trace);
@@ -1319,7 +1319,7 @@ int isscabac_decode_symbols(isscabac_engine *e, const uint8_t *payload, const ui
   for (uint64_t s = 0; s < S; s++)
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
       return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_symbols: offsets not monotone at stream %llu", (unsigned long long)s);
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);
   const uint64_t out_bytes = S * pitch, total = offsets[S];
   int rc;
   {
