@@ -794,7 +794,7 @@ def test_distinct_engines_on_distinct_host_threads(oracle):
     """SURVEY 8(b) threading: a handle is not thread-safe, but distinct handles may be driven from distinct host threads
     at the same time (own stream, own scratch).  Four threads, each with its own engine and its own batches."""
     import threading
-    from isscabac_amd import Engine
+    from isscabac_amd import Engine, Stream
     errors = []
 
     def worker(tid):
@@ -816,6 +816,15 @@ def test_distinct_engines_on_distinct_host_threads(oracle):
                 assert (status == 0).all()
                 for s in range(S):
                     assert (dec[s, :nb[s]] == bins[s, :nb[s]]).all()
+                # ... and its own per-bin handle between the batch calls: the handle's polling live kernel (cabac_stream.hip)
+                # lives beside the other threads' kernels and leaves before this engine's next batch call
+                s0 = int(np.argmax(nb))
+                n0 = min(int(nb[s0]), 60)
+                h = Stream(eng, init)
+                h.decode_start(payload[int(offsets[s0]):int(offsets[s0 + 1])])
+                got = [int(h.decode_bins(ctx[s0, i:i + 1])[0]) for i in range(n0)]
+                assert got == bins[s0, :n0].tolist()
+                h.close()
             eng.close()
         except BaseException as exc:  # noqa: BLE001 - reported by the main thread
             errors.append((tid, repr(exc)))
