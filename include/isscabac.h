@@ -327,7 +327,9 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
  * by a live kernel polling a pinned mailbox -- about 2.3 us per call, against 12.6 us for a launch and a synchronisation
  * (ISSCABAC_STREAM_LIVE=0 switches it off); it leaves after 200 us without requests, and at once when anything else is enqueued for the engine.  This is the compatibility path
  * (cabacWrapper.encodeBin / decodeBin one bin at a time, context chosen by the caller from already decoded bins);
- * throughput lives in the batch calls.  A handle is not thread safe.
+ * throughput lives in the batch calls.  A handle is not thread safe and belongs to its engine: the engine's calls and its
+ * handles' calls must not run concurrently (they share the engine's stream, and the engine stops its handles' live kernels
+ * before it enqueues anything else); handles of different engines are independent.
  *
  *   SimpleCABACMex('initByProb'|'initByState', fn, ctxInit)  -> isscabac_init_by_* + isscabac_stream_open
  *   ('encodeStart', h)        -> isscabac_stream_encode_start      (ref: :186-209)
