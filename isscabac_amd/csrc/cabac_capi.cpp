@@ -119,6 +119,7 @@ void isscabac_destroy(isscabac_engine *e) {
   if (e->h_total) (void)hipHostFree(e->h_total);
   if (e->sym_pin) (void)hipHostFree(e->sym_pin);
   if (e->wide_init) (void)hipFree(e->wide_init);
+  if (e->mat_bins) (void)hipFree(e->mat_bins);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }

@@ -57,6 +57,8 @@ struct isscabac_engine {
   // per-bin handles opened on this engine (cabac_stream.hip): their live kernels are stopped before anything else is
   // launched for the engine -- a polling kernel must never stand in front of another kernel in a hardware queue
   std::vector<isscabac_stream *> handles;
+  void *mat_bins = nullptr;  // a whole matrix as one stream: its bin / context sequence for the bin-level encoder (cabac_symbols.hip)
+  uint64_t mat_bins_bytes = 0;
   size_t sym_cnt_lds = 0;  // dynamic LDS granted to the statistics kernel so far (cabac_symbols.hip: k_encode_symbols<true>)
   // what isscabac_sync has to report about the most recent (async) encode
   uint64_t *h_total = nullptr;  // pinned host word, target of an async copy of offsets[S]

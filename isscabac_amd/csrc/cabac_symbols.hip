@@ -250,6 +250,68 @@ __global__ void __launch_bounds__(256) k_encode_symbols(SymEncArgs a) {
   if (a.nbins_out) a.nbins_out[s] = nbins;
 }
 
+// ---- a whole matrix as ONE stream, encoder: the walk in parallel, the coder on the bin sequence ---------------------------------
+// One stream is one lane, and a lone wave issues an instruction every ~2 ns: the fused symbol kernel spends 150 ns per bin on
+// the reference's real ISS format (16 268 bins for a 400 x 20 matrix: 2.5 ms).  But binarisation and context selection never
+// look across columns (ref: +coder/cabacContextSelection.m:24-67, cabacEncode.m:52), so ONE workgroup walks all columns at
+// once -- lane = column: count the bins of its column, an exclusive scan over the columns, then write its bins and context
+// indices at their place in the stream's sequence -- and the bin-level encoder codes that sequence as a batch of one stream
+// (cabac_pair.hip: 60 ns per bin).  Same bytes: the sequence is the one the fused kernel codes.
+struct MatBinsArgs {
+  const uint8_t *sym;
+  uint8_t *bins, *ctx;
+  uint32_t *nbins_out, *nbins_user;  // the stream's bin count for the encoder / for the caller (nullable)
+  uint32_t nsym, col_rows;
+  SymParams P;  // col_rows = 0: a lane's column is a stream of its own
+};
+constexpr uint32_t kMatCols = 1024;
+__global__ void __launch_bounds__(kMatCols) k_iss_matrix_bins(MatBinsArgs a) {
+  __shared__ uint2 bt[256];
+  __shared__ uint32_t offs[kMatCols + 1];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 256) {
+    const BinString g = binarize(min(tid, a.P.nq - 1), a.P);
+    bt[tid] = make_uint2(g.bits, g.len | (g.np << 8));
+  }
+  __syncthreads();
+  const uint32_t ncols = (a.nsym + a.col_rows - 1) / a.col_rows;
+  const uint32_t first = tid * a.col_rows;
+  const uint32_t cnt = tid < ncols ? min(a.col_rows, a.nsym - first) : 0u;
+  const uint8_t *col = a.sym + first;
+  uint32_t nb = 0;
+  for (uint32_t i = 0; i < cnt; i++) nb += bt[col[i]].y & 0xFFu;
+  offs[tid] = nb;
+  __syncthreads();
+  if (tid == 0) {  // (at most 1 024 columns: a serial scan is microseconds)
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < ncols; c++) {
+      const uint32_t v = offs[c];
+      offs[c] = run;
+      run += v;
+    }
+    offs[kMatCols] = run;
+    *a.nbins_out = run;
+    if (a.nbins_user) *a.nbins_user = run;
+  }
+  __syncthreads();
+  uint32_t o = offs[tid < ncols ? tid : 0];
+  SymWalk w;
+  w.start();
+  while (w.idx < cnt) {
+    if (w.n == 1) {
+      const uint2 g = bt[col[w.idx]];
+      w.cur.bits = g.x;
+      w.cur.len = g.y & 0xFFu;
+      w.cur.np = g.y >> 8;
+    }
+    a.ctx[o] = (uint8_t)w.ctx(a.P);
+    a.bins[o] = (uint8_t)((w.cur.bits >> (w.n - 1)) & 1u);
+    o++;
+    if (w.n == w.cur.len) w.next_symbol(a.P);
+    else w.n++;
+  }
+}
+
 struct SymDevMem {
   const uint8_t *base;
   uint64_t avail;
@@ -1022,6 +1084,46 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
   if (!d_sym || !d_payload || !d_offsets || (reinterpret_cast<uintptr_t>(d_sym) & 15u))
     return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_symbols_dev: null or misaligned buffer");
   ENGINE_ENTER(e);
+  // a whole matrix as one stream: walk the columns in parallel, code the bin sequence with the bin-level encoder (see
+  // k_iss_matrix_bins); the statistics want the fused kernel's per-bin cadence and keep it
+  const uint64_t mat_bins = (uint64_t)nsym * maxbins, mat_pitch = (mat_bins + 15) & ~15ull;
+  if (S == 1 && !d_nsym && !d_stats && a.P.col_rows != 0 && a.P.selector == ISSCABAC_SEL_ISS &&
+      (nsym + a.P.col_rows - 1) / a.P.col_rows <= kMatCols && mat_pitch <= ISSCABAC_MAX_PITCH && getenv("ISSCABAC_SYM_NO_MATRIX_SPLIT") == nullptr) {
+    const uint64_t stride1 = slot_stride_for((uint32_t)mat_pitch);
+    if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, stride1))) return rc;
+    if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, sizeof(uint32_t)))) return rc;
+    if ((rc = sym_grow(e, &e->scan_tmp, &e->scan_tmp_bytes, scan_tmp_bytes(1)))) return rc;
+    if ((rc = sym_grow(e, &e->mat_bins, &e->mat_bins_bytes, 2 * mat_pitch + 16))) return rc;
+    uint8_t *mb = static_cast<uint8_t *>(e->mat_bins);
+    MatBinsArgs m;
+    m.sym = d_sym;
+    m.bins = mb;
+    m.ctx = mb + mat_pitch;
+    m.nbins_out = reinterpret_cast<uint32_t *>(mb + 2 * mat_pitch);
+    m.nbins_user = d_nbins_out;
+    m.nsym = nsym;
+    m.col_rows = a.P.col_rows;
+    m.P = a.P;
+    m.P.col_rows = 0;
+    hipLaunchKernelGGL(k_iss_matrix_bins, dim3(1), dim3(kMatCols), 0, e->stream, m);
+    HIP_TRY(e, hipGetLastError());
+    BatchShape sh;
+    memset(&sh, 0, sizeof sh);
+    sh.S = 1;
+    sh.nbins = (uint32_t)mat_bins;
+    sh.pitch = (uint32_t)mat_pitch;
+    sh.nctx = (uint32_t)nctx;
+    sh.latency = true;
+    sh.tiny = true;
+    sh.d_order = nullptr;
+    memcpy(sh.ctx_init, a.ctx_init, 64);
+    for (int c = 64; c < 256; c++) sh.ctx_init[c] = 1;
+    HIP_TRY(e, launch_encode(sh, m.bins, m.ctx, m.nbins_out, e->slots, stride1, e->lens, e->stream));
+    if ((rc = sym_ensure_words(e))) return rc;
+    HIP_TRY(e, launch_scan_gather(e->slots, stride1, e->lens, 1, d_offsets, e->scan_tmp, d_payload, payload_cap, e->stream, e->flag + 2,
+                                  host_word >= 0 ? e->h_total_dev + host_word : nullptr));
+    return ISSCABAC_OK;
+  }
   const uint64_t stride = slot_stride_for(nsym * maxbins);
   if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, S * stride))) return rc;
   if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->lens), &e->lens_bytes, S * sizeof(uint32_t)))) return rc;

@@ -1092,3 +1092,30 @@ def test_the_native_example_program(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "4 bytes: AB B1 2F 09" in out.stdout and "AB B1 2F 09 and back" in out.stdout
+
+
+@pytest.mark.parametrize("rows,cols,tail,nq,method,k,types,nlbp", [
+    (400, 20, 0, 8, "EG", 0, 15, 3), (7, 1, 0, 4, "TU", 0, 15, 3), (33, 70, 5, 16, "EG", 1, 31, 2), (5, 1000, 3, 8, "EG", 2, 3, 4),
+    (109, 20, 0, 8, "EG", 0, 15, 3), (64, 64, 63, 12, "TU", 0, 12, 1)])
+def test_whole_matrix_stream_walked_in_parallel_equals_the_fused_kernel(engine, oracle, monkeypatch, rows, cols, tail, nq, method, k, types, nlbp):
+    """A whole matrix as ONE stream (the reference's real ISS format, +coder/cabacEncode.m:45-70): the encoder walks the columns
+    in parallel and hands the bin sequence to the bin-level encoder (cabac_symbols.hip: k_iss_matrix_bins).  Same bytes and bin
+    count as the fused symbol kernel (ISSCABAC_SYM_NO_MATRIX_SPLIT=1) and as the oracle; a last column that is cut short,
+    one column, more columns than a wave has lanes; decodes back."""
+    from isscabac_amd import SymbolParams
+    rng = np.random.default_rng(rows * 1000 + cols)
+    n = rows * cols + tail  # `tail` symbols of one more, shorter column
+    sym = np.minimum(rng.exponential(1.3, (1, n)).astype(np.int64), nq - 1).astype(np.uint8)
+    nctx = 7 * nlbp + 2
+    init = rng.integers(0, 126, nctx).astype(np.uint8)
+    mp = SymbolParams.iss(nq, method, k, types, nlbp, col_rows=rows)
+    p1, o1, nb1 = engine.encode_symbols(sym, mp, init)
+    monkeypatch.setenv("ISSCABAC_SYM_NO_MATRIX_SPLIT", "1")
+    p2, o2, nb2 = engine.encode_symbols(sym, mp, init)
+    monkeypatch.delenv("ISSCABAC_SYM_NO_MATRIX_SPLIT")
+    assert p1.tobytes() == p2.tobytes() and (o1 == o2).all() and nb1[0] == nb2[0]
+    if tail == 0:
+        want, wnb = oracle.iss_encode_matrix(sym.reshape(cols, rows).T.copy(), nq, method, k, types, nlbp, init)
+        assert p1.tobytes() == want.tobytes() and int(nb1[0]) == wnb
+    dec, st = engine.decode_symbols(p1, o1, n, mp, init)
+    assert st[0] == 0 and (dec[0, :n] == sym[0]).all()
