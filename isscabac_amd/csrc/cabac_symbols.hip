@@ -1087,7 +1087,7 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
   // a whole matrix as one stream: walk the columns in parallel, code the bin sequence with the bin-level encoder (see
   // k_iss_matrix_bins); the statistics want the fused kernel's per-bin cadence and keep it
   const uint64_t mat_bins = (uint64_t)nsym * maxbins, mat_pitch = (mat_bins + 15) & ~15ull;
-  if (S == 1 && !d_nsym && !d_stats && a.P.col_rows != 0 && a.P.selector == ISSCABAC_SEL_ISS &&
+  if (S == 1 && nsym != 0 && !d_nsym && !d_stats && a.P.col_rows != 0 && a.P.selector == ISSCABAC_SEL_ISS &&
       (nsym + a.P.col_rows - 1) / a.P.col_rows <= kMatCols && mat_pitch <= ISSCABAC_MAX_PITCH && getenv("ISSCABAC_SYM_NO_MATRIX_SPLIT") == nullptr) {
     const uint64_t stride1 = slot_stride_for((uint32_t)mat_pitch);
     if ((rc = sym_grow(e, reinterpret_cast<void **>(&e->slots), &e->slots_bytes, stride1))) return rc;
