@@ -790,77 +790,99 @@ enum { ST_A_PRE, ST_Z_PRE, ST_D_C, ST_J_C0, ST_Y0_C, ST_J_C1, ST_Y1_C, ST_D_B, S
        ST_J_CS0, ST_Y0_CS, ST_J_CS1, ST_Y1_CS, ST_PER_N };
 constexpr int kMaxStat = 8 * ST_PER_N + 4;
 
+// One thread per matrix cell, a grid-stride loop of wave-uniform trip count; every counter is a boolean per cell, so a wave
+// adds it up with ONE ballot + population count and lane 0 adds that to the workgroup's LDS histogram -- the first version did
+// an LDS atomic per lane and counter (64 lanes on one address serialise) and 70 global atomics per 256 cells: 10 ms for 131 M
+// cells against 3.3 ms for coding them (profiles/r05/symbol_host_rate_full.txt).
 __global__ void __launch_bounds__(256) k_iss_ctx_stats(const uint8_t *sym, uint64_t S, uint32_t nsym, uint32_t pitch,
                                                        SymParams P, unsigned long long *counts) {
   __shared__ unsigned int hist[kMaxStat];
+  __shared__ uint2 bt[256];  // every symbol value binarised once: {bits, len | np << 8}, np = position of the first 0 (or len)
   const int nstat = (int)P.nlbp * ST_PER_N + 4;
   for (int i = threadIdx.x; i < nstat; i += 256) hist[i] = 0;
+  {
+    const BinString g = binarize(min((uint32_t)threadIdx.x, P.nq - 1), P);
+    uint32_t np = first_zero_1based(g.bits, g.len);
+    if (!np) np = g.len;
+    bt[threadIdx.x] = make_uint2(g.bits, g.len | (np << 8));
+  }
   __syncthreads();
-  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid < S * nsym) {
-    const uint64_t col = gid / nsym;
-    const uint32_t d = (uint32_t)(gid % nsym);
-    const uint8_t *row = sym + col * pitch;
-    const BinString cur = binarize(row[d], P);
-    uint32_t np = first_zero_1based(cur.bits, cur.len);
-    if (!np) np = cur.len;
-    // the cell above the first row is a NaN in the reference: length 1, np_up1 = 0, equal to neither 0 nor 1
-    BinString up{0, 1};
-    uint32_t np_up = 0;
-    const bool nan_up = d == 0;
-    if (!nan_up) {
-      up = binarize(row[d - 1], P);
-      np_up = first_zero_1based(up.bits, up.len);
-      if (!np_up) np_up = up.len;
+  const int lane = threadIdx.x & 63;
+  const uint64_t total = S * nsym, step = (uint64_t)gridDim.x * 256;
+  // counter i += number of lanes with cond (all 64 lanes of the wave get here together)
+  auto count = [&](unsigned int *h, int i, bool cond) {
+    const unsigned long long m = __ballot(cond);
+    if (lane == 0 && m) atomicAdd(&h[i], (unsigned int)__popcll(m));
+  };
+  auto sum = [&](unsigned int *h, int i, uint32_t v) {  // counter i += sum of v over the wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    if (lane == 0 && v) atomicAdd(&h[i], v);
+  };
+  auto bit = [](uint32_t bits, uint32_t i) { return (bits >> ((i - 1) & 31u)) & 1u; };  // 1-based (evaluated for every cell: the count's condition says whether i is a position)
+  for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += step) {  // (base is the same for the whole workgroup)
+    const uint64_t gid = base + threadIdx.x;
+    const bool in = gid < total;
+    uint32_t cb = 0, cl = 1, np = 1, ub = 0, ul = 1, np_up = 0;
+    bool nan_up = true;
+    if (in) {
+      const uint64_t col = gid / nsym;
+      const uint32_t d = (uint32_t)(gid - col * nsym);
+      const uint8_t *row = sym + col * pitch;
+      const uint2 c = bt[row[d]];
+      cb = c.x;
+      cl = c.y & 0xFFu;
+      np = c.y >> 8;
+      // the cell above the first row is a NaN in the reference: length 1, np_up1 = 0, equal to neither 0 nor 1
+      nan_up = d == 0;
+      if (!nan_up) {
+        const uint2 u = bt[row[d - 1]];
+        ub = u.x;
+        ul = u.y & 0xFFu;
+        np_up = u.y >> 8;
+      }
     }
-    auto bit = [](BinString g, uint32_t i) { return (g.bits >> (i - 1)) & 1u; };  // 1-based
     for (uint32_t n = 1; n <= P.nlbp; n++) {
       unsigned int *h = hist + (n - 1) * ST_PER_N;
-      if (n <= np) {
-        atomicAdd(&h[ST_A_PRE], 1u);
-        if (bit(cur, n) == 0) atomicAdd(&h[ST_Z_PRE], 1u);
-      }
-      if (n <= np && n <= np_up) {  // np_up == 0 on the first row
-        const uint32_t y = bit(up, n), x = bit(cur, n);
-        atomicAdd(&h[ST_D_C], 1u);
-        if (y == 0) atomicAdd(&h[ST_Y0_C], 1u);
-        else atomicAdd(&h[ST_Y1_C], 1u);
-        if (x == 0 && y == 0) atomicAdd(&h[ST_J_C0], 1u);
-        if (x == 0 && y == 1) atomicAdd(&h[ST_J_C1], 1u);
-      }
-      if (n + 1 <= np && np_up < n + 1) {
-        atomicAdd(&h[ST_D_B], 1u);
-        if (bit(cur, n) == 1) {
-          atomicAdd(&h[ST_X1_B], 1u);
-          if (bit(cur, n + 1) == 0) atomicAdd(&h[ST_J_B], 1u);
-        }
-      }
-      if (n + np <= cur.len) {
-        atomicAdd(&h[ST_D_S], 1u);
-        if (bit(cur, n + np) == 0) atomicAdd(&h[ST_Z_S], 1u);
-        if (n + np_up <= up.len) {
-          atomicAdd(&h[ST_D_CS], 1u);
-          if (!nan_up) {
-            const uint32_t ys = bit(up, n + np_up), yn = bit(up, n), x = bit(cur, n + np);
-            if (x == 0 && ys == 0) atomicAdd(&h[ST_J_CS0], 1u);
-            if (x == 0 && ys == 1) atomicAdd(&h[ST_J_CS1], 1u);
-            if (yn == 0) atomicAdd(&h[ST_Y0_CS], 1u);  // the reference normalises with y(n), not y(n + np_up1) (:96,:108)
-            else atomicAdd(&h[ST_Y1_CS], 1u);
-          }
-        }
-      }
+      const bool pre = in && n <= np;
+      count(h, ST_A_PRE, pre);
+      count(h, ST_Z_PRE, pre && bit(cb, n) == 0);
+      const bool c2 = pre && n <= np_up;  // np_up == 0 on the first row
+      const uint32_t y = bit(ub, n), x = bit(cb, n);
+      count(h, ST_D_C, c2);
+      count(h, ST_Y0_C, c2 && y == 0);
+      count(h, ST_Y1_C, c2 && y != 0);
+      count(h, ST_J_C0, c2 && x == 0 && y == 0);
+      count(h, ST_J_C1, c2 && x == 0 && y == 1);
+      const bool b2 = in && n + 1 <= np && np_up < n + 1;
+      count(h, ST_D_B, b2);
+      count(h, ST_X1_B, b2 && x == 1);
+      count(h, ST_J_B, b2 && x == 1 && bit(cb, n + 1) == 0);
+      const bool s2 = in && n + np <= cl;
+      count(h, ST_D_S, s2);
+      count(h, ST_Z_S, s2 && bit(cb, n + np) == 0);
+      const bool cs = s2 && n + np_up <= ul;
+      count(h, ST_D_CS, cs);
+      const bool cs2 = cs && !nan_up;
+      const uint32_t ys = bit(ub, n + np_up), xs = bit(cb, n + np);
+      count(h, ST_J_CS0, cs2 && xs == 0 && ys == 0);
+      count(h, ST_J_CS1, cs2 && xs == 0 && ys == 1);
+      count(h, ST_Y0_CS, cs2 && y == 0);  // the reference normalises with y(n), not y(n + np_up1) (:96,:108)
+      count(h, ST_Y1_CS, cs2 && y != 0);
     }
     unsigned int *r = hist + P.nlbp * ST_PER_N;
     const uint32_t n = P.nlbp + 1;
-    if (n <= np) {
-      const uint32_t cnt = np - n + 1, seg = (cur.bits >> (n - 1)) & low_mask(cnt);
-      atomicAdd(&r[0], cnt);
-      atomicAdd(&r[1], cnt - (uint32_t)__popc(seg));
+    {
+      const bool t = in && n <= np;
+      const uint32_t cnt = t ? np - n + 1 : 0u, seg = (cb >> (n - 1)) & low_mask(cnt);
+      sum(r, 0, cnt);
+      sum(r, 1, t ? cnt - (uint32_t)__popc(seg) : 0u);
     }
-    if (n > np && n <= cur.len) {
-      const uint32_t cnt = cur.len - n + 1, seg = (cur.bits >> (n - 1)) & low_mask(cnt);
-      atomicAdd(&r[2], cnt);
-      atomicAdd(&r[3], cnt - (uint32_t)__popc(seg));
+    {
+      const bool t = in && n > np && n <= cl;
+      const uint32_t cnt = t ? cl - n + 1 : 0u, seg = (cb >> (n - 1)) & low_mask(cnt);
+      sum(r, 2, cnt);
+      sum(r, 3, t ? cnt - (uint32_t)__popc(seg) : 0u);
     }
   }
   __syncthreads();
@@ -981,7 +1003,9 @@ int isscabac_iss_init_context_model_dev(isscabac_engine *e, const uint8_t *d_sym
   if (rc) return rc;
   unsigned long long *d_counts = static_cast<unsigned long long *>(e->scan_tmp);
   HIP_TRY(e, hipMemsetAsync(d_counts, 0, kMaxStat * sizeof(unsigned long long), e->stream));
-  const uint64_t nblk = (S * nsym + 255) / 256;
+  // (a workgroup's LDS counters are 32 bits: at most 2^22 cells per workgroup leave a factor of eight below 2^32 for nlbp + 32 bins)
+  const uint64_t cells = S * (uint64_t)nsym, want = (cells + 255) / 256, cap = (uint64_t)e->num_cus * 16;
+  const uint64_t nblk = std::max<uint64_t>(std::min(want, cap), (cells + (1ull << 22) - 1) >> 22);
   hipLaunchKernelGGL(k_iss_ctx_stats, dim3((unsigned)nblk), dim3(256), 0, e->stream, d_sym, S, nsym, pitch, P, d_counts);
   HIP_TRY(e, hipGetLastError());
   unsigned long long counts[kMaxStat];
