@@ -793,7 +793,8 @@ constexpr int kMaxStat = 8 * ST_PER_N + 4;
 // One thread per matrix cell, a grid-stride loop of wave-uniform trip count; every counter is a boolean per cell, so a wave
 // adds it up with ONE ballot + population count and lane 0 adds that to the workgroup's LDS histogram -- the first version did
 // an LDS atomic per lane and counter (64 lanes on one address serialise) and 70 global atomics per 256 cells: 10 ms for 131 M
-// cells against 3.3 ms for coding them (profiles/r05/symbol_host_rate_full.txt).
+// cells against 3.3 ms for coding them (profiles/r05/symbol_host_rate_full.txt).  (The ballot's count travels through lane j of a
+// register to counter j, see `count` below.)
 __global__ void __launch_bounds__(256) k_iss_ctx_stats(const uint8_t *sym, uint64_t S, uint32_t nsym, uint32_t pitch,
                                                        SymParams P, unsigned long long *counts) {
   __shared__ unsigned int hist[kMaxStat];
@@ -809,16 +810,16 @@ __global__ void __launch_bounds__(256) k_iss_ctx_stats(const uint8_t *sym, uint6
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t total = S * nsym, step = (uint64_t)gridDim.x * 256;
-  // counter i += number of lanes with cond (all 64 lanes of the wave get here together)
-  auto count = [&](unsigned int *h, int i, bool cond) {
-    const unsigned long long m = __ballot(cond);
-    if (lane == 0 && m) atomicAdd(&h[i], (unsigned int)__popcll(m));
-  };
-  auto sum = [&](unsigned int *h, int i, uint32_t v) {  // counter i += sum of v over the wave
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    if (lane == 0 && v) atomicAdd(&h[i], v);
-  };
+  // counter j of the current bin position += number of lanes with cond (all 64 lanes of the wave get here together): the
+  // population count of the ballot goes into LANE j of `vec` (v_writelane), and ONE LDS add per bin position, lane j on
+  // counter j, moves the 17 counts to the workgroup's histogram -- three instructions per counter, no branch
+  uint32_t vec = 0;
+#define ST_COUNT(J, COND)                                                                \
+  do {                                                                                   \
+    const uint32_t c_ = (uint32_t)__popcll(__ballot(COND)); /* wave-uniform */           \
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(c_), "n"(J));                     \
+  } while (0)
+  uint32_t r_acc[4] = {0, 0, 0, 0};  // the four "rest" counters are sums: kept per lane, reduced once behind the loop
   auto bit = [](uint32_t bits, uint32_t i) { return (bits >> ((i - 1) & 31u)) & 1u; };  // 1-based (evaluated for every cell: the count's condition says whether i is a position)
   for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += step) {  // (base is the same for the whole workgroup)
     const uint64_t gid = base + threadIdx.x;
@@ -844,51 +845,63 @@ __global__ void __launch_bounds__(256) k_iss_ctx_stats(const uint8_t *sym, uint6
     }
     for (uint32_t n = 1; n <= P.nlbp; n++) {
       unsigned int *h = hist + (n - 1) * ST_PER_N;
+      vec = 0;
       const bool pre = in && n <= np;
-      count(h, ST_A_PRE, pre);
-      count(h, ST_Z_PRE, pre && bit(cb, n) == 0);
+      ST_COUNT(ST_A_PRE, pre);
+      ST_COUNT(ST_Z_PRE, pre && bit(cb, n) == 0);
       const bool c2 = pre && n <= np_up;  // np_up == 0 on the first row
       const uint32_t y = bit(ub, n), x = bit(cb, n);
-      count(h, ST_D_C, c2);
-      count(h, ST_Y0_C, c2 && y == 0);
-      count(h, ST_Y1_C, c2 && y != 0);
-      count(h, ST_J_C0, c2 && x == 0 && y == 0);
-      count(h, ST_J_C1, c2 && x == 0 && y == 1);
+      ST_COUNT(ST_D_C, c2);
+      ST_COUNT(ST_Y0_C, c2 && y == 0);
+      ST_COUNT(ST_Y1_C, c2 && y != 0);
+      ST_COUNT(ST_J_C0, c2 && x == 0 && y == 0);
+      ST_COUNT(ST_J_C1, c2 && x == 0 && y == 1);
       const bool b2 = in && n + 1 <= np && np_up < n + 1;
-      count(h, ST_D_B, b2);
-      count(h, ST_X1_B, b2 && x == 1);
-      count(h, ST_J_B, b2 && x == 1 && bit(cb, n + 1) == 0);
+      ST_COUNT(ST_D_B, b2);
+      ST_COUNT(ST_X1_B, b2 && x == 1);
+      ST_COUNT(ST_J_B, b2 && x == 1 && bit(cb, n + 1) == 0);
       const bool s2 = in && n + np <= cl;
-      count(h, ST_D_S, s2);
-      count(h, ST_Z_S, s2 && bit(cb, n + np) == 0);
+      ST_COUNT(ST_D_S, s2);
+      ST_COUNT(ST_Z_S, s2 && bit(cb, n + np) == 0);
       const bool cs = s2 && n + np_up <= ul;
-      count(h, ST_D_CS, cs);
+      ST_COUNT(ST_D_CS, cs);
       const bool cs2 = cs && !nan_up;
       const uint32_t ys = bit(ub, n + np_up), xs = bit(cb, n + np);
-      count(h, ST_J_CS0, cs2 && xs == 0 && ys == 0);
-      count(h, ST_J_CS1, cs2 && xs == 0 && ys == 1);
-      count(h, ST_Y0_CS, cs2 && y == 0);  // the reference normalises with y(n), not y(n + np_up1) (:96,:108)
-      count(h, ST_Y1_CS, cs2 && y != 0);
+      ST_COUNT(ST_J_CS0, cs2 && xs == 0 && ys == 0);
+      ST_COUNT(ST_J_CS1, cs2 && xs == 0 && ys == 1);
+      ST_COUNT(ST_Y0_CS, cs2 && y == 0);  // the reference normalises with y(n), not y(n + np_up1) (:96,:108)
+      ST_COUNT(ST_Y1_CS, cs2 && y != 0);
+      if (lane < ST_PER_N && vec) atomicAdd(&h[lane], vec);
     }
-    unsigned int *r = hist + P.nlbp * ST_PER_N;
     const uint32_t n = P.nlbp + 1;
     {
       const bool t = in && n <= np;
       const uint32_t cnt = t ? np - n + 1 : 0u, seg = (cb >> (n - 1)) & low_mask(cnt);
-      sum(r, 0, cnt);
-      sum(r, 1, t ? cnt - (uint32_t)__popc(seg) : 0u);
+      r_acc[0] += cnt;
+      r_acc[1] += t ? cnt - (uint32_t)__popc(seg) : 0u;
     }
     {
       const bool t = in && n > np && n <= cl;
       const uint32_t cnt = t ? cl - n + 1 : 0u, seg = (cb >> (n - 1)) & low_mask(cnt);
-      sum(r, 2, cnt);
-      sum(r, 3, t ? cnt - (uint32_t)__popc(seg) : 0u);
+      r_acc[2] += cnt;
+      r_acc[3] += t ? cnt - (uint32_t)__popc(seg) : 0u;
+    }
+  }
+  {  // (a lane sees at most 2^22 / 256 cells of at most 32 bins: far below 2^32)
+    unsigned int *r = hist + P.nlbp * ST_PER_N;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t v = r_acc[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+      if (lane == 0 && v) atomicAdd(&r[i], v);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nstat; i += 256)
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
 }
+#undef ST_COUNT
 
 static uint32_t max_bins_of(const SymParams &P) {
   if (P.nq < 2 || P.nq > 256) return 0;
