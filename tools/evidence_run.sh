@@ -30,6 +30,9 @@ echo "== tools/per_bin_rate.py"; python tools/per_bin_rate.py
 echo "== tests/perf/per_bin_native.cpp (the per-bin commands from C++; second run: ISSCABAC_STREAM_LIVE=0)"
 mkdir -p tests/_build && g++ -O2 -std=c++17 -I include tests/perf/per_bin_native.cpp -o tests/_build/per_bin_native -L isscabac_amd/lib -lisscabac_hip -Wl,-rpath,"$GRAFT_REPO_ROOT/isscabac_amd/lib" -Wl,--allow-shlib-undefined && { LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-} timeout 300 tests/_build/per_bin_native; LD_LIBRARY_PATH=/opt/rocm/lib:${LD_LIBRARY_PATH:-} ISSCABAC_STREAM_LIVE=0 timeout 300 tests/_build/per_bin_native; }
 echo "== tools/wide_rate.py"; python tools/wide_rate.py 65536 1024 999; python tools/wide_rate.py 1048576 1024 999; python tools/wide_rate.py 1048576 1024 500; python tools/wide_rate.py 1048576 1024 256
+echo "== tools/init_rate.py"; python tools/init_rate.py
+echo "== tools/iss_matrix_rate.py"; python tools/iss_matrix_rate.py
+echo "== tools/live_interleave.py"; python tools/live_interleave.py
 echo "== tests/perf/symbol_host_rate.py --real-only"; python tests/perf/symbol_host_rate.py --real-only
 } > $O/other_shapes.txt 2>&1
 tail -3 $O/other_shapes.txt
