@@ -177,7 +177,7 @@ def main():
                                                            "mode, per GPU in weak mode)")
     ap.add_argument("--chunk-streams", type=int, default=CHUNK_STREAMS, help="streams per kernel launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency"),
+    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency", "latency_single"),
                     help="kernel instance (isscabac_set_tuning); auto picks by launch size")
     ap.add_argument("--round-trip", action="store_true", help="config2: time encode + decode instead of its encode-only step")
     ap.add_argument("--no-verify", action="store_true")
@@ -302,7 +302,17 @@ def main():
     totals = [int(b["offsets"][-1]) for b in bufs]
     for b, tot in zip(bufs, totals):
         assert tot <= b["cap"], "payload buffer too small"
+    # what each rank saw, for the line (a first N-GPU run must explain itself: which rank was slow, which kernels it ran)
+    mine = {"rank": rank, "device": local_rank, "ms_per_step": elapsed / args.steps * 1e3, "streams": my_streams,
+            "launches_per_step": len(bufs), "payload_bytes": int(sum(totals)),
+            "encode_instance": eng.last_instance("encode"), "decode_instance": eng.last_instance("decode"),
+            "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+    per_rank = [mine]
+    dist_info = None
     if multi:
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "launcher_world_size": world}
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -416,6 +426,9 @@ def main():
             "gather_ms": gather_ms,
             "gather_ok": gather_ok,
             "gather_bytes": gather_bytes,
+            "gather_GBps": gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms and gather_bytes else None,
+            "dist": dist_info,    # the process group as torch.distributed reports it (None: one rank, no group)
+            "per_rank": per_rank,  # every rank's own wall time per step, shard, kernel instances and kernel times
         }
         if args.cpu_seconds > 0:
             b0 = bufs[0]  # rank 0's first launch starts at global stream 0 in both modes

@@ -91,12 +91,22 @@ int isscabac_abi_version(void);
  *   AUTO        by launch size: the latency-oriented instance when the launch leaves at most two waves on a SIMD
  *               (up to 512 streams per compute unit: 128 Ki streams on an MI355X), else the throughput one
  *   THROUGHPUT  fewest instructions per bin; relies on four resident waves per SIMD to hide LDS latency
- *   LATENCY     state prefetch + register forwarding, no LDS round trip on the range recurrence; for small batches
+ *   LATENCY     state prefetch + register forwarding, no LDS round trip on the range recurrence; for small batches.
+ *               With <= 64 contexts the encoder runs as a producer / consumer wave pair, and so does the decoder for
+ *               launches of at most two waves of streams per compute unit
+ *   LATENCY_SINGLE  the latency-oriented instances on ONE wave per 64 streams whatever the launch size -- what AUTO
+ *               runs for the decoder between 32 Ki and 128 Ki streams (a strong-scaled job's per-GPU share); lets
+ *               tests and A/B runs reach those instances with small batches
  * (a strong-scaled job leaves each GPU 1/N of the streams: SURVEY.md 8(e)) */
 #define ISSCABAC_TUNE_AUTO 0
 #define ISSCABAC_TUNE_THROUGHPUT 1
 #define ISSCABAC_TUNE_LATENCY 2
+#define ISSCABAC_TUNE_LATENCY_SINGLE 3
 int isscabac_set_tuning(isscabac_engine *e, int mode);
+/* the kernel instance the engine's most recent 8-bit batch call launched: which = 0 encode ("k_encode_pair",
+ * "k_encode<1,false,false>" = <context-image size class, latency-oriented, length-bucketed>, ...), 1 decode.  A string
+ * owned by the library, "" before the first call.  For tests, A/B runs and the bench line; results never depend on it */
+const char *isscabac_last_instance(const isscabac_engine *e, int which);
 /* use this HIP stream (hipStream_t) for all work of the engine; NULL = the engine's own stream */
 int isscabac_set_stream(isscabac_engine *e, void *hip_stream);
 
@@ -325,11 +335,16 @@ uint32_t isscabac_symbol_max_bins(const isscabac_symbol_params *params);
  * the reference's exact write-out cadence, so getNumBits between bins reports what the reference reports.  encodeBin
  * queues on the host; calls that need an answer at once (decodeBin, getNumBits behind up to 32 queued bins) are served
  * by a live kernel polling a pinned mailbox -- about 2.3 us per call, against 12.6 us for a launch and a synchronisation
- * (ISSCABAC_STREAM_LIVE=0 switches it off); it leaves after 200 us without requests, and at once when anything else is enqueued for the engine.  This is the compatibility path
+ * (ISSCABAC_STREAM_LIVE=0 switches it off); it leaves after 200 us without requests, after 2 ms of residency whatever the
+ * traffic (the next call starts the next one), and at once when anything else is enqueued for the engine.  Work of OTHER
+ * engines or other HIP users in the process that the runtime maps onto the same hardware queue can wait behind it for up to
+ * those 2 ms.  This is the compatibility path
  * (cabacWrapper.encodeBin / decodeBin one bin at a time, context chosen by the caller from already decoded bins);
  * throughput lives in the batch calls.  A handle is not thread safe and belongs to its engine: the engine's calls and its
  * handles' calls must not run concurrently (they share the engine's stream, and the engine stops its handles' live kernels
- * before it enqueues anything else); handles of different engines are independent.
+ * before it enqueues anything else); handles of different engines are independent.  Close a handle before isscabac_destroy
+ * of its engine; a handle that outlives its engine is stopped by the destroy, answers ISSCABAC_ERR_STATE to every call and
+ * can only be closed.
  *
  *   SimpleCABACMex('initByProb'|'initByState', fn, ctxInit)  -> isscabac_init_by_* + isscabac_stream_open
  *   ('encodeStart', h)        -> isscabac_stream_encode_start      (ref: :186-209)
@@ -391,6 +406,10 @@ typedef struct isscabac_multi isscabac_multi;
 int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out);
 void isscabac_destroy_multi(isscabac_multi *m);
 int isscabac_multi_device_count(const isscabac_multi *m);
+/* how device g's shard reaches the root (device 0 of the list) in the final gather: 0 = same device, 1 = peer access
+ * (hipDeviceCanAccessPeer was true and it is enabled: xGMI / P2P copy), 2 = no peer access, hipMemcpyPeerAsync stages through
+ * the host; -1 = bad argument.  ISSCABAC_MULTI_LOG=1 prints one line per pair at isscabac_create_multi */
+int isscabac_multi_peer_access(const isscabac_multi *m, int g);
 isscabac_engine *isscabac_multi_engine(isscabac_multi *m, int g); /* engine g, e.g. for isscabac_dev_alloc / isscabac_set_tuning */
 const char *isscabac_multi_last_error(const isscabac_multi *m);
 void isscabac_multi_shard(const isscabac_multi *m, uint64_t S, int g, uint64_t *first, uint64_t *end);

@@ -94,6 +94,7 @@ int isscabac_create(int device, isscabac_engine **out) {
 void isscabac_destroy(isscabac_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  if (!e->handles.empty()) engine_orphan_handles(e);  // per-bin handles still open: their live kernels leave, they can only be closed from now on
   (void)hipStreamSynchronize(e->stream);
   if (e->slots) (void)hipFree(e->slots);
   if (e->lens) (void)hipFree(e->lens);
@@ -128,10 +129,14 @@ const char *isscabac_last_error(const isscabac_engine *e) { return e ? e->err.c_
 
 int isscabac_set_tuning(isscabac_engine *e, int mode) {
   if (!e) return ISSCABAC_ERR_ARG;
-  if (mode != ISSCABAC_TUNE_AUTO && mode != ISSCABAC_TUNE_THROUGHPUT && mode != ISSCABAC_TUNE_LATENCY)
+  if (mode != ISSCABAC_TUNE_AUTO && mode != ISSCABAC_TUNE_THROUGHPUT && mode != ISSCABAC_TUNE_LATENCY && mode != ISSCABAC_TUNE_LATENCY_SINGLE)
     return fail(e, ISSCABAC_ERR_ARG, "isscabac_set_tuning: unknown mode %d", mode);
   e->tuning = mode;
   return ISSCABAC_OK;
+}
+
+const char *isscabac_last_instance(const isscabac_engine *e, int which) {
+  return e && (which == 0 || which == 1) && e->last_instance[which] ? e->last_instance[which] : "";
 }
 
 int isscabac_set_stream(isscabac_engine *e, void *hip_stream) {
@@ -199,11 +204,12 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   // on the throughput instance wins by 3-5 %.  The switch sits at two waves per SIMD.
   // More than 128 contexts: the state image (256 bytes per four contexts and wave) leaves at most 2.5 waves per SIMD
   // whatever the batch's size, the latency instance's regime: 190 contexts 514 -> 542 Gbin/s, 253 contexts 434 -> 483.
-  sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY ||
+  sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY || e->tuning == ISSCABAC_TUNE_LATENCY_SINGLE ||
                 (e->tuning == ISSCABAC_TUNE_AUTO && (nctx > 128 || S <= 2ull * (uint64_t)e->num_cus * 4 * 64));
   // The decoder's helper wave (cabac_pair.hip: k_decode_pair) takes a fifth of the instructions off the decoding wave but not
   // its chain: same-box sweep 16 Ki streams 0.358 -> 0.306 ms, 64 Ki 0.364 -> 0.363, 128 Ki 0.460 -> 0.486 (profiles/r05)
   sh->tiny = S <= (uint64_t)e->num_cus * ISSCABAC_DEC_PAIR_WAVES_PER_CU * 64;
+  sh->pair = e->tuning != ISSCABAC_TUNE_LATENCY_SINGLE;
   for (int c = 0; c < nctx; c++) {
     if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
     sh->ctx_init[c] = ctx_init[c];
@@ -218,7 +224,9 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
 // small or uniform batches.
 static int bucket_by_length(isscabac_engine *e, BatchShape *sh, const uint32_t *d_nbins) {
   sh->d_order = nullptr;
-  if (!d_nbins || sh->S < 4096 || sh->S >= (1ull << 31) || e->tuning == ISSCABAC_TUNE_LATENCY) return ISSCABAC_OK;
+  if (!d_nbins || sh->S < 4096 || sh->S >= (1ull << 31) || e->tuning == ISSCABAC_TUNE_LATENCY ||
+      e->tuning == ISSCABAC_TUNE_LATENCY_SINGLE)
+    return ISSCABAC_OK;
   int rc;
   if ((rc = grow(e, reinterpret_cast<void **>(&e->order), &e->order_bytes, sh->S * sizeof(uint32_t)))) return rc;
   const uint64_t need = order_tmp_bytes(sh->S);
@@ -310,6 +318,7 @@ int isscabac_encode_batch_dev_async(isscabac_engine *e, const uint8_t *d_bins, c
   if ((rc = bucket_by_length(e, &sh, d_nbins))) return rc;
   PROF_MARK(e, ps, 0);
   HIP_TRY(e, launch_encode(sh, d_bins, d_ctx, d_nbins, e->slots, stride, e->lens, e->stream));
+  e->last_instance[0] = sh.instance;
   PROF_MARK(e, ps, 1);
   // the payload size (offsets[S]) also lands in the engine's pinned word 0, written by the scan kernel itself: the host reads it
   // after its synchronisation, no copy command in the stream
@@ -370,18 +379,26 @@ int isscabac_decode_batch_dev_async(isscabac_engine *e, const uint8_t *d_payload
   if ((rc = ensure_words(e))) return rc;
   isscabac_engine::ProfSlot *ps;
   if ((rc = prof_slot(e, 1, &ps))) return rc;
-  // this call's flag word is zero: the previous call's second kernel left it so (the two words take turns)
+  // this call's flag word is zero: the previous call's second kernel left it so (the two words take turns).  The turn moves on
+  // only when both kernels are in the stream; a failure in between restores "both words zero" with a memset
   uint32_t *flag = e->flag + e->flag_turn, *next_flag = e->flag + (e->flag_turn ^ 1);
-  e->flag_turn ^= 1;
   if ((rc = bucket_by_length(e, &sh, d_nbins))) return rc;
   PROF_MARK(e, ps, 0);
-  HIP_TRY(e, launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream));
-  PROF_MARK(e, ps, 1);
+  hipError_t herr = launch_decode(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream);
+  if (herr == hipSuccess) {
+    e->last_instance[1] = sh.instance;
+    if (ps) herr = hipEventRecord(ps->ev[1], e->stream);
+  }
   // streams that start with 0xFF (corrupt input): the reference's value register overflows on those, and only its own
   // formulation reproduces what it then decodes (cabac_lane.h: RefDec).  The kernel looks at the flag the decode kernel
   // left on the device and returns at once when it is clear, so the host never has to read it.
-  HIP_TRY(e, launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream,
-                                 next_flag));
+  if (herr == hipSuccess)
+    herr = launch_decode_exact(sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, flag, e->stream, next_flag);
+  if (herr != hipSuccess) {
+    (void)hipMemsetAsync(e->flag, 0, 2 * sizeof(uint32_t), e->stream);
+    return fail(e, herr == hipErrorOutOfMemory ? ISSCABAC_ERR_NOMEM : ISSCABAC_ERR_HIP, "isscabac_decode_batch_dev: %s", hipGetErrorString(herr));
+  }
+  e->flag_turn ^= 1;
   return ISSCABAC_OK;
 }
 
@@ -396,8 +413,8 @@ int isscabac_decode_batch_dev(isscabac_engine *e, const uint8_t *d_payload, uint
 }
 
 // ---- batches of more than 255 contexts: 16-bit context indices (cabac_wide.hip) -------------------------------------
-static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init,
-                        int nctx) {
+// pure argument validation (no device work): first thing in the host forms as well as in the device forms
+static int wide_check(isscabac_engine *e, const char *who, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx) {
   if (!e) return ISSCABAC_ERR_ARG;
   if (S == 0) return fail(e, ISSCABAC_ERR_ARG, "%s: S must be > 0", who);
   if (pitch == 0 || (pitch & 15u)) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) must be a positive multiple of 16", who, pitch);
@@ -405,13 +422,18 @@ static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_
   if (pitch > ISSCABAC_MAX_PITCH) return fail(e, ISSCABAC_ERR_ARG, "%s: pitch (%u) exceeds %u bins per stream", who, pitch, (unsigned)ISSCABAC_MAX_PITCH);
   if (nctx < 1 || nctx > ISSCABAC_MAX_CTX16) return fail(e, ISSCABAC_ERR_ARG, "%s: nctx (%d) must be 1..%d", who, nctx, ISSCABAC_MAX_CTX16);
   if (!ctx_init) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init is null", who);
-  if (S > (1ull << 31)) return fail(e, ISSCABAC_ERR_ARG, "%s: S too large", who);
+  if (S > (1ull << 31)) return fail(e, ISSCABAC_ERR_ARG, "%s: S too large", who);  // (S * pitch <= 2^56: no overflow in the callers' sizes)
+  for (int c = 0; c < nctx; c++)
+    if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
+  return ISSCABAC_OK;
+}
+static int wide_prepare(isscabac_engine *e, const char *who, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init,
+                        int nctx) {
+  const int rc = wide_check(e, who, S, nbins, pitch, ctx_init, nctx);
+  if (rc) return rc;
   uint8_t init[1024];
   memset(init, 1, sizeof init);  // contexts the caller did not initialise: the reference's default ContextModel(), (mps 1, state 0)
-  for (int c = 0; c < nctx; c++) {
-    if ((ctx_init[c] >> 1) > 62) return fail(e, ISSCABAC_ERR_ARG, "%s: ctx_init[%d] has state 63 (allowed: 0..62)", who, c);
-    init[c] = ctx_init[c];
-  }
+  memcpy(init, ctx_init, (size_t)nctx);
   ENGINE_ENTER(e);
   if (!e->wide_init) HIP_TRY(e, hipMalloc(reinterpret_cast<void **>(&e->wide_init), sizeof init));
   // (a blocking copy of 1 KiB out of this stack frame: the previous call's kernels have long read theirs -- every wide call synchronises)
@@ -464,10 +486,11 @@ int isscabac_encode_batch16(isscabac_engine *e, const uint8_t *bins, const uint1
                             uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx, uint8_t *payload, uint64_t payload_cap,
                             uint64_t *offsets, uint64_t *total_bytes) {
   if (!e) return ISSCABAC_ERR_ARG;
-  if (!bins || !ctx16 || !payload || !offsets || S == 0 || pitch == 0) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16: null buffer or empty batch");
+  if (!bins || !ctx16 || !payload || !offsets) return fail(e, ISSCABAC_ERR_ARG, "isscabac_encode_batch16: null buffer");
+  int rc;
+  if ((rc = wide_check(e, "isscabac_encode_batch16", S, nbins, pitch, ctx_init, nctx))) return rc;  // before any allocation or copy
   ENGINE_ENTER(e);
   const uint64_t nb = S * pitch, dev_cap = S * isscabac_stream_bound(nbins);
-  int rc;
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
   if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], 2 * nb))) return rc;
   if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
@@ -495,13 +518,14 @@ int isscabac_decode_batch16(isscabac_engine *e, const uint8_t *payload, const ui
                             const uint32_t *nbins_per_stream, uint64_t S, uint32_t nbins, uint32_t pitch, const uint8_t *ctx_init, int nctx,
                             uint8_t *bins_out, uint32_t *status) {
   if (!e) return ISSCABAC_ERR_ARG;
-  if (!payload || !offsets || !ctx16 || !bins_out || S == 0 || pitch == 0) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: null buffer or empty batch");
+  if (!payload || !offsets || !ctx16 || !bins_out) return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: null buffer");
+  int rc;
+  if ((rc = wide_check(e, "isscabac_decode_batch16", S, nbins, pitch, ctx_init, nctx))) return rc;  // before any allocation or copy
   for (uint64_t s = 0; s < S; s++)
     if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] > 0xFFFFFFFFull)
       return fail(e, ISSCABAC_ERR_ARG, "isscabac_decode_batch16: offsets not monotone at stream %llu", (unsigned long long)s);
   ENGINE_ENTER(e);
   const uint64_t nb = S * pitch, total = offsets[S];
-  int rc;
   if ((rc = grow(e, &e->stage[0], &e->stage_bytes[0], nb))) return rc;
   if ((rc = grow(e, &e->stage[1], &e->stage_bytes[1], 2 * nb))) return rc;
   if ((rc = grow(e, &e->stage[2], &e->stage_bytes[2], S * sizeof(uint32_t)))) return rc;
@@ -631,6 +655,7 @@ static int encode_host(isscabac_engine *e, const uint8_t *bins, const uint8_t *c
     if (packed) HIP_TRY(e, launch_unpack_bits(d_bits + s0 * (pitch / 8), d_bins + s0 * pitch, n, pitch, e->stream));
     HIP_TRY(e, launch_encode(g, d_bins + s0 * pitch, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, e->slots + s0 * stride, stride,
                              e->lens + s0, e->stream));
+    e->last_instance[0] = g.instance;
   }
   HIP_TRY(e, launch_scan_gather(e->slots, stride, e->lens, S, d_offsets, e->scan_tmp, d_payload, dev_cap, e->stream));
   if ((rc = ensure_words(e))) return rc;
@@ -708,6 +733,7 @@ static int decode_host(isscabac_engine *e, const uint8_t *payload, const uint64_
     // (offsets are positions in the whole payload: the group's kernels get the array from its first stream on)
     HIP_TRY(e, launch_decode(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr, d_out + s0 * pitch,
                              d_status + s0, e->flag + 3, e->stream));
+    e->last_instance[1] = g.instance;
     // streams that start with 0xFF (corrupt input): redone in the reference's own formulation, see isscabac_decode_batch_dev
     HIP_TRY(e, launch_decode_exact(g, d_payload, total, d_offsets + s0, d_ctx + s0 * pitch, d_nb ? d_nb + s0 : nullptr,
                                    d_out + s0 * pitch, d_status + s0, e->flag + 3, e->stream));

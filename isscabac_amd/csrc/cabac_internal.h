@@ -18,6 +18,7 @@ struct isscabac_engine {
   int device = 0;
   int num_cus = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   int tuning = 0;     // ISSCABAC_TUNE_*
+  const char *last_instance[2] = {"", ""};  // kernel instance of the most recent batch encode / decode (isscabac_last_instance)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
   std::string err;
@@ -103,8 +104,10 @@ struct BatchShape {
   uint32_t nctx;     // contexts (1..255)
   bool latency;      // run the latency-oriented kernel instance (few waves per SIMD), see isscabac_set_tuning
   bool tiny;         // at most two waves of streams per CU: the decoder + helper wave pair pays (cabac_pair.hip)
+  bool pair;         // the wave-pair kernels may run (false: ISSCABAC_TUNE_LATENCY_SINGLE, one wave per 64 streams)
   const uint32_t *d_order;  // device: stream ids sorted by bin count (length-bucketed launch, cabac_order.hip) or null
   uint8_t ctx_init[256];
+  mutable const char *instance;  // out: the kernel instance launch_encode / launch_decode chose (a string literal)
 };
 
 // bytes of HBM slot reserved per stream by the encode kernel (bound + dword slack, 16-byte aligned)
@@ -151,6 +154,7 @@ hipError_t launch_unpack_bits(const uint8_t *d_packed, uint8_t *d_bins, uint64_t
 hipError_t launch_pack_bits(const uint8_t *d_bins, uint8_t *d_packed, uint64_t S, uint32_t pitch, hipStream_t stream);
 // per-bin handles (cabac_stream.hip): make the live kernels of the engine's handles (all but `except`) leave and wait until they have
 int engine_quiesce_live(isscabac_engine *e, isscabac_stream *except);
+void engine_orphan_handles(isscabac_engine *e);  // isscabac_destroy with handles still open
 // first statement of every entry point that enqueues work for an engine
 #define ENGINE_ENTER(e)                                             \
   do {                                                              \

@@ -1270,16 +1270,29 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
 
 // sh.latency selects the latency-oriented instance (cabac_capi.cpp: small launches, and every launch of more than 128
 // contexts, whose occupancy the state image keeps at or below 2.5 waves per SIMD)
-#define ISSCABAC_DISPATCH(FN, ARGS)                                                                     \
+// (sh.instance: the name of the instance that ran, for isscabac_last_instance -- tests and the bench line say which kernel they measured)
+#define ISSCABAC_RUN(FN, KN, CM, LAT, PERM, ARGS) \
+  do {                                           \
+    sh.instance = KN "<" #CM "," #LAT "," #PERM ">"; \
+    return FN<CM, LAT, PERM>(ARGS, stream);      \
+  } while (0)
+#define ISSCABAC_DISPATCH(FN, KN, ARGS)                                                                 \
   do {                                                                                                  \
     if (sh.d_order) { /* length-bucketed launch */                                                      \
-      if (sh.nctx <= 64) return FN<1, false, true>(ARGS, stream);                                       \
-      if (sh.nctx <= 128) return FN<3, false, true>(ARGS, stream);                                      \
-      return FN<2, false, true>(ARGS, stream);                                                          \
+      if (sh.nctx <= 64) ISSCABAC_RUN(FN, KN, 1, false, true, ARGS);                                    \
+      if (sh.nctx <= 128) ISSCABAC_RUN(FN, KN, 3, false, true, ARGS);                                   \
+      ISSCABAC_RUN(FN, KN, 2, false, true, ARGS);                                                       \
     }                                                                                                   \
-    if (sh.nctx <= 64) return sh.latency ? FN<1, true, false>(ARGS, stream) : FN<1, false, false>(ARGS, stream); \
-    if (sh.nctx <= 128) return sh.latency ? FN<3, true, false>(ARGS, stream) : FN<3, false, false>(ARGS, stream); \
-    return sh.latency ? FN<2, true, false>(ARGS, stream) : FN<2, false, false>(ARGS, stream);            \
+    if (sh.nctx <= 64) {                                                                                \
+      if (sh.latency) ISSCABAC_RUN(FN, KN, 1, true, false, ARGS);                                       \
+      ISSCABAC_RUN(FN, KN, 1, false, false, ARGS);                                                      \
+    }                                                                                                   \
+    if (sh.nctx <= 128) {                                                                               \
+      if (sh.latency) ISSCABAC_RUN(FN, KN, 3, true, false, ARGS);                                       \
+      ISSCABAC_RUN(FN, KN, 3, false, false, ARGS);                                                      \
+    }                                                                                                   \
+    if (sh.latency) ISSCABAC_RUN(FN, KN, 2, true, false, ARGS);                                         \
+    ISSCABAC_RUN(FN, KN, 2, false, false, ARGS);                                                        \
   } while (0)
 
 hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint8_t *d_ctx, const uint32_t *d_nbins,
@@ -1299,8 +1312,11 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
   a.img_bytes = image_bytes_for(sh.nctx);
   std::memcpy(a.ctx_init, sh.ctx_init, 256);
   // small launches of <= 64 contexts: the producer / consumer wave pair (cabac_pair.hip)
-  if (sh.latency && !sh.d_order && sh.nctx <= 64 && encode_pair_enabled()) return run_encode_pair(a, stream);
-  ISSCABAC_DISPATCH(run_encode, a);
+  if (sh.latency && sh.pair && !sh.d_order && sh.nctx <= 64 && encode_pair_enabled()) {
+    sh.instance = "k_encode_pair";
+    return run_encode_pair(a, stream);
+  }
+  ISSCABAC_DISPATCH(run_encode, "k_encode", a);
 }
 
 static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
@@ -1339,8 +1355,11 @@ hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_
   DecArgs a;
   fill_dec_args(a, sh, d_payload, payload_bytes, d_offsets, d_ctx, d_nbins, d_bins_out, d_status, d_flag);
   // small launches of <= 64 contexts: the decoder + helper wave pair (cabac_pair.hip)
-  if (sh.latency && sh.tiny && !sh.d_order && sh.nctx <= 64 && decode_pair_enabled()) return run_decode_pair(a, stream);
-  ISSCABAC_DISPATCH(run_decode, a);
+  if (sh.latency && sh.tiny && sh.pair && !sh.d_order && sh.nctx <= 64 && decode_pair_enabled()) {
+    sh.instance = "k_decode_pair";
+    return run_decode_pair(a, stream);
+  }
+  ISSCABAC_DISPATCH(run_decode, "k_decode", a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -9,6 +9,9 @@
 // buffer.  One host thread per device drives its engine, so the devices run concurrently.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstring>
 #include <memory>
 #include <new>
@@ -27,6 +30,9 @@ struct isscabac_multi {
   std::vector<uint64_t> pay_cap;
   std::vector<uint64_t *> d_off;
   std::vector<uint64_t> off_cap;
+  // how device g reaches the root's memory for the gather: 0 = it IS the root's device, 1 = peer access (xGMI / PCIe P2P,
+  // hipDeviceCanAccessPeer said yes and it is enabled), 2 = no peer access: hipMemcpyPeerAsync stages through the host
+  std::vector<int> peer;
 };
 
 namespace isscabac {
@@ -104,13 +110,21 @@ int isscabac_create_multi(const int *device_ids, int n, isscabac_multi **out) {
   m->d_off.assign(n, nullptr);
   m->off_cap.assign(n, 0);
   // peer access root <-> others where the hardware offers it (hipMemcpyPeerAsync works without, through the host)
+  m->peer.assign(n, 0);
+  const char *log = getenv("ISSCABAC_MULTI_LOG");  // set: one line per device pair on stderr (a first multi-GPU run explains itself)
   for (int g = 1; g < n; g++) {
     int can = 0;
-    if (m->dev[g] != m->dev[0] && hipDeviceCanAccessPeer(&can, m->dev[g], m->dev[0]) == hipSuccess && can) {
+    if (m->dev[g] == m->dev[0]) continue;
+    m->peer[g] = 2;
+    if (hipDeviceCanAccessPeer(&can, m->dev[g], m->dev[0]) == hipSuccess && can) {
       (void)hipSetDevice(m->dev[g]);
-      (void)hipDeviceEnablePeerAccess(m->dev[0], 0);  // "already enabled" is fine
+      const hipError_t pe = hipDeviceEnablePeerAccess(m->dev[0], 0);  // "already enabled" is fine
       (void)hipGetLastError();
+      if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) m->peer[g] = 1;
     }
+    if (log && log[0] && log[0] != '0')
+      fprintf(stderr, "isscabac_multi: device %d -> root device %d: hipDeviceCanAccessPeer=%d, gather %s\n", m->dev[g], m->dev[0], can,
+              m->peer[g] == 1 ? "peer to peer" : "staged through the host");
   }
   *out = m;
   return ISSCABAC_OK;
@@ -128,6 +142,7 @@ void isscabac_destroy_multi(isscabac_multi *m) {
   delete m;
 }
 
+int isscabac_multi_peer_access(const isscabac_multi *m, int g) { return m && g >= 0 && g < (int)m->peer.size() ? m->peer[g] : -1; }
 int isscabac_multi_device_count(const isscabac_multi *m) { return m ? (int)m->eng.size() : 0; }
 isscabac_engine *isscabac_multi_engine(isscabac_multi *m, int g) { return m && g >= 0 && g < (int)m->eng.size() ? m->eng[g] : nullptr; }
 const char *isscabac_multi_last_error(const isscabac_multi *m) { return m ? m->err.c_str() : isscabac_last_error(nullptr); }

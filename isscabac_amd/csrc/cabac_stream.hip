@@ -298,7 +298,7 @@ __global__ void k_stream_dec_finish(StreamDev *st, StreamMailbox *mb, const uint
 // for the next kernel -- the host tells the two apart by `done` (cabac_stream.hip: live_call).
 __global__ void k_stream_live(StreamDev *st, StreamMailbox *mb, const uint8_t *payload, uint8_t *out, uint32_t *tr_enc,
                               uint32_t *tr_dec /* the next free trace record of either side, or null */, uint32_t last,
-                              uint64_t idle_ticks) {
+                              uint64_t idle_ticks, uint64_t max_ticks) {
   __shared__ StageLds lds_e, lds_d;  // (one wave: the other lanes only help to stage the states in)
   StagedStates ce = stage_in(lds_e, st->q_enc), cd = stage_in(lds_d, st->q_dec);
   if (threadIdx.x != 0) return;
@@ -306,9 +306,13 @@ __global__ void k_stream_live(StreamDev *st, StreamMailbox *mb, const uint8_t *p
   GlobalSink sink{out, st->enc_bytes};
   RefDec d = st->dec;
   RefReader rd{payload, st->dec_len, st->dec_pos, st->dec_last};
-  uint64_t t0 = wall_clock64();
+  // Two clocks: it leaves after idle_ticks without a request, and after max_ticks of residency whatever the traffic -- a caller
+  // that keeps it busy must not keep it in front of a foreign kernel (another engine's, another HIP user's: the engine's own
+  // work stops it first) that the runtime mapped onto the same hardware queue.  The next call starts the next kernel.
+  const uint64_t t_in = wall_clock64();
+  uint64_t t0 = t_in;
   bool leaving = false;
-  for (uint32_t it = 0; it < (1u << 24); it++) {  // (the count is a backstop for the clock)
+  for (uint32_t it = 0; it < (1u << 24); it++) {  // (the count is a backstop for the clocks)
     const uint64_t r = __hip_atomic_load(&mb->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t seq = (uint32_t)r;
     if (seq != last) {
@@ -342,6 +346,7 @@ __global__ void k_stream_live(StreamDev *st, StreamMailbox *mb, const uint8_t *p
       last = seq;
       if (leaving) break;
       t0 = wall_clock64();
+      if (t0 - t_in > max_ticks) break;  // (the answer is out: the host finds `exited` and starts the next kernel with its next call)
       continue;
     }
     if (leaving) break;  // looked once more after deciding to leave: nothing came
@@ -365,7 +370,8 @@ __global__ void k_stream_live(StreamDev *st, StreamMailbox *mb, const uint8_t *p
 using namespace isscabac;
 
 struct isscabac_stream {
-  isscabac_engine *e = nullptr;
+  isscabac_engine *e = nullptr;  // null once its engine has been destroyed: every call but close then returns ISSCABAC_ERR_STATE
+  int device = 0;
   int nctx = 0;
   StreamDev *st = nullptr;
   uint8_t *d_init = nullptr;
@@ -427,6 +433,7 @@ static int trace_room(isscabac_stream *s, int side, uint64_t have, uint64_t n, u
 static inline uint64_t mb_load64(const uint64_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static inline uint32_t mb_load32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
+constexpr uint64_t kLiveMaxIdles = 10;  // a live kernel's residency bound in idle times: 2 ms
 static int quiesce_others(isscabac_stream *s);
 static int live_launch(isscabac_stream *s) {
   isscabac_engine *e = s->e;
@@ -434,7 +441,7 @@ static int live_launch(isscabac_stream *s) {
   uint32_t *tr_enc = s->tracing && s->d_trace[0] ? reinterpret_cast<uint32_t *>(s->d_trace[0]) + s->bins_total : nullptr;
   uint32_t *tr_dec = s->tracing && s->d_trace[1] ? reinterpret_cast<uint32_t *>(s->d_trace[1]) + s->dec_total : nullptr;
   hipLaunchKernelGGL(k_stream_live, dim3(1), dim3(64), 0, s->live_stream, s->st, s->d_mb, s->d_payload, s->d_out, tr_enc, tr_dec,
-                     (uint32_t)mb_load64(&s->mb->done), s->idle_ticks);
+                     (uint32_t)mb_load64(&s->mb->done), s->idle_ticks, kLiveMaxIdles * s->idle_ticks);
   HIP_TRY(e, hipGetLastError());
   s->live = true;
   return ISSCABAC_OK;
@@ -596,6 +603,15 @@ static const char *op_problem(const isscabac_stream *s, uint16_t op) {
 }
 
 namespace isscabac {
+// isscabac_destroy: stop the live kernels and cut the handles loose -- they stay valid to close, nothing else
+void engine_orphan_handles(isscabac_engine *e) {
+  (void)engine_quiesce_live(e, nullptr);
+  for (isscabac_stream *h : e->handles) {
+    if (h->live_stream) (void)hipStreamSynchronize(h->live_stream);
+    h->e = nullptr;
+  }
+  e->handles.clear();
+}
 int engine_quiesce_live(isscabac_engine *e, isscabac_stream *except) {
   for (isscabac_stream *h : e->handles)
     if (h != except && h->live) {
@@ -619,9 +635,10 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
     if ((ctx_init[c] >> 1) > 62) return engine_fail(e, ISSCABAC_ERR_ARG, "isscabac_stream_open: ctx_init[%d] has state 63", c);
     init[c] = ctx_init[c];
   }
-  HIP_TRY(e, hipSetDevice(e->device));
+  ENGINE_ENTER(e);  // (the reset kernel below goes into the engine's stream: no live kernel of an older handle may stand in front of it)
   isscabac_stream *s = new isscabac_stream;
   s->e = e;
+  s->device = e->device;
   s->nctx = nctx;
   hipError_t err;
   if ((err = hipMalloc(reinterpret_cast<void **>(&s->st), sizeof(StreamDev))) != hipSuccess ||
@@ -653,13 +670,15 @@ int isscabac_stream_open(isscabac_engine *e, const uint8_t *ctx_init, int nctx, 
 
 void isscabac_stream_close(isscabac_stream *s) {
   if (!s) return;
-  (void)hipSetDevice(s->e->device);
-  (void)live_stop(s);
-  {
+  if (s->e) {  // (null: the engine was destroyed first, isscabac_destroy stopped the live kernel and left the handle orphaned)
+    (void)hipSetDevice(s->e->device);
+    (void)live_stop(s);
     auto &hs = s->e->handles;
     hs.erase(std::remove(hs.begin(), hs.end(), s), hs.end());
+    (void)hipStreamSynchronize(s->e->stream);
+  } else {
+    (void)hipSetDevice(s->device);
   }
-  (void)hipStreamSynchronize(s->e->stream);
   if (s->live_stream) (void)hipStreamDestroy(s->live_stream);
   for (void *p : {(void *)s->st, (void *)s->d_init, (void *)s->d_out, (void *)s->d_io, (void *)s->d_payload,
                   (void *)s->d_trace[0], (void *)s->d_trace[1]})
@@ -670,6 +689,7 @@ void isscabac_stream_close(isscabac_stream *s) {
 
 int isscabac_stream_set_trace(isscabac_stream *s, int enabled) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   if (s->encoding || s->decoding)
     return engine_fail(s->e, ISSCABAC_ERR_STATE, "isscabac_stream_set_trace: switch tracing before encodeStart / decodeStart");
   if (const int rc = live_stop(s)) return rc;
@@ -679,6 +699,7 @@ int isscabac_stream_set_trace(isscabac_stream *s, int enabled) {
 
 int isscabac_stream_encode_start(isscabac_stream *s) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (s->encoding) return engine_fail(e, ISSCABAC_ERR_STATE, "encodeStart: the bitstream is already open for writing");  // ref asserts, CABAC_BitstreamFile.cpp:52
   HIP_TRY(e, hipSetDevice(e->device));
@@ -696,6 +717,7 @@ int isscabac_stream_encode_start(isscabac_stream *s) {
 
 int isscabac_stream_encode_ops(isscabac_stream *s, const uint8_t *bins, const uint16_t *ops, uint32_t n) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!s->encoding) return engine_fail(e, ISSCABAC_ERR_STATE, "encodeBin before encodeStart");
   if (n && (!bins || !ops)) return engine_fail(e, ISSCABAC_ERR_ARG, "encodeBin: null buffer");
@@ -714,6 +736,7 @@ int isscabac_stream_encode_ops(isscabac_stream *s, const uint8_t *bins, const ui
 
 int isscabac_stream_encode_bins(isscabac_stream *s, const uint8_t *bins, const uint8_t *ctx, uint32_t n) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   if (n && !ctx) return engine_fail(s->e, ISSCABAC_ERR_ARG, "encodeBin: null buffer");
   if (n <= kInlineOps) {  // (the per-bin callers: no heap traffic)
     uint16_t small[kInlineOps];
@@ -727,6 +750,7 @@ int isscabac_stream_encode_bins(isscabac_stream *s, const uint8_t *bins, const u
 
 int isscabac_stream_num_bits(isscabac_stream *s, uint64_t *bits) {
   if (!s || !bits) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;
   isscabac_engine *e = s->e;
   HIP_TRY(e, hipSetDevice(e->device));
   const int rc = stream_flush_pending(s);
@@ -737,6 +761,7 @@ int isscabac_stream_num_bits(isscabac_stream *s, uint64_t *bits) {
 
 int isscabac_stream_encode_finish(isscabac_stream *s, uint8_t *out, uint64_t cap, uint64_t *nbytes) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!s->encoding && !s->enc_done) return engine_fail(e, ISSCABAC_ERR_STATE, "encodeFinish before encodeStart");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -763,6 +788,7 @@ int isscabac_stream_encode_finish(isscabac_stream *s, uint8_t *out, uint64_t cap
 
 int isscabac_stream_decode_start(isscabac_stream *s, const uint8_t *payload, uint64_t nbytes) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!payload && nbytes) return engine_fail(e, ISSCABAC_ERR_ARG, "decodeStart: null payload");
   if (nbytes > 0xFFFFFFF0ull) return engine_fail(e, ISSCABAC_ERR_ARG, "decodeStart: payload too large");
@@ -783,6 +809,7 @@ int isscabac_stream_decode_start(isscabac_stream *s, const uint8_t *payload, uin
 
 int isscabac_stream_decode_ops(isscabac_stream *s, const uint16_t *ops, uint32_t n, uint8_t *bins_out) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!s->decoding) return engine_fail(e, ISSCABAC_ERR_STATE, "decodeBin before decodeStart");
   if (n == 0) return ISSCABAC_OK;
@@ -829,6 +856,7 @@ int isscabac_stream_decode_ops(isscabac_stream *s, const uint16_t *ops, uint32_t
 
 int isscabac_stream_decode_bins(isscabac_stream *s, const uint8_t *ctx, uint32_t n, uint8_t *bins_out) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   if (n && !ctx) return engine_fail(s->e, ISSCABAC_ERR_ARG, "decodeBin: null buffer");
   if (n <= kInlineOps) {
     uint16_t small[kInlineOps];
@@ -842,6 +870,7 @@ int isscabac_stream_decode_bins(isscabac_stream *s, const uint8_t *ctx, uint32_t
 
 int isscabac_stream_decode_finish(isscabac_stream *s, uint32_t *status) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!s->decoding) return engine_fail(e, ISSCABAC_ERR_STATE, "decodeFinish before decodeStart");
   HIP_TRY(e, hipSetDevice(e->device));
@@ -888,6 +917,7 @@ int isscabac_trace_stats(const uint32_t *records, uint64_t nrecords, int ctx, in
 int isscabac_stream_get_stats(isscabac_stream *s, int decoder, int ctx, uint8_t *trace5, uint64_t cap_steps, uint64_t *nsteps,
                               uint32_t *transitions) {
   if (!s) return ISSCABAC_ERR_ARG;
+  if (!s->e) return ISSCABAC_ERR_STATE;  // its engine is gone (isscabac_destroy): only isscabac_stream_close is left
   isscabac_engine *e = s->e;
   if (!s->tracing) return engine_fail(e, ISSCABAC_ERR_STATE, "getEncoderStats: tracing is off (isscabac_stream_set_trace)");
   if (ctx < 0 || ctx >= s->nctx) return engine_fail(e, ISSCABAC_ERR_ARG, "Error: invalid context index");

@@ -1152,6 +1152,7 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
     sh.nctx = (uint32_t)nctx;
     sh.latency = true;
     sh.tiny = true;
+    sh.pair = e->tuning != ISSCABAC_TUNE_LATENCY_SINGLE;
     sh.d_order = nullptr;
     memcpy(sh.ctx_init, a.ctx_init, 64);
     for (int c = 64; c < 256; c++) sh.ctx_init[c] = 1;

@@ -105,6 +105,8 @@ def _load():
     L.isscabac_last_error.restype = C.c_char_p
     L.isscabac_set_stream.argtypes = [_vp, _vp]
     L.isscabac_set_tuning.argtypes = [_vp, C.c_int]
+    L.isscabac_last_instance.argtypes = [_vp, C.c_int]
+    L.isscabac_last_instance.restype = C.c_char_p
     L.isscabac_init_by_prob.argtypes = [_f64p, C.c_int, _u8p]
     L.isscabac_init_by_state.argtypes = [_f64p, C.c_int, _u8p]
     L.isscabac_stream_bound.argtypes = [C.c_uint32]
@@ -176,6 +178,7 @@ def _load():
     L.isscabac_destroy_multi.argtypes = [_vp]
     L.isscabac_destroy_multi.restype = None
     L.isscabac_multi_device_count.argtypes = [_vp]
+    L.isscabac_multi_peer_access.argtypes = [_vp, C.c_int]
     L.isscabac_multi_engine.argtypes = [_vp, C.c_int]
     L.isscabac_multi_engine.restype = _vp
     L.isscabac_multi_last_error.argtypes = [_vp]
@@ -300,9 +303,13 @@ class Engine:
         self._check(self._L.isscabac_set_stream(self._h, _vp(hip_stream or 0)))
 
     def set_tuning(self, mode):
-        """mode: 'auto' | 'throughput' | 'latency' (or the ISSCABAC_TUNE_* integer): which kernel instance runs."""
-        m = {"auto": 0, "throughput": 1, "latency": 2}.get(mode, mode)
+        """mode: 'auto' | 'throughput' | 'latency' | 'latency_single' (or the ISSCABAC_TUNE_* integer): which kernel instance runs."""
+        m = {"auto": 0, "throughput": 1, "latency": 2, "latency_single": 3}.get(mode, mode)
         self._check(self._L.isscabac_set_tuning(self._h, int(m)))
+
+    def last_instance(self, which):
+        """which: 'encode' | 'decode' -> name of the kernel instance the most recent 8-bit batch call launched."""
+        return self._L.isscabac_last_instance(self._h, {"encode": 0, "decode": 1}[which]).decode()
 
     def set_profiling(self, on):
         self._check(self._L.isscabac_set_profiling(self._h, int(bool(on))))
@@ -761,6 +768,10 @@ class MultiEngine:
 
     def engine_handle(self, g):
         return self._L.isscabac_multi_engine(self._h, int(g))
+
+    def peer_access(self, g):
+        """how device g's shard reaches the root in the gather: 0 same device, 1 peer to peer, 2 staged through the host"""
+        return int(self._L.isscabac_multi_peer_access(self._h, int(g)))
 
     def encode(self, bins, ctx, ctx_init, nbins=None):
         bins, ctx = _np(bins, np.uint8), _np(ctx, np.uint8)

@@ -395,7 +395,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs < 4 || nrhs > 5) mexErrMsgTxt("Error: encodeBatchPacked needs the handle, the bins as bits, ctx and optionally nbins\n");
     const uint8_t *bits = u8_arg(prhs[2], "Error: the packed bins must be a uint8 matrix (one stream per column)\n");
-    const uint8_t *ctx = u8_arg(prhs[3], "Error: ctx must be a uint8 matrix (one stream per column)\n");
+    const uint8_t *ctx = u8_arg(prhs[3], "Error: ctx must be a uint8 matrix (one stream per column; no packed form for 16-bit context indices)\n");
     const size_t B = mxGetM(prhs[3]), S = mxGetN(prhs[3]);
     const uint32_t pitch = (uint32_t)((B + 15) / 16 * 16);
     if (B == 0 || S == 0 || mxGetM(prhs[2]) != pitch / 8 || mxGetN(prhs[2]) != S)
@@ -422,11 +422,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 5 || nrhs > 6) mexErrMsgTxt("Error: decodeBatchPacked needs the handle, payload, offsets, ctx and optionally nbins\n");
     const uint8_t *payload = u8_arg(prhs[2], "Error: payload must be uint8\n");
     if (!mxIsClass(prhs[3], "double")) mexErrMsgTxt("Error: offsets must be double\n");
-    const bool wide = mxIsClass(prhs[4], "uint16");
-    const uint8_t *ctx = wide ? NULL : u8_arg(prhs[4], "Error: ctx must be a uint8 (or, for more than 255 contexts, uint16) matrix (one stream per column)\n");
+    // (no packed form behind 16-bit context indices: a uint16 ctx is refused by u8_arg like any other class, as in encodeBatchPacked)
+    const uint8_t *ctx = u8_arg(prhs[4], "Error: ctx must be a uint8 matrix (one stream per column; no packed form for 16-bit context indices)\n");
     const size_t B = mxGetM(prhs[4]), S = mxGetN(prhs[4]);
     if (mxGetNumberOfElements(prhs[3]) != S + 1 || B == 0 || S == 0) mexErrMsgTxt("Error: offsets must have one entry per stream plus one\n");
-    if (!wide && h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: a uint8 ctx matrix names a context in one byte: at most 255 contexts (pass ctx as uint16)\n");
+    if (h->ctx_init.size() > ISSCABAC_MAX_CTX) mexErrMsgTxt("Error: the batch commands name a context in one byte: at most 255 contexts\n");
     uint64_t *offsets = (uint64_t *)scratch((S + 1) * sizeof(uint64_t));
     for (size_t s = 0; s <= S; s++) offsets[s] = (uint64_t)mxGetPr(prhs[3])[s];
     if (offsets[S] > mxGetNumberOfElements(prhs[2])) mexErrMsgTxt("Error: offsets exceed the payload\n");

@@ -16,10 +16,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng, orc = Engine(0), Oracle()
 t0, rounds, bins_total, flagged = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
-    S = int(rng.choice([1, 3, 63, 64, 65, 200, 777, 2500]))
+    S = int(rng.choice([1, 3, 63, 64, 65, 200, 777, 2500, 40000, 70000]))
     B = int(rng.choice([1, 5, 16, 17, 100, 640, 1000, 4096, 5000]))
+    if S >= 40000:  # AUTO's own choice between 32 Ki and 128 Ki streams (k_encode_pair + k_decode<1,true,false>): short rows, the oracle is one core
+        B = int(rng.choice([1, 16, 17, 40, 100, 130]))
     Cn = int(rng.choice([1, 3, 4, 5, 23, 64, 65, 128, 129, 150, 190, 253, 255]))
-    eng.set_tuning(str(rng.choice(["throughput", "latency"])))  # (auto would always pick the latency instance at these sizes)
+    # (auto would always pick the wave pairs at the small sizes; at 40 000 / 70 000 streams it is what a strong-scaled job's rank runs)
+    eng.set_tuning("auto" if S >= 40000 else str(rng.choice(["throughput", "latency", "latency_single"])))
     ep = float(rng.choice([0.0, 0.0, 0.05, 0.5, 1.0]))
     init = rng.integers(0, 126, Cn).astype(np.uint8)
     ctx = rng.integers(0, Cn, (S, B)).astype(np.uint8)

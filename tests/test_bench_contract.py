@@ -24,7 +24,8 @@ def test_bench_json_line_contract():
         assert isinstance(d[key], typ), (key, d[key])
     # the BASELINE.json metric string is only true for its own shape: a reduced run names the shape it really coded
     assert d["metric"] != json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] and "8192 streams x 4096 bins" in d["metric"]
-    assert d["gather_ok"] is None and d["gather_ms"] is None  # one rank: nothing to gather
+    assert d["gather_ok"] is None and d["gather_ms"] is None and d["gather_GBps"] is None and d["dist"] is None  # one rank: nothing to gather
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["encode_instance"] == "k_encode_pair"
     assert d["unit"] == "Gbin/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -102,6 +103,15 @@ def test_bench_multi_rank_branch_runs_with_one_rank():
     assert d["gather_ok"] is True and d["gather_ms"] > 0 and d["gather_bytes"] == d["config"]["payload_bytes_per_gpu"]
     assert d["n_gpus"] == 1 and d["verified_bit_exact"] is True and d["value"] > 0
     assert d["step_kernel_ms_min"] <= d["step_kernel_ms_median"]
+    # a first N-GPU run explains itself: the group as RCCL reports it, the gather's rate, every rank's time, shard and kernels
+    assert d["dist"] == {"backend": "nccl", "world_size": 1, "launcher_world_size": 1}
+    assert abs(d["gather_GBps"] - d["gather_bytes"] / (d["gather_ms"] * 1e-3) / 1e9) < 1e-6 * d["gather_GBps"]
+    assert len(d["per_rank"]) == 1
+    r0 = d["per_rank"][0]
+    assert r0["rank"] == 0 and r0["streams"] == 8192 and r0["payload_bytes"] == d["config"]["payload_bytes_per_gpu"]
+    assert 0 < r0["ms_per_step"] <= d["ms_per_step"] * 1.0001  # the line's figure is the MAX over ranks
+    assert r0["encode_instance"] == "k_encode_pair" and r0["decode_instance"] == "k_decode_pair"  # 8 192 streams under AUTO
+    assert set(r0["kernels_ms"]) == {"encode", "scan", "gather", "decode"}
 
 
 @pytest.mark.gpu

@@ -341,3 +341,59 @@ def test_a_polling_live_kernel_never_stands_in_front_of_other_work(engine, oracl
     hs[0].close()
     assert per_call < 250e-6, "handles decoding in turn: %.0f us per call" % (per_call * 1e6)
     assert float(np.median(lat)) < 600e-6, "a batch call behind a decodeBin: %.0f us" % (np.median(lat) * 1e6)
+
+
+def test_a_busy_live_kernel_leaves_after_its_residency_bound_and_the_next_call_goes_on(engine, oracle):
+    """A caller that never pauses must not keep its polling kernel resident for ever (a kernel of another engine or HIP user queued
+    behind it would wait): the kernel leaves after 2 ms whatever the traffic and the next call starts the next one.  5 000
+    back-to-back decodeBin calls (>= 10 ms) therefore cross several kernel generations; every bin must still be the oracle's,
+    and a SECOND engine's batch call issued in the middle must come back in far less than the backstop (seconds)."""
+    import time
+    from isscabac_amd import Engine, Stream
+    rng = np.random.default_rng(5)
+    n = 5000
+    ctx = rng.integers(0, 5, n).astype(np.uint8)
+    bins = (rng.random(n) < 0.3).astype(np.uint8)
+    init = rng.integers(0, 126, 5).astype(np.uint8)
+    payload = oracle.encode_stream(bins, ctx, init)
+    other = Engine(0)
+    bb = rng.integers(0, 2, (64, 64)).astype(np.uint8)
+    cc = rng.integers(0, 5, (64, 64)).astype(np.uint8)
+    want = oracle.encode_batch(bb, cc, init)[0]
+    h = Stream(engine, init)
+    h.decode_start(payload)
+    worst = 0.0
+    for i in range(n):
+        assert h.decode_bins(ctx[i:i + 1])[0] == bins[i], i
+        if i % 1000 == 500:
+            t0 = time.perf_counter()
+            got = other.encode(bb, cc, init)[0]
+            worst = max(worst, time.perf_counter() - t0)
+            assert got.tobytes() == want.tobytes()
+    assert h.decode_finish() == 0
+    h.close()
+    other.close()
+    assert worst < 0.05, "a foreign engine's batch call behind a busy live kernel: %.1f ms" % (worst * 1e3)
+
+
+def test_a_handle_that_outlives_its_engine_can_only_be_closed(oracle):
+    """isscabac_destroy with a handle still open (and its live kernel still polling): the destroy stops the kernel and cuts the
+    handle loose; every later call on it answers ISSCABAC_ERR_STATE, close frees it (once a use after free)."""
+    import ctypes as C
+    from isscabac_amd import Engine, Stream
+    eng = Engine(0)
+    init = np.zeros(3, np.uint8)
+    payload = oracle.encode_stream(np.array([1, 0, 1, 1], np.uint8), np.array([0, 1, 2, 0], np.uint8), init)
+    h = Stream(eng, init)
+    h.decode_start(payload)
+    assert h.decode_bins(np.array([0], np.uint8))[0] == 1  # leaves a live kernel polling
+    L, s = eng._L, h._s
+    eng.close()
+    out = (C.c_uint8 * 1)()
+    ctxb = (C.c_uint8 * 1)(1)
+    assert L.isscabac_stream_decode_bins(s, ctxb, 1, out) == 5  # ISSCABAC_ERR_STATE
+    assert L.isscabac_stream_encode_start(s) == 5
+    bits = C.c_uint64(0)
+    assert L.isscabac_stream_num_bits(s, C.byref(bits)) == 5
+    L.isscabac_stream_close(s)
+    h._s = None

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_host_batches_equal_a_single_engine(oracle, ndev):
     from isscabac_amd import MultiEngine
     m = MultiEngine([0] * ndev)
+    assert [m.peer_access(g) for g in range(ndev)] == [0] * ndev and m.peer_access(ndev) == -1  # one device here: no pair to ask about
     rng = np.random.default_rng(ndev)
     for S, B, C in ((1, 64, 3), (7, 200, 5), (257, 1040, 64)):
         bins, ctx = oracle.synth(0xCABAC005, 5, S, B, C, True)

@@ -56,6 +56,14 @@ def test_packed_batch_commands_match_the_byte_commands(gw, oracle, tmp_path):
     assert (np.unpackbits(dbits, axis=0, bitorder="little")[:B] == bins).all()
     with pytest.raises(MexError, match="packed bins must have"):
         gw.call("encodeBatchPacked", h, bits[:-1], ctx, nlhs=2)
+    # 16-bit context indices have no packed form: both commands refuse a uint16 ctx with a message (B not a multiple of 16 here:
+    # the case that once reached a NULL base in the padding copy of decodeBatchPacked), and B = 208 (a multiple of 16) as well
+    for rows in (B, 208):
+        c16 = np.zeros((rows, S), np.uint16)
+        with pytest.raises(MexError, match="no packed form for 16-bit context indices"):
+            gw.call("encodeBatchPacked", h, np.zeros(((rows + 15) // 16 * 2, S), np.uint8), c16, nlhs=2)
+        with pytest.raises(MexError, match="no packed form for 16-bit context indices"):
+            gw.call("decodeBatchPacked", h, p2, o2, c16, nlhs=2)
 
 
 @pytest.mark.gpu
