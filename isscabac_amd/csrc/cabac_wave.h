@@ -264,6 +264,54 @@ struct TilePairT {
   template <bool NT = false>
   __device__ static __forceinline__ void load_rows_ids(uint4 (&)[NLD], const uint8_t *, const uint32_t *, uint32_t, uint32_t, int) {}
 };
+// Whole 128-byte lines per stream and load round, asked for as TWO 64-byte segments back to back: load k (k < 4) fetches bytes
+// 0..63 of rows 16 k .. 16 k + 15 like TileT<4>, load k + 4 bytes 64..127 of the same rows, issued right behind it -- the L2 fills
+// each line once (the second request finds the fill pending) where TileT<4>'s rounds, 64 bins apart, fill it twice.  The parts go
+// to LDS exactly like TileT<4>'s (four half-wave stores per part; TileT<8> needs eight quarter-wave ones).  32 registers per array.
+struct TileLine4 {
+  static constexpr int T = 128, H = 32, NLD = 8, NP = 4;
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return (k & 3) * 16 + lane / 4; }
+  __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % 4; }
+  template <bool NT = false>
+  __device__ static __forceinline__ void load(uint4 (&r)[NLD], const uint8_t *rows, uint32_t nrows, uint32_t pitch, uint32_t off, int lane) {
+    const uint32_t b0 = min(off + ch_of(lane) * 16, pitch - 16u), b1 = min(off + 64u + ch_of(lane) * 16, pitch - 16u);  // (clamped like TileT::load)
+    const uint32_t ro0 = min(row_of(0, lane), nrows - 1u) * pitch, ro1 = min(row_of(1, lane), nrows - 1u) * pitch;
+    const uint32_t ro2 = min(row_of(2, lane), nrows - 1u) * pitch, ro3 = min(row_of(3, lane), nrows - 1u) * pitch;
+    r[0] = NT ? nt_load16(rows + (ro0 + b0)) : ld16(rows + (ro0 + b0));
+    r[4] = NT ? nt_load16(rows + (ro0 + b1)) : ld16(rows + (ro0 + b1));
+    r[1] = NT ? nt_load16(rows + (ro1 + b0)) : ld16(rows + (ro1 + b0));
+    r[5] = NT ? nt_load16(rows + (ro1 + b1)) : ld16(rows + (ro1 + b1));
+    r[2] = NT ? nt_load16(rows + (ro2 + b0)) : ld16(rows + (ro2 + b0));
+    r[6] = NT ? nt_load16(rows + (ro2 + b1)) : ld16(rows + (ro2 + b1));
+    r[3] = NT ? nt_load16(rows + (ro3 + b0)) : ld16(rows + (ro3 + b0));
+    r[7] = NT ? nt_load16(rows + (ro3 + b1)) : ld16(rows + (ro3 + b1));
+  }
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
+    const uint32_t c = ch_of(lane);
+    uint8_t *p0 = tile + lds_off(row_of(0, lane), c & 1), *p1 = tile + lds_off(row_of(1, lane), c & 1);
+    uint8_t *p2 = tile + lds_off(row_of(2, lane), c & 1), *p3 = tile + lds_off(row_of(3, lane), c & 1);
+    if ((int)(c >> 1) == (h & 1)) {
+      if (h < 2) {
+        *reinterpret_cast<uint4 *>(p0) = r[0];
+        *reinterpret_cast<uint4 *>(p1) = r[1];
+        *reinterpret_cast<uint4 *>(p2) = r[2];
+        *reinterpret_cast<uint4 *>(p3) = r[3];
+      } else {
+        *reinterpret_cast<uint4 *>(p0) = r[4];
+        *reinterpret_cast<uint4 *>(p1) = r[5];
+        *reinterpret_cast<uint4 *>(p2) = r[6];
+        *reinterpret_cast<uint4 *>(p3) = r[7];
+      }
+    }
+  }
+  __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
+    return *reinterpret_cast<const uint4 *>(tile + lds_off(lane, j));
+  }
+  // (the length-bucketed instances keep TileT<4> -- these only let `if (PERM)` compile)
+  template <bool NT = false>
+  __device__ static __forceinline__ void load_rows(uint4 (&)[NLD], const uint8_t *, const uint32_t (&)[NLD], uint32_t, uint32_t, int) {}
+};
 typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
 // the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
 // both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
@@ -287,12 +335,18 @@ constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads
 #ifndef ISSCABAC_ENC_TILE_PAIR
 #define ISSCABAC_ENC_TILE_PAIR 0
 #endif
+#ifndef ISSCABAC_ENC_LINE_B
+#define ISSCABAC_ENC_LINE_B 0  // the bins array by whole lines (TileLine4)
+#endif
+#ifndef ISSCABAC_ENC_LINE_C
+#define ISSCABAC_ENC_LINE_C 0  // the ctx array by whole lines
+#endif
 template <bool PERM>
-using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
-                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_B, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
 template <bool PERM>
-using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
-                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type;
+using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_C, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
+                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type>::type;
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
