@@ -396,6 +396,42 @@ int isscabac_stream_get_stats(isscabac_stream *s, int decoder, int ctx, uint8_t 
 int isscabac_trace_stats(const uint32_t *records, uint64_t nrecords, int ctx, int decoder, uint8_t *trace5,
                          uint64_t cap_steps, uint64_t *nsteps, uint32_t *transitions);
 
+/* ---- host twins of the SERIAL entry points (`cabac_cpu_*`) ------------------------------------------------------
+ * The reference's own use of this engine is serial: one bin per MEX call (ref: CABAC/cabacWrapper.m:39-66), or a whole matrix
+ * as ONE stream (ref: ISS/+coder/cabacEncode.m:45-70).  Neither has parallelism to give a GPU: a device handle answers a
+ * decodeBin in 2.3 us and codes a 400 x 20 matrix in 1.3 ms, one host core needs ~15 ns per bin.  These twins are the engine's
+ * own per-lane code (isscabac_amd/csrc/cabac_lane.h, cabac_symbols.h -- the functions the HIP kernels call) compiled for the
+ * host: same arguments, same bytes, same getNumBits cadence, same status words, same trace records as their device
+ * counterparts, and no engine argument -- they need no GPU.  They are explicitly named entry points, never a fallback: no
+ * isscabac_* batch call routes here, and the batch calls still fail with ISSCABAC_ERR_HIP without a device.
+ *   isscabac_cpu_stream_*          = isscabac_stream_*            (ref: CABAC/SimpleCABACMex.cpp:186-354, 356-466)
+ *   isscabac_cpu_encode_symbols    = isscabac_encode_symbols_stats (stats may be NULL), streams coded one after the other
+ *   isscabac_cpu_decode_symbols    = isscabac_decode_symbols
+ * matlab/SimpleCABACMex.cpp serves the per-bin commands from these by default (ISSCABAC_MEX_PERBIN=gpu: the device handle). */
+typedef struct isscabac_cpu_stream isscabac_cpu_stream;
+int isscabac_cpu_stream_open(const uint8_t *ctx_init, int nctx, isscabac_cpu_stream **out);
+void isscabac_cpu_stream_close(isscabac_cpu_stream *s);
+const char *isscabac_cpu_stream_last_error(const isscabac_cpu_stream *s);
+int isscabac_cpu_stream_encode_start(isscabac_cpu_stream *s);
+int isscabac_cpu_stream_encode_bins(isscabac_cpu_stream *s, const uint8_t *bins, const uint8_t *ctx, uint32_t n);
+int isscabac_cpu_stream_encode_ops(isscabac_cpu_stream *s, const uint8_t *bins, const uint16_t *ops, uint32_t n);
+int isscabac_cpu_stream_num_bits(isscabac_cpu_stream *s, uint64_t *bits);
+int isscabac_cpu_stream_encode_finish(isscabac_cpu_stream *s, uint8_t *out, uint64_t cap, uint64_t *nbytes);
+int isscabac_cpu_stream_decode_start(isscabac_cpu_stream *s, const uint8_t *payload, uint64_t nbytes);
+int isscabac_cpu_stream_decode_bins(isscabac_cpu_stream *s, const uint8_t *ctx, uint32_t n, uint8_t *bins_out);
+int isscabac_cpu_stream_decode_ops(isscabac_cpu_stream *s, const uint16_t *ops, uint32_t n, uint8_t *bins_out);
+int isscabac_cpu_stream_decode_finish(isscabac_cpu_stream *s, uint32_t *status);
+int isscabac_cpu_stream_set_trace(isscabac_cpu_stream *s, int enabled);
+int isscabac_cpu_stream_get_stats(isscabac_cpu_stream *s, int decoder, int ctx, uint8_t *trace5, uint64_t cap_steps,
+                                  uint64_t *nsteps, uint32_t *transitions);
+int isscabac_cpu_encode_symbols(const uint8_t *sym, const uint32_t *nsym_per_stream, uint64_t S, uint32_t nsym, uint32_t pitch,
+                                const isscabac_symbol_params *params, const uint8_t *ctx_init, int nctx, uint8_t *payload,
+                                uint64_t payload_cap, uint64_t *offsets, uint64_t *total_bytes, uint32_t *nbins_out,
+                                const isscabac_symbol_stats *stats);
+int isscabac_cpu_decode_symbols(const uint8_t *payload, const uint64_t *offsets, const uint32_t *nsym_per_stream, uint64_t S,
+                                uint32_t nsym, uint32_t pitch, const isscabac_symbol_params *params, const uint8_t *ctx_init,
+                                int nctx, uint8_t *sym_out, uint32_t *status);
+
 /* ---- several GPUs behind one handle, one process (what a MEX / FFI caller can use) -------------------
  * isscabac_multi owns one engine per listed device.  A batch is split like the multi-process path splits it
  * (isscabac_amd/sharding.py): streams are independent, device g of n codes the contiguous block

@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # ISSCABAC_LIB selects another build of the same ABI (A/B experiments: tools/ab_bench.py)
 LIB = os.environ.get("ISSCABAC_LIB") or os.path.join(HERE, "lib", "libisscabac_hip.so")
-SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_wide.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip", "cabac_capi.cpp", "cabac_container.cpp"]
+SOURCES = ["cabac_kernels.hip", "cabac_pair.hip", "cabac_wide.hip", "cabac_stream.hip", "cabac_symbols.hip", "cabac_multi.hip", "cabac_order.hip", "cabac_capi.cpp", "cabac_container.cpp", "cabac_host.cpp"]
+HOST_ONLY = ["cabac_host.cpp"]  # the host twins of the serial entry points (isscabac_cpu_*)
 HEADERS = ["cabac_lane.h", "cabac_wave.h", "cabac_symbols.h", "cabac_internal.h", os.path.join("..", "..", "include", "isscabac.h")]
 
 
@@ -37,6 +38,9 @@ def _compile_objects(objdir, flags, verbose=False):
         src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
         objs.append(obj)
         if os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(src)):
+            continue
+        if f in HOST_ONLY:  # plain C++: the per-lane headers compile without the HIP runtime (no device pass, no hip_runtime.h)
+            jobs.append([hipcc(), "-O2", "-std=c++17", "-fPIC", "-Wall"] + flags + ["-c", "-x", "c++", src, "-o", obj])
             continue
         lang = ["-x", "hip"] if f.endswith(".hip") else []
         jobs.append([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + flags + ["-c"] + lang + [src, "-o", obj])
@@ -70,9 +74,12 @@ def build_variant(tag, defines):
     """Same sources with extra -D flags -> tools/ab/variant_<tag>.so (A/B experiments, see tools/ab_bench.py)."""
     out = os.path.join(HERE, "..", "tools", "ab", "variant_%s.so" % tag)  # A/B builds live beside the tools, not beside the product library
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", out] + \
-          ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES]
-    subprocess.check_call(cmd)
+    objdir = os.path.join(os.path.dirname(out), "obj_%s" % tag)
+    if os.path.isdir(objdir):
+        shutil.rmtree(objdir)
+    objs = _compile_objects(objdir, ["-D" + d for d in defines])
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    shutil.rmtree(objdir)
     return out
 
 

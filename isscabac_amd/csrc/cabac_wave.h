@@ -287,22 +287,19 @@ struct TileLine4 {
     r[3] = NT ? nt_load16(rows + (ro3 + b0)) : ld16(rows + (ro3 + b0));
     r[7] = NT ? nt_load16(rows + (ro3 + b1)) : ld16(rows + (ro3 + b1));
   }
-  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
-    const uint32_t c = ch_of(lane);
-    uint8_t *p0 = tile + lds_off(row_of(0, lane), c & 1), *p1 = tile + lds_off(row_of(1, lane), c & 1);
-    uint8_t *p2 = tile + lds_off(row_of(2, lane), c & 1), *p3 = tile + lds_off(row_of(3, lane), c & 1);
-    if ((int)(c >> 1) == (h & 1)) {
-      if (h < 2) {
-        *reinterpret_cast<uint4 *>(p0) = r[0];
-        *reinterpret_cast<uint4 *>(p1) = r[1];
-        *reinterpret_cast<uint4 *>(p2) = r[2];
-        *reinterpret_cast<uint4 *>(p3) = r[3];
-      } else {
-        *reinterpret_cast<uint4 *>(p0) = r[4];
-        *reinterpret_cast<uint4 *>(p1) = r[5];
-        *reinterpret_cast<uint4 *>(p2) = r[6];
-        *reinterpret_cast<uint4 *>(p3) = r[7];
-      }
+  // h may be a run-time value (the kernels keep the loop over the parts rolled): the parts always leave registers 0..3, and the
+  // line's second half moves down into them before part 2 (16 moves per 128 bytes of every row; a register index computed from h
+  // would put the array into scratch)
+  __device__ static __forceinline__ void half_to_lds(uint8_t *tile, uint4 (&r)[NLD], int h, int lane) {
+    if (h == 2) {
+      r[0] = r[4];
+      r[1] = r[5];
+      r[2] = r[6];
+      r[3] = r[7];
+    }
+    if ((int)(ch_of(lane) >> 1) == (h & 1)) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane) & 1)) = r[k];
     }
   }
   __device__ static __forceinline__ uint4 row_chunk(const uint8_t *tile, int lane, int j) {
@@ -335,11 +332,14 @@ constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads
 #ifndef ISSCABAC_ENC_TILE_PAIR
 #define ISSCABAC_ENC_TILE_PAIR 0
 #endif
+// Round 6, same box, medians of 5 (profiles/r06/ab_line.txt): both arrays by whole lines k_encode 2.885 -> 2.790 ms and FETCH_SIZE
+// 8.56 -> 4.30 GB per launch (L2 <-> fabric traffic 17.9 -> 9.5 GB = 1.05 x the algorithmic bytes); either array alone 2.876 / 2.857;
+// with streaming (nt) loads on top 2.862.  125 VGPRs, no spill (TileT<8> for both: 128 + 2 spilled, 8 quarter-wave LDS stores per part).
 #ifndef ISSCABAC_ENC_LINE_B
-#define ISSCABAC_ENC_LINE_B 0  // the bins array by whole lines (TileLine4)
+#define ISSCABAC_ENC_LINE_B 1  // the bins array by whole lines (TileLine4); 0: TileT<ISSCABAC_ENC_LPR_B>
 #endif
 #ifndef ISSCABAC_ENC_LINE_C
-#define ISSCABAC_ENC_LINE_C 0  // the ctx array by whole lines
+#define ISSCABAC_ENC_LINE_C 1  // the ctx array by whole lines
 #endif
 template <bool PERM>
 using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_B, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,

@@ -173,6 +173,27 @@ def _load():
     _u16p = C.POINTER(C.c_uint16)
     L.isscabac_stream_encode_ops.argtypes = [_vp, _u8p, _u16p, C.c_uint32]
     L.isscabac_stream_decode_ops.argtypes = [_vp, _u16p, C.c_uint32, _u8p]
+    # host twins of the serial entry points (no engine, no GPU)
+    L.isscabac_cpu_stream_open.argtypes = [_u8p, C.c_int, C.POINTER(_vp)]
+    L.isscabac_cpu_stream_close.argtypes = [_vp]
+    L.isscabac_cpu_stream_close.restype = None
+    L.isscabac_cpu_stream_last_error.argtypes = [_vp]
+    L.isscabac_cpu_stream_last_error.restype = C.c_char_p
+    L.isscabac_cpu_stream_encode_start.argtypes = [_vp]
+    L.isscabac_cpu_stream_encode_bins.argtypes = [_vp, _u8p, _u8p, C.c_uint32]
+    L.isscabac_cpu_stream_encode_ops.argtypes = [_vp, _u8p, _u16p, C.c_uint32]
+    L.isscabac_cpu_stream_num_bits.argtypes = [_vp, _u64p]
+    L.isscabac_cpu_stream_encode_finish.argtypes = [_vp, _u8p, C.c_uint64, _u64p]
+    L.isscabac_cpu_stream_decode_start.argtypes = [_vp, _u8p, C.c_uint64]
+    L.isscabac_cpu_stream_decode_bins.argtypes = [_vp, _u8p, C.c_uint32, _u8p]
+    L.isscabac_cpu_stream_decode_ops.argtypes = [_vp, _u16p, C.c_uint32, _u8p]
+    L.isscabac_cpu_stream_decode_finish.argtypes = [_vp, _u32p]
+    L.isscabac_cpu_stream_set_trace.argtypes = [_vp, C.c_int]
+    L.isscabac_cpu_stream_get_stats.argtypes = [_vp, C.c_int, C.c_int, _u8p, C.c_uint64, _u64p, _u32p]
+    L.isscabac_cpu_encode_symbols.argtypes = [_u8p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams), _u8p, C.c_int,
+                                              _u8p, C.c_uint64, _u64p, _u64p, _u32p, C.POINTER(SymbolStats)]
+    L.isscabac_cpu_decode_symbols.argtypes = [_u8p, _u64p, _u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(SymbolParams), _u8p,
+                                              C.c_int, _u8p, _u32p]
     # several devices behind one handle
     L.isscabac_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]
     L.isscabac_destroy_multi.argtypes = [_vp]
@@ -985,3 +1006,152 @@ class Stream:
         st = C.c_uint32(0)
         self._eng._check(self._L.isscabac_stream_decode_finish(self._s, C.byref(st)))
         return int(st.value)
+
+
+class CpuStream:
+    """Host twin of Stream (isscabac_cpu_stream_*): the reference's per-bin commands served by the engine's own per-lane
+    code compiled for the host -- no engine, no GPU.  Same methods, same bytes, same getNumBits cadence, same status words."""
+
+    def __init__(self, ctx_init):
+        self._L = _load()
+        ci = _np(ctx_init, np.uint8)
+        h = _vp()
+        rc = self._L.isscabac_cpu_stream_open(_ptr(ci, _u8p), ci.size, C.byref(h))
+        if rc:
+            raise EngineError(rc, "isscabac_cpu_stream_open: bad context initialisation")
+        self._s = h
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.isscabac_cpu_stream_close(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(rc, self._L.isscabac_cpu_stream_last_error(self._s).decode())
+
+    def encode_start(self):
+        self._check(self._L.isscabac_cpu_stream_encode_start(self._s))
+
+    def encode_bins(self, bins, ctx):
+        b, c = _np(bins, np.uint8).ravel(), _np(ctx, np.uint8).ravel()
+        assert b.size == c.size
+        self._check(self._L.isscabac_cpu_stream_encode_bins(self._s, _ptr(b, _u8p), _ptr(c, _u8p), b.size))
+
+    def encode_ops(self, bins, ops):
+        b, o = _np(bins, np.uint8).ravel(), _np(ops, np.uint16).ravel()
+        assert b.size == o.size
+        self._check(self._L.isscabac_cpu_stream_encode_ops(self._s, _ptr(b, _u8p), _ptr(o, C.POINTER(C.c_uint16)), b.size))
+
+    def num_bits(self):
+        v = C.c_uint64(0)
+        self._check(self._L.isscabac_cpu_stream_num_bits(self._s, C.byref(v)))
+        return int(v.value)
+
+    def encode_finish(self):
+        n = C.c_uint64(0)
+        buf = np.empty(1 << 12, np.uint8)
+        rc = self._L.isscabac_cpu_stream_encode_finish(self._s, _ptr(buf, _u8p), buf.size, C.byref(n))
+        if rc == 4:
+            buf = np.empty(int(n.value), np.uint8)
+            rc = self._L.isscabac_cpu_stream_encode_finish(self._s, _ptr(buf, _u8p), buf.size, C.byref(n))
+        self._check(rc)
+        return buf[:int(n.value)].copy()
+
+    def decode_start(self, payload):
+        p = _np(payload, np.uint8).ravel()
+        self._check(self._L.isscabac_cpu_stream_decode_start(self._s, _ptr(p, _u8p), p.size))
+
+    def decode_bins(self, ctx):
+        c = _np(ctx, np.uint8).ravel()
+        out = np.zeros(c.size, np.uint8)
+        self._check(self._L.isscabac_cpu_stream_decode_bins(self._s, _ptr(c, _u8p), c.size, _ptr(out, _u8p)))
+        return out
+
+    def decode_ops(self, ops):
+        o = _np(ops, np.uint16).ravel()
+        out = np.zeros(o.size, np.uint8)
+        self._check(self._L.isscabac_cpu_stream_decode_ops(self._s, _ptr(o, C.POINTER(C.c_uint16)), o.size, _ptr(out, _u8p)))
+        return out
+
+    def decode_finish(self):
+        st = C.c_uint32(0)
+        self._check(self._L.isscabac_cpu_stream_decode_finish(self._s, C.byref(st)))
+        return int(st.value)
+
+    def set_trace(self, on=True):
+        self._check(self._L.isscabac_cpu_stream_set_trace(self._s, int(bool(on))))
+
+    def get_stats(self, ctx, decoder=False):
+        n = C.c_uint64(0)
+        trans = np.zeros((128, 128), np.uint32)
+        self._check(self._L.isscabac_cpu_stream_get_stats(self._s, int(bool(decoder)), int(ctx), None, 0, C.byref(n), _ptr(trans, _u32p)))
+        trace = np.zeros((max(1, int(n.value)), 5), np.uint8)
+        self._check(self._L.isscabac_cpu_stream_get_stats(self._s, int(bool(decoder)), int(ctx), _ptr(trace, _u8p), trace.shape[0],
+                                                          C.byref(n), None))
+        return trace[:int(n.value)].copy(), trans
+
+
+def cpu_encode_symbols(sym, params, ctx_init, nsym=None, stats=False, trace=False):
+    """Host twin of Engine.encode_symbols / encode_symbols_stats (isscabac_cpu_encode_symbols): a few streams of symbols, e.g.
+    a whole matrix as ONE stream (params.col_rows), coded one after the other on the calling core.  Returns (payload, offsets,
+    bins_per_stream) and, with stats=True, ctx_hist, ctx_cost, sym_bits (and the per-bin trace records with trace=True)."""
+    L = _load()
+    sym = _np(sym, np.uint8)
+    S, R = sym.shape
+    pitch = max(16, (R + 15) // 16 * 16)
+    symp = Engine._pad_rows(sym, pitch)
+    ci = _np(ctx_init, np.uint8)
+    ns = None if nsym is None else _np(nsym, np.uint32)
+    mb = int(L.isscabac_symbol_max_bins(C.byref(params)))
+    if mb == 0:
+        raise EngineError(1, "unsupported symbol parameters")
+    cap = S * stream_bound(R * mb)
+    payload = np.empty(cap, np.uint8)
+    offsets = np.zeros(S + 1, np.uint64)
+    nbins = np.zeros(S, np.uint32)
+    total = C.c_uint64(0)
+    st = None
+    if stats or trace:
+        hist = np.zeros((S, STAT_CTX), np.uint32)
+        cost = np.zeros((S, STAT_CTX), np.uint32)
+        hb = np.zeros((S, pitch), np.uint16)
+        rec = np.zeros((S, R * mb), np.uint32) if trace else None
+        st = SymbolStats(hist.ctypes.data_as(C.POINTER(C.c_uint32)), cost.ctypes.data_as(C.POINTER(C.c_uint32)),
+                         hb.ctypes.data_as(C.POINTER(C.c_uint16)), rec.ctypes.data_as(C.POINTER(C.c_uint32)) if trace else None,
+                         R * mb if trace else 0)
+    rc = L.isscabac_cpu_encode_symbols(_ptr(symp, _u8p), _ptr(ns, _u32p), S, R, pitch, C.byref(params), _ptr(ci, _u8p), ci.size,
+                                       _ptr(payload, _u8p), cap, _ptr(offsets, _u64p), C.byref(total), _ptr(nbins, _u32p),
+                                       C.byref(st) if st is not None else None)
+    if rc:
+        raise EngineError(rc, "isscabac_cpu_encode_symbols")
+    out = (payload[:int(total.value)].copy(), offsets, nbins)
+    if st is not None:
+        out += (hist, cost, hb[:, :R].copy())
+        if trace:
+            out += (rec,)
+    return out
+
+
+def cpu_decode_symbols(payload, offsets, R, params, ctx_init, nsym=None):
+    """Host twin of Engine.decode_symbols.  Returns (sym uint8[S, R], status uint32[S])."""
+    L = _load()
+    payload = _np(payload, np.uint8)
+    offsets = _np(offsets, np.uint64)
+    S = offsets.size - 1
+    pitch = max(16, (R + 15) // 16 * 16)
+    ci = _np(ctx_init, np.uint8)
+    ns = None if nsym is None else _np(nsym, np.uint32)
+    out = np.zeros((S, pitch), np.uint8)
+    status = np.zeros(S, np.uint32)
+    rc = L.isscabac_cpu_decode_symbols(_ptr(payload, _u8p), _ptr(offsets, _u64p), _ptr(ns, _u32p), S, R, pitch, C.byref(params),
+                                       _ptr(ci, _u8p), ci.size, _ptr(out, _u8p), _ptr(status, _u32p))
+    if rc:
+        raise EngineError(rc, "isscabac_cpu_decode_symbols")
+    return out[:, :R].copy(), status

@@ -1,5 +1,7 @@
 """Python mirror of the reference's MATLAB handle class (ref: CABAC/cabacWrapper.m:15-77): same constructor,
-same method names and argument meaning, same error behaviour, on top of the HIP engine.  It is what
+same method names and argument meaning, same error behaviour.  The per-bin commands are served by the engine's host twin
+(isscabac_cpu_stream_*: the kernels' own per-lane code compiled for the host -- one bin per call has no parallelism to give a
+GPU) or, with per_bin="gpu" / an engine handed in, by the device-resident handle; the batch methods run on the GPU.  It is what
 matlab/cabacWrapper.m does through the MEX shim, written in Python so that the test-suite can drive the reference's
 own usage patterns (cabacDemo.m, +coder/cabacEncode.m) on the GPU box, where no MATLAB exists.
 
@@ -20,8 +22,8 @@ def _get_engine():
 
 
 class cabacWrapper:
-    def __init__(self, cm, fn, initByProb=1, engine=None):
-        # ref: cabacWrapper.m:15-30
+    def __init__(self, cm, fn, initByProb=1, engine=None, per_bin=None):
+        # ref: cabacWrapper.m:15-30.  per_bin: "host" (default) or "gpu" (default when an engine is handed in)
         if not isinstance(fn, str):
             raise ValueError("bitStreamName should be string")
         self.bitStreamName = fn
@@ -29,7 +31,10 @@ class cabacWrapper:
         if self.contextModelInitOptions.ndim > 2:
             raise ValueError("context model initialization options should be like this: "
                              "[ctxID mps probIndex, ctxID mps probIndex, ...]")
-        self._engine = engine or _get_engine()
+        self._per_bin = per_bin or ("gpu" if engine is not None else "host")
+        if self._per_bin not in ("host", "gpu"):
+            raise ValueError("per_bin must be 'host' or 'gpu'")
+        self._engine_arg = engine
         self.cabac_handle = None
         self.init(initByProb)
 
@@ -37,8 +42,15 @@ class cabacWrapper:
         # ref: cabacWrapper.m:31-39 -> SimpleCABACMex('initByProb' | 'initByState', fn, ctxInit), :120-185
         flat = self.contextModelInitOptions.ravel(order="F")  # the MEX reads the MATLAB array column-major
         self.ctx_init = _engine.init_by_prob(flat) if initByProb else _engine.init_by_state(flat)
-        self.cabac_handle = _engine.Stream(self._engine, self.ctx_init)
+        if self._per_bin == "gpu":
+            self.cabac_handle = _engine.Stream(self._engine, self.ctx_init)
+        else:
+            self.cabac_handle = _engine.CpuStream(self.ctx_init)
         self.cabac_handle.set_trace(True)  # what the reference's Windows build always records (getEncoderStats)
+
+    @property
+    def _engine(self):  # the GPU engine, created when first needed (never for per-bin work on the host twin)
+        return self._engine_arg or _get_engine()
 
     # ---- per-bin commands ----------------------------------------------------------------------------
     def encodeStart(self):

@@ -52,15 +52,31 @@ namespace {
 isscabac_engine *g_engine = NULL;
 isscabac_multi *g_multi = NULL;  // set by 'setDevices': the batch commands then run on several GPUs
 
+// The per-bin commands are served by the host twin of the handle (isscabac_cpu_stream_*: the engine's own per-lane code compiled
+// for the host -- one bin per call has no parallelism to give a GPU: ~20 ns against 2.3 us per decodeBin), or, with
+// ISSCABAC_MEX_PERBIN=gpu in the environment at init time, by the device-resident handle (isscabac_stream_*).  Same results
+// either way; the batch / symbol commands always run on the GPU.
 struct Handle {
-  isscabac_stream *stream;
+  isscabac_stream *stream;   // device handle, or NULL
+  isscabac_cpu_stream *cpu;  // host twin, or NULL
   std::string fn;
   std::vector<uint8_t> ctx_init;
 };
+// A few whole-matrix streams (col_rows > 0: the reference's one-file-per-matrix format) are serial work as well: up to this many
+// of them per call are coded by the host twin (a 400 x 20 matrix: 0.2 ms on one core against 1.3 / 2.5 ms on one GPU lane);
+// more streams, or columns as streams, go to the GPU
+const size_t kSerialMatrixStreams = 4;
+bool perbin_on_gpu();
+bool serial_on_host(const isscabac_symbol_params &sp, size_t S) { return sp.col_rows > 0 && S <= kSerialMatrixStreams && !perbin_on_gpu() && !g_multi; }
+bool perbin_on_gpu() {
+  const char *v = getenv("ISSCABAC_MEX_PERBIN");
+  return v && (v[0] == 'g' || v[0] == 'G');
+}
 std::set<Handle *> g_handles;  // every live handle: 'delete' and at_exit() only touch what is really there
 
 void close_handle(Handle *h) {
-  isscabac_stream_close(h->stream);
+  if (h->stream) isscabac_stream_close(h->stream);
+  if (h->cpu) isscabac_cpu_stream_close(h->cpu);
   g_handles.erase(h);
   delete h;
   if (g_handles.empty() && mexIsLocked()) mexUnlock();
@@ -91,6 +107,30 @@ void check(int rc, const char *what) {
   if (rc == ISSCABAC_OK) return;
   mexPrintf("Error: %s: %s\n", what, isscabac_last_error(g_engine));
   mexErrMsgTxt("Error: CABAC engine call failed\n");
+}
+void check_h(const Handle *h, int rc, const char *what) {  // a per-bin command's status: the text comes from whoever served it
+  if (rc == ISSCABAC_OK) return;
+  mexPrintf("Error: %s: %s\n", what, h->cpu ? isscabac_cpu_stream_last_error(h->cpu) : isscabac_last_error(g_engine));
+  mexErrMsgTxt("Error: CABAC engine call failed\n");
+}
+// the per-bin calls, on whichever form of the handle exists
+int h_encode_start(Handle *h) { return h->cpu ? isscabac_cpu_stream_encode_start(h->cpu) : isscabac_stream_encode_start(h->stream); }
+int h_encode_ops(Handle *h, const uint8_t *b, const uint16_t *op, uint32_t n) {
+  return h->cpu ? isscabac_cpu_stream_encode_ops(h->cpu, b, op, n) : isscabac_stream_encode_ops(h->stream, b, op, n);
+}
+int h_num_bits(Handle *h, uint64_t *bits) { return h->cpu ? isscabac_cpu_stream_num_bits(h->cpu, bits) : isscabac_stream_num_bits(h->stream, bits); }
+int h_encode_finish(Handle *h, uint8_t *out, uint64_t cap, uint64_t *n) {
+  return h->cpu ? isscabac_cpu_stream_encode_finish(h->cpu, out, cap, n) : isscabac_stream_encode_finish(h->stream, out, cap, n);
+}
+int h_decode_start(Handle *h, const uint8_t *p, uint64_t n) {
+  return h->cpu ? isscabac_cpu_stream_decode_start(h->cpu, p, n) : isscabac_stream_decode_start(h->stream, p, n);
+}
+int h_decode_ops(Handle *h, const uint16_t *op, uint32_t n, uint8_t *out) {
+  return h->cpu ? isscabac_cpu_stream_decode_ops(h->cpu, op, n, out) : isscabac_stream_decode_ops(h->stream, op, n, out);
+}
+int h_decode_finish(Handle *h, uint32_t *st) { return h->cpu ? isscabac_cpu_stream_decode_finish(h->cpu, st) : isscabac_stream_decode_finish(h->stream, st); }
+int h_get_stats(Handle *h, int decoder, int ctx, uint8_t *t5, uint64_t cap, uint64_t *n, uint32_t *tr) {
+  return h->cpu ? isscabac_cpu_stream_get_stats(h->cpu, decoder, ctx, t5, cap, n, tr) : isscabac_stream_get_stats(h->stream, decoder, ctx, t5, cap, n, tr);
 }
 void check_multi(int rc, const char *what) {
   if (rc == ISSCABAC_OK) return;
@@ -200,11 +240,11 @@ void stats_command(int decoder, int nlhs, mxArray *plhs[], int nrhs, const mxArr
   if (nrhs < 3) mexErrMsgTxt("Error: invalid context index\n");
   const int ctx = (int)ctx_op(h, prhs[2]);
   uint64_t n = 0;
-  check(isscabac_stream_get_stats(h->stream, decoder, ctx, NULL, 0, &n, NULL), decoder ? "getDecoderStats" : "getEncoderStats");
+  check_h(h, h_get_stats(h, decoder, ctx, NULL, 0, &n, NULL), decoder ? "getDecoderStats" : "getEncoderStats");
   plhs[0] = mxCreateNumericMatrix(5, (size_t)n, mxUINT8_CLASS, mxREAL);
   plhs[1] = mxCreateNumericMatrix(128, 128, mxUINT32_CLASS, mxREAL);
-  check(isscabac_stream_get_stats(h->stream, decoder, ctx, (uint8_t *)mxGetData(plhs[0]), n, &n, (uint32_t *)mxGetData(plhs[1])),
-        decoder ? "getDecoderStats" : "getEncoderStats");
+  check_h(h, h_get_stats(h, decoder, ctx, (uint8_t *)mxGetData(plhs[0]), n, &n, (uint32_t *)mxGetData(plhs[1])),
+          decoder ? "getDecoderStats" : "getEncoderStats");
 }
 
 }  // namespace
@@ -228,10 +268,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const int rc = c == "initByState" ? isscabac_init_by_state(mxGetPr(prhs[2]), nctx, init) : isscabac_init_by_prob(mxGetPr(prhs[2]), nctx, init);
     if (rc != ISSCABAC_OK) mexErrMsgTxt("Error: invalid context initialization\n");
     isscabac_stream *stream = NULL;
-    check(isscabac_stream_open(engine(), init, nctx, &stream), "init");  // (nothing of ours is allocated yet if this raises)
-    check(isscabac_stream_set_trace(stream, 1), "init");  // what the reference's Windows build always records
+    isscabac_cpu_stream *cpu = NULL;
+    if (perbin_on_gpu()) {
+      check(isscabac_stream_open(engine(), init, nctx, &stream), "init");  // (nothing of ours is allocated yet if this raises)
+      check(isscabac_stream_set_trace(stream, 1), "init");  // what the reference's Windows build always records
+    } else {  // the host twin: no engine, no GPU touched until a batch command asks for one
+      if (isscabac_cpu_stream_open(init, nctx, &cpu) != ISSCABAC_OK || isscabac_cpu_stream_set_trace(cpu, 1) != ISSCABAC_OK)
+        mexErrMsgTxt("Error: invalid context initialization\n");
+      mexAtExit(at_exit);
+    }
     Handle *h = new Handle;
     h->stream = stream;
+    h->cpu = cpu;
     char *fn = mxArrayToString(prhs[1]);
     h->fn = fn ? fn : "";
     if (fn) mxFree(fn);
@@ -248,37 +296,37 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       mexErrMsgTxt("Error: bitstreamfile access error\n");
     }
     fclose(f);
-    check(isscabac_stream_encode_start(h->stream), "encodeStart");
+    check_h(h, h_encode_start(h), "encodeStart");
   } else if (c == "encodeBin") {
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs != 4) mexErrMsgTxt("Error: invalid input, provide the bin and context index to be encoded with\n");
     const uint8_t b = bin_arg(prhs[2]);
     const uint16_t op = ctx_op(h, prhs[3]);
-    check(isscabac_stream_encode_ops(h->stream, &b, &op, 1), "encodeBin");
+    check_h(h, h_encode_ops(h, &b, &op, 1), "encodeBin");
   } else if (c == "encodeBinEP" || c == "encodeBinProb") {
     Handle *h = get_handle(nrhs, prhs);
     const bool ep = c == "encodeBinEP";
     if (nrhs != (ep ? 3 : 4)) mexErrMsgTxt(ep ? "Error: invalid input, provide the bin to be encoded\n" : "Error: invalid input, provide the bin and its probability of being 1 in percent\n");
     const uint8_t b = bin_arg(prhs[2]);
     const uint16_t op = ep ? ISSCABAC_OP_BYPASS : prob_op(prhs[3]);
-    check(isscabac_stream_encode_ops(h->stream, &b, &op, 1), cmd);
+    check_h(h, h_encode_ops(h, &b, &op, 1), cmd);
   } else if (c == "getNumBits") {
     Handle *h = get_handle(nrhs, prhs);
     if (nrhs != 2) mexErrMsgTxt("Error: invalid input\n");
     uint64_t bits = 0;
-    check(isscabac_stream_num_bits(h->stream, &bits), "getNumBits");
+    check_h(h, h_num_bits(h, &bits), "getNumBits");
     plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL);
     *mxGetPr(plhs[0]) = (double)bits;
   } else if (c == "encodeFinish") {
     Handle *h = get_handle(nrhs, prhs);
     uint64_t n = 0;
     uint8_t *buf = scratch(1 << 16);
-    int rc = isscabac_stream_encode_finish(h->stream, buf, 1 << 16, &n);
+    int rc = h_encode_finish(h, buf, 1 << 16, &n);
     if (rc == ISSCABAC_ERR_CAPACITY) {
       buf = scratch((size_t)n);
-      rc = isscabac_stream_encode_finish(h->stream, buf, n, &n);
+      rc = h_encode_finish(h, buf, n, &n);
     }
-    check(rc, "encodeFinish");
+    check_h(h, rc, "encodeFinish");
     FILE *f = fopen(h->fn.c_str(), "wb");
     const bool ok = f && fwrite(buf, 1, (size_t)n, f) == n;
     if (f) fclose(f);
@@ -297,7 +345,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const bool ok = len >= 0 && fread(buf, 1, (size_t)len, f) == (size_t)len;
     fclose(f);
     if (!ok) mexErrMsgTxt("Error: bitstreamfile access error\n");
-    check(isscabac_stream_decode_start(h->stream, buf, (uint64_t)len), "decodeStart");
+    check_h(h, h_decode_start(h, buf, (uint64_t)len), "decodeStart");
   } else if (c == "decodeBin" || c == "decodeBinEP" || c == "decodeBinProb") {
     if (nrhs < 2) mexErrMsgTxt("Error: You need to provide the pointer to the initialized CABAC engine \n");
     if (nlhs != 1) mexErrMsgTxt("Error: invalid command, provide a variable to store the decoded bin \n");
@@ -308,13 +356,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       op = c == "decodeBin" ? ctx_op(h, prhs[2]) : prob_op(prhs[2]);
     }
     uint8_t bin = 0;
-    check(isscabac_stream_decode_ops(h->stream, &op, 1, &bin), cmd);
+    check_h(h, h_decode_ops(h, &op, 1, &bin), cmd);
     plhs[0] = mxCreateDoubleMatrix(1, 1, mxREAL);
     *mxGetPr(plhs[0]) = bin;
   } else if (c == "decodeFinish") {
     Handle *h = get_handle(nrhs, prhs);
     uint32_t status = 0;
-    check(isscabac_stream_decode_finish(h->stream, &status), "decodeFinish");
+    check_h(h, h_decode_finish(h, &status), "decodeFinish");
     // the reference asserts here (CABAC_ArithmeticDecoder.cpp:78-81) and a release MEX build compiles the asserts out:
     // report, do not raise
     if (status != 0) mexWarnMsgTxt("bitstream not terminated properly");
@@ -470,8 +518,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       st.ctx_cost = (uint32_t *)scratch(S * ISSCABAC_STAT_CTX * sizeof(uint32_t));
       st.sym_bits = (uint16_t *)scratch(S * (size_t)pitch * sizeof(uint16_t));
     }
-    engine();
-    if (g_multi)  // the streams (columns, or whole matrices) split over the devices of 'setDevices'
+    if (serial_on_host(sp, S)) {
+      if (isscabac_cpu_encode_symbols(sym, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), payload, cap, offsets,
+                                      &total, nbins, stats ? &st : NULL) != ISSCABAC_OK)
+        mexErrMsgTxt("Error: unsupported symbol parameters\n");
+    } else if (engine(), g_multi)  // the streams (columns, or whole matrices) split over the devices of 'setDevices'
       check_multi(isscabac_multi_encode_symbols_stats(g_multi, sym, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(),
                                                       payload, cap, offsets, &total, nbins, stats ? &st : NULL), cmd);
     else
@@ -509,8 +560,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     const uint32_t pitch = (uint32_t)((R + 15) / 16 * 16);
     uint8_t *sym = scratch((size_t)pitch * S);
     uint32_t *status = (uint32_t *)scratch(S * sizeof(uint32_t));
-    engine();
-    if (g_multi)
+    if (serial_on_host(sp, S)) {
+      if (isscabac_cpu_decode_symbols(payload, offsets, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(), (int)h->ctx_init.size(), sym, status) != ISSCABAC_OK)
+        mexErrMsgTxt("Error: unsupported symbol parameters\n");
+    } else if (engine(), g_multi)
       check_multi(isscabac_multi_decode_symbols(g_multi, payload, offsets, ns, S, (uint32_t)R, pitch, &sp, h->ctx_init.data(),
                                                 (int)h->ctx_init.size(), sym, status), "decodeSymbols");
     else

@@ -23,10 +23,53 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
     }                                                                                               \
   } while (0)
 
+// the same three loops on the host twin of the handle (isscabac_cpu_stream_*: no engine, no GPU)
+static int host_twin(const std::vector<uint8_t> &bins, const std::vector<uint8_t> &ctx, uint32_t n) {
+  isscabac_engine *e = nullptr;  // (CHECK prints its error text)
+  const uint8_t init[3] = {0, 0, 0};
+  isscabac_cpu_stream *s = nullptr, *d = nullptr;
+  CHECK(isscabac_cpu_stream_open(init, 3, &s));
+  CHECK(isscabac_cpu_stream_encode_start(s));
+  const double t0 = now();
+  for (uint32_t i = 0; i < n; i++) CHECK(isscabac_cpu_stream_encode_bins(s, &bins[i], &ctx[i], 1));
+  const double t1 = now();
+  std::vector<uint8_t> payload(n / 4 + 64);
+  uint64_t nbytes = 0, bits = 0, sum = 0;
+  CHECK(isscabac_cpu_stream_encode_finish(s, payload.data(), payload.size(), &nbytes));
+  CHECK(isscabac_cpu_stream_encode_start(s));
+  const double t2 = now();
+  for (uint32_t i = 0; i < n; i++) {
+    CHECK(isscabac_cpu_stream_encode_bins(s, &bins[i], &ctx[i], 1));
+    CHECK(isscabac_cpu_stream_num_bits(s, &bits));
+    sum += bits;
+  }
+  const double t3 = now();
+  CHECK(isscabac_cpu_stream_open(init, 3, &d));
+  CHECK(isscabac_cpu_stream_decode_start(d, payload.data(), nbytes));
+  uint32_t wrong = 0;
+  const double t4 = now();
+  for (uint32_t i = 0; i < n; i++) {
+    uint8_t b = 2;
+    CHECK(isscabac_cpu_stream_decode_bins(d, &ctx[i], 1, &b));
+    wrong += b != bins[i];
+  }
+  const double t5 = now();
+  uint32_t status = 99;
+  CHECK(isscabac_cpu_stream_decode_finish(d, &status));
+  printf("the same on the host twin (isscabac_cpu_stream_*, one host core, %u bins): encodeBin %.1f Mbin/s (%.3f us per call), encodeBin + "
+         "getNumBits %.1f Mbin/s (%.3f us per pair), decodeBin %.1f Mbin/s (%.3f us per call); %llu bytes, %u wrong bins, status %u (checksum %llu)\n",
+         n, n / (t1 - t0) / 1e6, (t1 - t0) / n * 1e6, n / (t3 - t2) / 1e6, (t3 - t2) / n * 1e6, n / (t5 - t4) / 1e6, (t5 - t4) / n * 1e6,
+         (unsigned long long)nbytes, wrong, status, (unsigned long long)sum);
+  isscabac_cpu_stream_close(s);
+  isscabac_cpu_stream_close(d);
+  return wrong != 0 || status != 0;
+}
+
 int main(int argc, char **argv) {
   const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 200000u;
+  const bool host_only = argc > 2 && argv[2][0] == 'h';  // `per_bin_native 200000 host`: no GPU needed
   isscabac_engine *e = nullptr;
-  CHECK(isscabac_create(0, &e));
+  if (!host_only) CHECK(isscabac_create(0, &e));
   // BASELINE config 1's shape: one stream, three contexts with different skews (a seeded generator of this file)
   std::vector<uint8_t> bins(n), ctx(n);
   uint32_t x = 12345;
@@ -36,6 +79,7 @@ int main(int argc, char **argv) {
     const uint32_t thr = ctx[i] == 0 ? 13107u : ctx[i] == 1 ? 32768u : 52429u;  // P(1) = 0.2 / 0.5 / 0.8
     bins[i] = (uint8_t)(((x >> 4) & 0xFFFFu) < thr);
   }
+  if (host_only) return host_twin(bins, ctx, n);
   const uint8_t init[3] = {0, 0, 0};
   isscabac_stream *s = nullptr, *d = nullptr;
   CHECK(isscabac_stream_open(e, init, 3, &s));
@@ -88,5 +132,5 @@ int main(int argc, char **argv) {
   isscabac_stream_close(s);
   isscabac_stream_close(d);
   isscabac_destroy(e);
-  return wrong != 0 || status != 0;
+  return (wrong != 0 || status != 0) | host_twin(bins, ctx, n);
 }

@@ -323,7 +323,7 @@ def test_single_stream_handle_per_bin_commands(engine, oracle, golden, tmp_path)
     # cabacDemo.m-style use of the wrapper class: 3 contexts chosen from previously coded bins, file hand-off
     fn = str(tmp_path / "test.bin")
     sym = np.minimum(np.abs(rng.normal(size=400) * 1.3).astype(np.uint32), 3)
-    enc = cabacWrapper(0.5 * np.ones(3), fn)
+    enc = cabacWrapper(0.5 * np.ones(3), fn, engine=engine)  # (an engine handed in: the device-resident handle)
     enc.encodeStart()
     prev_first = None
     for v in sym:
@@ -335,7 +335,7 @@ def test_single_stream_handle_per_bin_commands(engine, oracle, golden, tmp_path)
     enc.encodeFinish()
     want, _ = oracle.demo_encode(sym, 4, oracle.init_by_prob([0.5] * 3))
     assert open(fn, "rb").read() == want.tobytes()
-    dec = cabacWrapper(0.5 * np.ones(3), fn)
+    dec = cabacWrapper(0.5 * np.ones(3), fn, engine=engine)
     dec.decodeStart()
     got, prev_first = [], None
     for _ in sym:
@@ -672,6 +672,12 @@ def test_coder_front_end_mirrors_cabacEncode_cabacDecode(engine, oracle, tmp_pat
         assert (hist == wh).all() and (cost == wc).all() and (H == wH).all()
         back = coder.cabacDecode(Nq, param, ctx0, G.shape, engine=engine)
         assert (back == G).all()
+        # the host twin (the default of both functions when no engine is handed in) writes the same file and statistics
+        hp = dict(param, fn=str(tmp_path / "h.bin"))
+        hbits, hctx0, hhist, hcost, hH = coder.cabacEncode(G, Nq, hp, engine=engine, stats=True, serial="host")
+        assert open(hp["fn"], "rb").read() == wp.tobytes() and hbits == nbits and (hctx0 == ctx0).all()
+        assert (hhist == wh).all() and (hcost == wc).all() and (hH == wH).all()
+        assert (coder.cabacDecode(Nq, hp, ctx0, G.shape, serial="host") == G).all()
     bad = bytearray(open(param["fn"], "rb").read())
     bad[-1] ^= 0x80
     with pytest.raises(ValueError):

@@ -11,6 +11,14 @@ def gw():
     return Gateway()
 
 
+@pytest.fixture(params=["host", pytest.param("gpu", marks=pytest.mark.gpu)])
+def perbin(request, monkeypatch):
+    """who serves the per-bin commands: the host twin of the handle (the gateway's default; these tests then need no GPU and run
+    in the CPU suite) or the device-resident handle (ISSCABAC_MEX_PERBIN=gpu, read by the gateway at init time)"""
+    monkeypatch.setenv("ISSCABAC_MEX_PERBIN", request.param)
+    return request.param
+
+
 def test_compiles_and_rejects_like_the_reference(gw):
     with pytest.raises(MexError, match="input 0 must be a valid keyword"):
         gw.call()
@@ -66,8 +74,7 @@ def test_packed_batch_commands_match_the_byte_commands(gw, oracle, tmp_path):
             gw.call("decodeBatchPacked", h, p2, o2, c16, nlhs=2)
 
 
-@pytest.mark.gpu
-def test_per_bin_commands_round_trip_and_numbits(gw, oracle, golden, tmp_path):
+def test_per_bin_commands_round_trip_and_numbits(gw, perbin, oracle, golden, tmp_path):
     s = {x["name"]: x for x in golden["streams"]}["lcg200_3ctx"]
     fn = str(tmp_path / "mex.bin")
     (h,) = gw.call("initByProb", fn, np.array([0.5, 0.5, 0.5]), nlhs=1)
@@ -127,8 +134,7 @@ def test_batch_commands(gw, oracle, tmp_path):
         gw.call("encodeBatch", h, bins.T.copy(), ctx.T[:10].copy(), nlhs=2)
 
 
-@pytest.mark.gpu
-def test_context_index_is_range_checked_before_narrowing(gw, tmp_path):
+def test_context_index_is_range_checked_before_narrowing(gw, perbin, tmp_path):
     """256 must not become context 0, and -1 / 255 / 511 must not become a bypass bin (round-1 finding)"""
     (h,) = gw.call("initByProb", str(tmp_path / "r.bin"), np.array([0.5, 0.5, 0.5]), nlhs=1)
     gw.call("encodeStart", h)
@@ -149,8 +155,7 @@ def test_context_index_is_range_checked_before_narrowing(gw, tmp_path):
         gw.call("encodeStart", h)  # a deleted handle is refused, not dereferenced
 
 
-@pytest.mark.gpu
-def test_handles_hold_the_mex_file_and_are_closed_at_exit(gw, tmp_path):
+def test_handles_hold_the_mex_file_and_are_closed_at_exit(gw, perbin, tmp_path):
     gw.shutdown()  # whatever earlier tests left open
     assert gw.locks() == 0
     hs = [gw.call("initByProb", str(tmp_path / ("l%d.bin" % i)), np.array([0.5]), nlhs=1)[0] for i in range(3)]
@@ -209,8 +214,7 @@ def test_more_than_255_contexts_per_bin_commands_only(gw, oracle, tmp_path):
     gw.call("delete", h)
 
 
-@pytest.mark.gpu
-def test_stats_ep_and_probability_commands(gw, oracle, tmp_path):
+def test_stats_ep_and_probability_commands(gw, perbin, oracle, tmp_path):
     rng = np.random.default_rng(5)
     fn = str(tmp_path / "s.bin")
     p0 = np.array([0.2, 0.5, 0.8])
@@ -278,9 +282,13 @@ def _iss_params(nq, rows, method=1, k=0, types=15, nlbp=3):
 
 
 @pytest.mark.gpu
-def test_symbol_commands_run_the_iss_coder_in_one_call_per_matrix(gw, oracle, tmp_path):
+@pytest.mark.parametrize("serial", ["host", "gpu"])
+def test_symbol_commands_run_the_iss_coder_in_one_call_per_matrix(gw, oracle, tmp_path, monkeypatch, serial):
     """the gateway calls matlab/+coder/cabacEncode.m / cabacDecode.m make, against the oracle's walk of the reference's
-    loops (ISS/+coder/cabacEncode.m:45-70, cabacDecode.m:29-55) on ISS.m's two matrix shapes"""
+    loops (ISS/+coder/cabacEncode.m:45-70, cabacDecode.m:29-55) on ISS.m's two matrix shapes.  The one stream per matrix is
+    coded by the host twin (the gateway's default for up to four whole-matrix streams) or on the device (ISSCABAC_MEX_PERBIN=gpu);
+    the context initialisation -- a histogram -- runs on the GPU either way."""
+    monkeypatch.setenv("ISSCABAC_MEX_PERBIN", serial)
     rng = np.random.default_rng(6)
     for rows, cols, nq in ((400, 20, 8), (109, 20, 8), (33, 7, 16)):
         x = np.abs(rng.normal(size=(rows, cols)))

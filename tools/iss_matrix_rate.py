@@ -36,6 +36,16 @@ for rows, cols in ((400, 20), (109, 20)):
     td, G2 = best(lambda: coder.cabacDecode(8, param, ci0, (rows, cols), engine=eng, payload=payload))
     assert (G2 == G).all() and 8 * payload.size == nbits
     tc, _ = best(lambda: eng.encode_symbols(one, mp, states))  # the coding call alone (cabacEncode adds the context initialisation call)
+    param_eq = dict(param, equalProb=True)  # (no histogram call: the coding alone, on the host twin -- the Python mirrors' default)
+    th, (hbits, hci) = best(lambda: coder.cabacEncode(G, 8, param_eq))
+    from isscabac_amd import cpu_decode_symbols, cpu_encode_symbols
+    thc, hout = best(lambda: cpu_encode_symbols(one, mp, states))
+    assert hout[0].tobytes() == payload.tobytes()
+    off = np.array([0, payload.size], np.uint64)
+    thd, hsym = best(lambda: cpu_decode_symbols(payload, off, rows * cols, mp, states))
+    assert (hsym[0].reshape(cols, rows).T == G).all()
+    host = ("; HOST TWIN (isscabac_cpu_encode_symbols / _decode_symbols, one core, same bytes): encode %.3f ms (%.0f ns per bin), decode %.3f ms "
+            "(%.0f ns per bin); coder.cabacEncode on it, equalProb %.3f ms" % (thc * 1e3, thc / int(nb[0]) * 1e9, thd * 1e3, thd / int(nb[0]) * 1e9, th * 1e3))
     line = ("%3d x %2d matrix as ONE stream: %d bins, %d bytes; cabacEncode %.2f ms (its coding call %.2f ms = %.0f ns per bin), cabacDecode %.2f ms "
             "(%.0f ns per bin)" % (rows, cols, int(nb[0]), payload.size, te * 1e3, tc * 1e3, tc / int(nb[0]) * 1e9, td * 1e3, td / int(nb[0]) * 1e9))
     try:
@@ -49,4 +59,4 @@ for rows, cols in ((400, 20), (109, 20)):
         line += "; one host core, C restatement of the whole walk: encode %.2f ms" % ((t1 - t0) / 20 * 1e3)
     except Exception as exc:  # noqa: BLE001
         line += "; (CPU leg skipped: %r)" % (exc,)
-    print(line)
+    print(line + host)
