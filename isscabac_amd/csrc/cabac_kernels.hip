@@ -471,7 +471,14 @@ struct DecLds {
   static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
   static constexpr uint32_t TILE = 32 * 64;  // the ctx half tile (TileT::H bytes per stream)
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
-  static constexpr uint32_t BYTES = SB + TILE + OutBuf::BYTES + IDS;
+  // <= 64 contexts: the mixed step's dummy row (cabac_lane.h: dec_bin_mixed2_nx_abs) is group 31 of the wave's region -- where a
+  // bypass byte's state address lands under the step's 5-bit group mask --, i.e. the 256 bytes chunk 7 of the output staging
+  // would take: that chunk moves up behind it (OutBufT<true>)
+  static constexpr bool MIXED2 = CM == 1;
+  typedef OutBufT<MIXED2> OBuf;
+  static constexpr uint32_t DUMMY_OFF = 31 * 256;
+  static_assert(!MIXED2 || SB + TILE + 7 * 256 == DUMMY_OFF, "the dummy row is the staging buffer's chunk-7 row");
+  static constexpr uint32_t BYTES = SB + TILE + OBuf::BYTES + IDS;
 };
 
 template <int CM, bool LAT, bool PERM>
@@ -496,8 +503,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       tab[8 * qb + 2 * r + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
     }
 #else
-    tab[2 * qb] = c_lps_rows[ps >> 1];
-    tab[2 * qb + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
+    // raw bytes 254 / 255 (state 63, no context's state): the bypass entry of the mixed step on a dummy context
+    tab[2 * qb] = qb >= (int)kDecBypassRaw ? 0u : c_lps_rows[ps >> 1];
+    tab[2 * qb + 1] = qb >= (int)kDecBypassRaw ? kDecBypassHi : dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
 #endif
   }
 #endif
@@ -512,8 +520,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   const uint32_t ctx_lim = min(sbytes >> 6, 255u), ctx_kadd = (256u - ctx_lim) * 0x01010101u;
   uint8_t *wbase = smem + kDecTabBytes + wib * (DL::BYTES - DL::SB + sbytes);
   uint8_t *tile_c = wbase + sbytes;
+  using OBuf = typename DL::OBuf;
   uint32_t *obuf = reinterpret_cast<uint32_t *>(tile_c + DL::TILE);
-  const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_c + DL::TILE + OutBuf::BYTES);  // PERM: the wave's stream ids
+  const uint32_t *wids = reinterpret_cast<const uint32_t *>(tile_c + DL::TILE + OBuf::BYTES);  // PERM: the wave's stream ids
 
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
@@ -536,6 +545,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     // and overruns the slot bound of 6
     const uint32_t ngrp = sbytes / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
+    if (DL::MIXED2) st32[DL::DUMMY_OFF / 4] = kDecBypassRaw * 0x01010101u;  // the bypass bins' dummy context: stays a bypass byte (0xFE | bin)
   }
   LdsStates stx{wbase + lane * 4};
   if (ISSCABAC_DEC_TAB_REPL) stx.rep = ((uint32_t)lane & 3u) << 3;
@@ -577,11 +587,11 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       // (formed here, behind an opaque lane id, so that they are not kept in registers across the bin loop)
       const uint32_t ln = opaque((uint32_t)lane);
       const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
-      const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
+      const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OBuf::idx(ln & 7, ln >> 3);
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         // idx(c, 8 k + i) = idx(c, i) ^ 8 k
-        const uint4 v = OutBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
+        const uint4 v = OBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
         const u32x4 w = {v.x, v.y, v.z, v.w};
         uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
 #if ISSCABAC_DEC_NOSTORE  // timing experiment only
@@ -598,7 +608,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
       const uint32_t row = k * 8 + (lane >> 3), c = lane & 7;
-      const uint4 v = OutBuf::unpack(obuf[OutBuf::idx(c, row)]);
+      const uint4 v = OBuf::unpack(obuf[OBuf::idx(c, row)]);
       const uint32_t boff = off + c * 16;
       if (row < nrows && boff < a.pitch) {
         // 32-bit offset from the wave's first row (see Tile::load), or the row of stream wids[row]
@@ -619,8 +629,8 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   [[maybe_unused]] auto store_one = [&](uint32_t off, int k) {
     const uint32_t ln = opaque((uint32_t)lane);
     const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
-    const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OutBuf::idx(ln & 7, ln >> 3);
-    const uint4 v = OutBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
+    const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OBuf::idx(ln & 7, ln >> 3);
+    const uint4 v = OBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
     const u32x4 w = {v.x, v.y, v.z, v.w};
     uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
@@ -804,10 +814,32 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
           asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
           clk_body += __builtin_amdgcn_s_memtime() - cb0;
 #endif
-        } else if (CM != 2 && full &&
+        } else if (DL::MIXED2 && full &&
+                   !wave_any((not_ctx64_nor_bypass(wc.x) | not_ctx64_nor_bypass(wc.y) | not_ctx64_nor_bypass(wc.z) | not_ctx64_nor_bypass(wc.w)) != 0)) {
+          // contexts below 64 and bypass bins only (config 5's chunks): the step on a dummy context (dec_bin_mixed2_nx_abs) -- under
+          // the 5-bit group mask a bypass byte's state address is the dummy row, whose byte finds the table's bypass entry
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            if (g == 2) src.ensure(47);
+            const uint32_t cw = word_of(wc, g);
+            dec_topup_abs(da, src);
+            const CtxQuad zs = stx.prep4(cw & 0x7F7F7F7Fu);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const uint32_t ak = stx.addr32_of(zs, k);
+              const uint32_t nx = k == 0 ? dec_bin_mixed2_nx_abs<true>(da, ak, stx.load_at(ak), stx) : dec_bin_mixed2_nx_abs<false>(da, ak, stx.load_at(ak), stx);
+              if (k == 0) put_out_byte<0>(oa, ob, nx);
+              else if (k == 1) put_out_byte<1>(oa, ob, nx);
+              else if (k == 2) put_out_byte<2>(oa, ob, nx);
+              else put_out_byte<3>(oa, ob, nx);
+            }
+            od |= (out_word(oa, ob) & 0x01010101u) << g;
+          }
+        } else if (CM == 3 && full &&
                    !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
-          // context-coded and bypass bins only: one select-based step for every lane (dec_bin_mixed_nx), see k_encode
-          constexpr uint32_t kIn = CM == 1 ? 0x3F3F3F3Fu : 0x7F7F7F7Fu;
+          // (<= 128 contexts: a bypass byte's masked address is context 127, a real one) context-coded and bypass bins only: one
+          // select-based step for every lane (dec_bin_mixed_nx), see k_encode
+          constexpr uint32_t kIn = 0x7F7F7F7Fu;
 #pragma unroll
           for (int g = 0; g < 4; g++) {
             if (g == 2) src.ensure(47);
@@ -865,7 +897,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         }
         }
         if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
-        obuf[OutBuf::idx(cidx, lane)] = od;
+        obuf[OBuf::idx(cidx, lane)] = od;
 #if ISSCABAC_EXP_SPREAD_ST
         if (t > 0) store_one((t - 1) * DTile::T, (int)cidx);
 #endif
@@ -877,7 +909,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
       out_off = (t * DTile::T) & ~127u;
       if (((t + 1) * DTile::T) % 128 != 0) {
         // the stream ends inside the block: its upper half was never written
-        for (uint32_t c = 4; c < 8; c++) obuf[OutBuf::idx(c, lane)] = 0;
+        for (uint32_t c = 4; c < 8; c++) obuf[OBuf::idx(c, lane)] = 0;
         wave_lds_sync();
       }
     }

@@ -1262,6 +1262,51 @@ CABAC_HD uint32_t dec_bin_mixed_nx_abs(DecAbs &a, uint32_t mb, Addr at, uint32_t
   return nx;
 }
 
+// The mixed step on a dummy context (the decoder's twin of enc_bin_mixed2_acc; batches of <= 64 contexts): a bypass bin's state
+// address is a byte of its own -- a dummy row of the wave's LDS -- that holds the raw state byte 254 / 255 (state 63: no
+// context's state, refused at initialisation and unreachable by any transition), and the table's entries for those two bytes are
+// the BYPASS entry: an all-zero rangeTabLps row (LPS term 0), successors 0xFE | bin decoded -- the dummy stays a bypass byte and
+// bit 0 of what is stored is the output, like everywhere --, and all ones in the upper half, whose sign IS the lane mask "this is
+// a bypass bin".  So the step has no select on the entry and none on the state store (dec_bin_mixed_nx_abs: three selects and a
+// two-instruction mask per bin); what remains is the bypass lane's "LPS term" R / 2, which no table can hold (R = range << sh
+// with an odd range): one shift and one and-or on the mask.  ref: CABAC_ArithmeticDecoder.cpp:288-331 (bypass), :87-190.
+constexpr uint32_t kDecBypassRaw = 0xFEu;
+constexpr uint32_t kDecBypassHi = 0xFFFF0000u | 0xFEu << 8 | 0xFFu;  // byte 0: value >= R / 2 -> bin 1; byte 1: below -> bin 0
+// bytes of a ctx word that are neither a context below 64 nor the bypass marker, as bit 7 of their byte (the chunk then takes the
+// general path: with the 5-bit group mask of the mixed2 step such a byte would address the wave's tiles)
+CABAC_HD uint32_t not_ctx64_nor_bypass(uint32_t cw) {
+  const uint32_t low7 = cw & 0x7F7F7F7Fu, u = low7 + 0x01010101u, s = low7 + 0x40404040u;
+  return ((cw & ~u) | (~cw & s)) & 0x80808080u;  // bit 7 set: not 0xFF; bit 7 clear: >= 64
+}
+template <bool FIRST, class States, class Addr>
+CABAC_HD uint32_t dec_bin_mixed2_nx_abs(DecAbs &a, Addr at, uint32_t qb, States &st) {
+  const uint64_t ent = st.entry_raw(qb);
+  const uint32_t hi = (uint32_t)(ent >> 32);
+  const uint32_t mb = (uint32_t)((int32_t)hi >> 31);  // ~0 on a bypass lane
+  const uint32_t rl = ((a.R >> 1) & mb) | abs_lps<FIRST>((uint32_t)ent, a.R);  // (a bypass entry's row is 0: its LPS term is 0)
+  const uint32_t cmpv = a.R - rl;
+  uint32_t nx;
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t diff, r;
+  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
+      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %0, %0, %3, vcc"
+      : "=&v"(diff), "=&v"(nx), "=&v"(r)
+      : "v"(a.v), "v"(cmpv), "v"(hi), "v"(rl)
+      : "vcc");
+  a.v = diff;
+  a.R = r;
+#else
+  const bool below = a.v < cmpv;
+  nx = (hi >> (below ? 8 : 0)) & 0xFFu;
+  a.R = below ? cmpv : rl;
+  a.v = below ? a.v : a.v - cmpv;
+#endif
+  st.store_at(at, nx);
+  return nx;
+}
+
 // The decoder's select-based step for chunks that mix context-coded and bypass bins (see enc_bin_mixed_acc): a bypass
 // bin compares the value with the whole range one bit further down (ref: CABAC_ArithmeticDecoder.cpp:288-331) and leaves
 // range and state alone.  Returns the (mps, path) pair of dec_bin_at_mem; a bypass bin reports mps 0, which makes

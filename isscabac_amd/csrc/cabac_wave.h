@@ -354,9 +354,12 @@ using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_C, TileLin
 // load + store: tools/ubench/tile_bw.hip, store_seg.hip -- the kernel was store-bound with them).  Dword (c, row) of the
 // eight chunks c sits at c * 64 + (row ^ 8 c): a lane writes its own row (all banks distinct), and the store pass
 // reads (8 rows) x (8 chunks) per instruction, again all banks distinct.
-struct OutBuf {
-  static constexpr uint32_t BYTES = 8 * 64 * 4;
-  __device__ static __forceinline__ uint32_t idx(uint32_t c, uint32_t row) { return c * 64 + (row ^ (c * 8)); }
+// GAP (k_decode with <= 64 contexts): chunk 7 sits 256 bytes further up -- the 256 bytes it would occupy are the dummy row of the
+// mixed step (cabac_lane.h: dec_bin_mixed2_nx_abs), which the 5-bit group mask of a bypass byte's state address lands on
+template <bool GAP>
+struct OutBufT {
+  static constexpr uint32_t BYTES = 8 * 64 * 4 + (GAP ? 256 : 0);
+  __device__ static __forceinline__ uint32_t idx(uint32_t c, uint32_t row) { return c * 64 + (row ^ (c * 8)) + ((GAP && c == 7) ? 64u : 0u); }
   __device__ static __forceinline__ uint32_t pack(const uint4 &v) {
     const uint32_t M = 0x01010101u;
     uint32_t d = v.x & M;
@@ -370,6 +373,7 @@ struct OutBuf {
     return make_uint4(d & M, (d >> 1) & M, (d >> 2) & M, (d >> 3) & M);
   }
 };
+typedef OutBufT<false> OutBuf;
 
 __device__ __forceinline__ uint32_t word_of(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 __device__ __forceinline__ void set_word(uint4 &v, int i, uint32_t w) {

@@ -28,10 +28,11 @@ struct NextTab {
 const NextTab kNext;
 
 struct HostStates {
-  uint8_t cm[256];  // doubled states q, like the kernels keep them in LDS
+  uint8_t cm[257];  // doubled states q, like the kernels keep them in LDS; [256]: the decoder's dummy context of the mixed step
   void init(const uint8_t *packed, int nctx) {
-    std::memset(cm, q_from_packed(1), sizeof cm);  // ContextModel() default: (mps 1, state 0)
+    std::memset(cm, q_from_packed(1), 256);  // ContextModel() default: (mps 1, state 0)
     for (int c = 0; c < nctx; c++) cm[c] = (uint8_t)q_from_packed(packed[c]);
+    cm[256] = (uint8_t)kDecBypassRaw;
   }
   void final_packed(uint8_t *out, int nctx) const {
     for (int c = 0; c < nctx; c++) out[c] = (uint8_t)packed_from_q(cm[c]);
@@ -56,6 +57,7 @@ struct HostStates {
   }
   // the decoder's entry by RAW state byte (LdsStates::entry_raw): bit 0 of the byte is a stale bin
   uint64_t entry_raw(uint32_t qb) const {
+    if (qb >= kDecBypassRaw) return (uint64_t)kDecBypassHi << 32;  // k_decode's table: raw bytes 254 / 255 hold the bypass entry
     const uint32_t q = qb & ~1u;
     return (uint64_t)kLpsRow[q >> 2] | (uint64_t)dec_entry_hi_out(q >> 1, next_path_mem(q), next_path_mem(q + 1u)) << 32;
   }
@@ -485,9 +487,16 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
     for (uint32_t k = 0; k < 16; k++) cb[k] = i0 + k < n ? ctx[i0 + k] : 0;  // (the kernel reads whatever the row holds)
     const bool full = i0 + 16 <= n;
     bool hi = false, odd = false;
+    uint32_t inv64 = 0;  // (through the kernel's own SWAR test, four bytes at a time)
     for (uint32_t k = 0; k < 16; k++) {
       hi |= cm == 2 ? cb[k] >= lim : (cb[k] & (cm == 1 ? 0xC0u : 0x80u)) != 0;
       odd |= (cb[k] & 0x80u) && cb[k] != 0xFFu;
+    }
+    for (uint32_t k = 0; k < 16; k += 4) inv64 |= not_ctx64_nor_bypass((uint32_t)cb[k] | (uint32_t)cb[k + 1] << 8 | (uint32_t)cb[k + 2] << 16 | (uint32_t)cb[k + 3] << 24);
+    {
+      bool want = false;
+      for (uint32_t k = 0; k < 16; k++) want |= cb[k] >= 64u && cb[k] != 0xFFu;
+      if (want != (inv64 != 0)) bad = 0xDEAD2000u;  // the SWAR test must say what the definition says
     }
     uint32_t ow[4] = {0, 0, 0, 0}, oa = 0, ob = 0;
     if (full && !hi) {
@@ -524,9 +533,28 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
         }
         ow[g] = out_word(oa, ob);
       }
-    } else if (cm != 2 && full && !odd) {
+    } else if (cm == 1 && full && inv64 == 0) {
+      // <= 64 contexts: the mixed step on a dummy context (dec_bin_mixed2_nx_abs); a bypass byte's state address is the dummy
       if (path_counts) path_counts[1]++;
-      const uint32_t in = cm == 1 ? 0x3Fu : 0x7Fu;
+      for (int g = 0; g < 4; g++) {
+        if (g == 2) src.ensure(47);
+        if (src.avail_bits() < (int32_t)clz32(da.R)) bad = 0xDEAD1000u;
+        dec_topup_abs(da, src);
+        for (int k = 0; k < 4; k++) {
+          const uint32_t c = cb[4 * g + k], a = c == 0xFFu ? 256u : c;
+          const uint32_t nx = k == 0 ? dec_bin_mixed2_nx_abs<true>(da, a, st.load_at(a), st) : dec_bin_mixed2_nx_abs<false>(da, a, st.load_at(a), st);
+          if (k == 0) put_out_byte<0>(oa, ob, nx);
+          else if (k == 1) put_out_byte<1>(oa, ob, nx);
+          else if (k == 2) put_out_byte<2>(oa, ob, nx);
+          else put_out_byte<3>(oa, ob, nx);
+          if (da.R < 256u) bad = 0xDEAD0000u | (i0 + 4 * g + k);
+          if ((c == 0xFFu) != (st.cm[256] >= kDecBypassRaw && a == 256u)) bad = 0xDEAD3000u;  // the dummy stays a bypass byte
+        }
+        ow[g] = out_word(oa, ob);
+      }
+    } else if (cm == 3 && full && !odd) {
+      if (path_counts) path_counts[1]++;
+      const uint32_t in = 0x7Fu;
       for (int g = 0; g < 4; g++) {
         if (g == 2) src.ensure(47);
         if (src.avail_bits() < (int32_t)clz32(da.R)) bad = 0xDEAD1000u;
