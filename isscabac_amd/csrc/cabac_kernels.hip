@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
-  using BTile = EncTileB<PERM>;
-  using CTile = EncTileC<PERM>;
+  using BTile = EncTileB<CM, PERM>;
+  using CTile = EncTileC<CM, PERM>;
   uint32_t ridb[BTile::NLD] = {}, ridc[CTile::NLD] = {};
   if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
     uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);

@@ -341,11 +341,13 @@ constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads
 #ifndef ISSCABAC_ENC_LINE_C
 #define ISSCABAC_ENC_LINE_C 1  // the ctx array by whole lines
 #endif
-template <bool PERM>
-using EncTileB = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_B, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
+// (more than 128 contexts -- CM 2, at most 2.5 waves per SIMD -- keep the 64-byte segments: 190 contexts 3.98 -> 4.19 ms, 253 contexts
+// 4.77 -> 4.95 ms with whole lines, 127 contexts 3.72 -> 3.63: profiles/r06/c_other_shapes.txt)
+template <int CM, bool PERM>
+using EncTileB = typename std::conditional<!PERM && CM != 2 && ISSCABAC_ENC_LINE_B, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
                                            TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
-template <bool PERM>
-using EncTileC = typename std::conditional<!PERM && ISSCABAC_ENC_LINE_C, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
+template <int CM, bool PERM>
+using EncTileC = typename std::conditional<!PERM && CM != 2 && ISSCABAC_ENC_LINE_C, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
                                            TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type>::type;
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
