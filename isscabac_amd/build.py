@@ -27,15 +27,16 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile_objects(objdir, flags, verbose=False):
+def _compile_objects(objdir, flags, verbose=False, csrc=None):
     """one object per source, compiled side by side (the whole library in one hipcc call takes a minute, the slowest file 25 s);
     an object is reused while it is newer than its source and every header"""
     from concurrent.futures import ThreadPoolExecutor
+    csrc = csrc or CSRC
     os.makedirs(objdir, exist_ok=True)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     jobs, objs = [], []
     for f in SOURCES:
-        src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
+        src, obj = os.path.join(csrc, f), os.path.join(objdir, f + ".o")
         objs.append(obj)
         if os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(src)):
             continue
@@ -70,15 +71,28 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
-def build_variant(tag, defines):
-    """Same sources with extra -D flags -> tools/ab/variant_<tag>.so (A/B experiments, see tools/ab_bench.py)."""
+def build_variant(tag, defines=(), patches=()):
+    """The library with extra -D flags (the ten tunables of DESIGN.md) and / or patches applied to a scratch copy of the sources
+    -> tools/ab/variant_<tag>.so, for same-box A/B runs (tools/ab_bench.py).  patches: files of tools/ab_patches/ (`patch -p1`
+    against a tree that holds csrc/): timing-only builds -- no input loads, no output stores, ... -- live there, not behind
+    switches in the shipped sources."""
+    import tempfile
     out = os.path.join(HERE, "..", "tools", "ab", "variant_%s.so" % tag)  # A/B builds live beside the tools, not beside the product library
     os.makedirs(os.path.dirname(out), exist_ok=True)
     objdir = os.path.join(os.path.dirname(out), "obj_%s" % tag)
     if os.path.isdir(objdir):
         shutil.rmtree(objdir)
-    objs = _compile_objects(objdir, ["-D" + d for d in defines])
-    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    with tempfile.TemporaryDirectory() as tmp:
+        csrc = CSRC
+        if patches:
+            # the sources include ../../include/isscabac.h: keep that shape in the scratch tree
+            csrc = os.path.join(tmp, "isscabac_amd", "csrc")
+            shutil.copytree(CSRC, csrc)
+            shutil.copytree(os.path.join(HERE, "..", "include"), os.path.join(tmp, "include"))
+            for p in patches:
+                subprocess.check_call(["patch", "-s", "-p1", "-d", os.path.join(tmp, "isscabac_amd"), "-i", os.path.abspath(p)])
+        objs = _compile_objects(objdir, ["-D" + d for d in defines], csrc=csrc)
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     shutil.rmtree(objdir)
     return out
 

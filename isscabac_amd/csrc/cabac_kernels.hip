@@ -147,19 +147,13 @@ struct EncLatPipe {
 // LDS bytes of one wave: context states, two half tiles, (encoder) the output staging, (bucketed launches) the wave's stream ids
 template <int CM, bool PERM = false>
 struct WaveLds {
-#ifndef ISSCABAC_EXP_SB32
-#define ISSCABAC_EXP_SB32 0  // occupancy experiment: a 2 KiB state image (batches of <= 32 contexts only) -> five encoder waves per SIMD
-#endif
-  static constexpr uint32_t SB = CM == 1 ? (ISSCABAC_EXP_SB32 ? 2048u : 4096u) : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
+  static constexpr uint32_t SB = CM == 1 ? 4096u : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
-#ifndef ISSCABAC_ENC_MIXED2
-#define ISSCABAC_ENC_MIXED2 1  // the mixed step on a dummy context (enc_bin_mixed2_acc); 0: the select-based step of rounds 2-3
-#endif
   // one more row of the state image, behind its last context group: the "context" bypass bins read and write in the mixed
   // step (a byte nobody else looks at).  Not with 255 contexts: there the mixed step does not run and the row would cost a wave per CU
-  static constexpr uint32_t DUMMY = (ISSCABAC_ENC_MIXED2 && CM != 2) ? 256u : 0u;
+  static constexpr uint32_t DUMMY = CM != 2 ? 256u : 0u;
   static constexpr uint32_t BYTES = SB + DUMMY + 2 * TILE + STAGE + IDS;
 };
 
@@ -187,14 +181,6 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabRowOff / 4 + 2 * ps] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
     tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
-#if ISSCABAC_ENC_BINADDR
-  for (int eb = tid; eb < 256; eb += blockDim.x) {  // e = q | bin: packed state e >> 1, bin e & 1
-    const uint32_t ps = eb >> 1, bin = eb & 1u;
-    const uint32_t succ = (c_next.eb[ps >> 1] >> (16 * (ps & 1) + 8 * bin)) & 0xFFu;
-    tab[kTabBin8Off / 4 + 2 * eb] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
-    tab[kTabBin8Off / 4 + 2 * eb + 1] = ps >= 126 ? 0u : succ | ((bin != (ps & 1u)) ? 0xFF00u : 0u);
-  }
-#endif
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * enc_waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
@@ -208,8 +194,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
-  using BTile = EncTileB<CM, PERM>;
-  using CTile = EncTileC<CM, PERM>;
+  using BTile = EncTile<CM, PERM>;  // the tile of both input arrays, bins and ctx
+  using CTile = BTile;
   uint32_t ridb[BTile::NLD] = {}, ridc[CTile::NLD] = {};
   if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
     uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);
@@ -247,62 +233,34 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   sink.pos = 0;
   sink.on = valid;
 
-  // The two arrays may come in rounds of different length (TileT<LPR>): the loop runs over the longer one's rounds in
-  // 32-byte parts, and an array's next round is requested when its last part has gone to LDS
-  constexpr int TM = BTile::T > CTile::T ? BTile::T : CTile::T, NPM = TM / 32;
+  // A load round is TM bytes of every row of both arrays, coded in 32-byte parts; the next round is requested when the round's last
+  // part has gone to LDS (the staging registers are free again)
+  constexpr int TM = BTile::T, NPM = TM / 32;
   const uint32_t nrounds = (nmax + TM - 1) / TM;
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
-  // Two sets of staging registers, taking turns: a round's loads are issued when the OTHER set's round is half coded --
-  // a round and a half (96 bins) before they are needed instead of half a round (ISSCABAC_ENC_DEPTH2 = 0: one set)
   uint4 pb0[BTile::NLD], pc0[CTile::NLD];
-#if ISSCABAC_ENC_DEPTH2
-  static_assert(BTile::T == CTile::T, "the two-set rotation assumes equal rounds");
-  uint4 pb1[BTile::NLD], pc1[CTile::NLD];
-#endif
-  auto fetch_into = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t off, bool both, bool cc) {
-    if (both || !cc) {
-      if (PERM) BTile::template load_rows<kEncNT>(pb, a.bins, ridb, a.pitch, off, lane);
-      else BTile::template load<kEncNT>(pb, bins_w, nrows, a.pitch, off, lane);
-    }
-    if (both || cc) {
-      if (PERM) CTile::template load_rows<kEncNT>(pc, a.ctx, ridc, a.pitch, off, lane);
-      else CTile::template load<kEncNT>(pc, ctx_w, nrows, a.pitch, off, lane);
-    }
+  auto fetch_into = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t off) {
+    if (PERM) BTile::template load_rows<kEncNT>(pb, a.bins, ridb, a.pitch, off, lane);
+    else BTile::template load<kEncNT>(pb, bins_w, nrows, a.pitch, off, lane);
+    if (PERM) CTile::template load_rows<kEncNT>(pc, a.ctx, ridc, a.pitch, off, lane);
+    else CTile::template load<kEncNT>(pc, ctx_w, nrows, a.pitch, off, lane);
   };
-  if (nrounds) fetch_into(pb0, pc0, 0, true, false);
-#if ISSCABAC_ENC_DEPTH2
-  if (TM < nmax) fetch_into(pb1, pc1, TM, true, false);
-#endif
+  if (nrounds) fetch_into(pb0, pc0, 0);
   wave_lds_sync();
-  // one round of the longer array out of the register set (pb, pc); `ahead` = rounds between a set's request and its use
-  auto round = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t t, uint32_t ahead) {
-#if ISSCABAC_ENC_ROLLED
-#pragma unroll 1
-#else
+  // one round out of the staging registers (pb, pc)
+  auto round = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t t) {
 #pragma unroll
-#endif
     for (int h = 0; h < NPM; h++) {
       const uint32_t pos = t * TM + h * 32;
       if (pos >= nmax) return;
-      BTile::half_to_lds(tile_b, pb, h % BTile::NP, lane);
-      CTile::half_to_lds(tile_c, pc, h % CTile::NP, lane);
+      BTile::half_to_lds(tile_b, pb, h, lane);
+      CTile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-#if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's bytes again and again)
-      // registers are free again: the set's next round
-      if (h % BTile::NP == BTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, false);
-      const bool fetch_c = h % CTile::NP == CTile::NP - 1 && pos + 32 + (ahead - 1) * TM < nmax;
-      if (!ISSCABAC_ENC_SPLIT_FETCH && fetch_c) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
-#else
-      const bool fetch_c = false;
-#endif
-#if ISSCABAC_ENC_ROLLED
-#pragma unroll 1
-#endif
+      if (h == NPM - 1 && pos + 32 < nmax) fetch_into(pb, pc, pos + 32);
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = pos + j * 16;
         if (i0 >= nmax) break;
-        if (ISSCABAC_ENC_SPLIT_FETCH && j == 1 && fetch_c) fetch_into(pb, pc, pos + 32 + (ahead - 1) * TM, false, true);
         const uint4 wb = BTile::row_chunk(tile_b, lane, j);
         const uint4 wc = CTile::row_chunk(tile_c, lane, j);
         const bool full = i0 + 16 <= nmin;
@@ -334,7 +292,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
               with_bin_of_word(k - 1, v2, v1, [&](auto bin) { enc_lat_arith(e, acc, ((k - 1) & 3) == 0, bin, p.q_done, p.row_done); return 0; });
               if (((k - 1) & 3) == 3) {
                 enc_word_close(e, acc);
-                if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+                if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
               }
             }
           }
@@ -343,7 +301,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const uint32_t v1 = wb.w, v2 = v1 << 1;
             enc_lat_arith(e, acc, false, BinOfWord<3>{v2, v1, 0u}, p.q_done, p.row_done);
             enc_word_close(e, acc);
-            if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+            if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
           }
         } else if (full && !hi) {
           // every lane codes 16 context bins: convergent
@@ -353,15 +311,6 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const CtxQuad z = stx.prep4(word_of(wc, k >> 2));  // once per word: the compiler keeps it across the four bins
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1, w8 = w1 << 3;
             // `low` takes the word's four additions at once (EncWordAcc): one 64-bit shift + add per word, not per bin
-#if ISSCABAC_ENC_BINADDR
-            if ((k & 3) == 0) enc_bin_binaddr_acc(e, acc, true, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
-            else if ((k & 3) == 1) enc_bin_binaddr_acc(e, acc, false, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
-            else if ((k & 3) == 2) enc_bin_binaddr_acc(e, acc, false, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
-            else {
-              enc_bin_binaddr_acc(e, acc, false, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
-              enc_word_close(e, acc);
-            }
-#else
             if ((k & 3) == 0) enc_bin_row_acc(e, acc, true, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
             else if ((k & 3) == 1) enc_bin_row_acc(e, acc, false, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
             else if ((k & 3) == 2) enc_bin_row_acc(e, acc, false, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
@@ -369,11 +318,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
               enc_bin_row_acc(e, acc, false, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
               enc_word_close(e, acc);
             }
-#endif
             // digits leave `low` only when some lane could overflow it within the next four bins (W < 39 here =>
             // W <= 62 four bins later): with ~0.8 bit per bin that is every ~11 bins, and then every lane that has a
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)
-            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
           }
         } else if (CM != 2 && full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
           // context-coded and bypass bins only (config 5's chunks): one select-based step per bin for every lane, no lane
@@ -386,7 +334,6 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
           for (int k = 0; k < 16; k++) {
             const uint32_t cw = word_of(wc, k >> 2);
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
-#if ISSCABAC_ENC_MIXED2
             // per word: the bypass bits as bytes of 0 / 1, of 0 / 0xFE (or-ed into the state: 0xFE is the all-zero table entry),
             // and the bypass bins of value 1; a bypass bin's state address is the dummy context behind the image
             constexpr uint32_t kDummy = (CM == 1 ? 64u : 128u) * 0x01010101u;
@@ -394,15 +341,9 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const CtxQuad z = stx.prep4(select_mask(mbfe | cwm, kDummy, cw & kIn));
             const uint32_t wbm = w1 & cwm;
             with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed2_acc(e, acc, (k & 3) == 0, bin, cwm, mbfe, wbm, stx.addr_of(z, k & 3), stx); return 0; });
-#else
-            const CtxQuad z = stx.prep4(cw & kIn);
-            const uint32_t wbm = w1 & (cw >> 7);  // per word: bit 0 of byte k = "bypass bin of 1"
-            const uint32_t mb = byte_bit_mask(cw, k & 3, 7), bm = byte_bit_mask(wbm, k & 3, 0);
-            with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed_acc(e, acc, (k & 3) == 0, bin, mb, bm, stx.addr_of(z, k & 3), stx); return 0; });
-#endif
             if ((k & 3) == 3) {
               enc_word_close(e, acc);
-              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
             }
           }
         } else {
@@ -427,7 +368,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
                 enc_bin_prob(e, (w1 >> (8 * (k & 3))) & 1u, cb - kProbBase, c_prob_rows[prob_row_index(cb - kProbBase)]);
               }
             }
-            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) ISSCABAC_FLUSH_FN(e, sink);
+            if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
           }
         }
         if (ISSCABAC_ENC_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -435,14 +376,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
       wave_lds_sync();
     }
   };
-#if ISSCABAC_ENC_DEPTH2
-  for (uint32_t t = 0; t < nrounds; t += 2) {
-    round(pb0, pc0, t, 2);
-    if (t + 1 < nrounds) round(pb1, pc1, t + 1, 2);
-  }
-#else
-  for (uint32_t t = 0; t < nrounds; t++) round(pb0, pc0, t, 1);
-#endif
+  for (uint32_t t = 0; t < nrounds; t++) round(pb0, pc0, t);
   enc_flush16(e, sink);
   enc_finish16(e, sink);
   sink.close();
@@ -452,20 +386,10 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
 // ------------------------------------------------------------------------------------------------
 // decode kernel
 // ------------------------------------------------------------------------------------------------
-#ifndef ISSCABAC_DEC_LPR
-#define ISSCABAC_DEC_LPR 8
-#endif
-// the decode kernel's input tile (its one input array: ctx): 128-byte row segments where the registers allow it -- the
-// plain instances; the latency-oriented and the bucketed instances keep 64-byte segments (16 registers instead of 32)
-#ifndef ISSCABAC_DEC_LPR_PERM
-#define ISSCABAC_DEC_LPR_PERM ISSCABAC_DEC_LPR
-#endif
-#ifndef ISSCABAC_DEC_TILE_PAIR
-#define ISSCABAC_DEC_TILE_PAIR 0
-#endif
+// the decode kernel's input tile (its one input array: ctx): 128-byte row segments (32 registers); the latency-oriented instances
+// keep 64-byte segments (16)
 template <bool LAT, bool PERM>
-using DecTile = typename std::conditional<!LAT && !PERM && ISSCABAC_DEC_TILE_PAIR, TilePairT<ISSCABAC_DEC_LPR>,
-                                          TileT<LAT ? 4 : PERM ? ISSCABAC_DEC_LPR_PERM : ISSCABAC_DEC_LPR>>::type;
+using DecTile = TileT<LAT ? 4 : 8>;
 template <int CM, bool PERM>
 struct DecLds {
   static constexpr uint32_t SB = WaveLds<CM, PERM>::SB;
@@ -482,33 +406,18 @@ struct DecLds {
 };
 
 template <int CM, bool LAT, bool PERM>
-__global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
+__global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-#if ISSCABAC_DEC_SPLIT_TAB
-  if (tid < 64) {
-    tab[tid] = c_lps_rows[tid];
-    const uint32_t e = c_next.ep[tid];  // state tid: (mps 0: LPS path, MPS path), (mps 1: LPS path, MPS path)
-    tab[64 + tid] = dec_entry_hi_out(2 * tid, e & 0xFFu, (e >> 8) & 0xFFu) | dec_entry_hi_out(2 * tid + 1, (e >> 16) & 0xFFu, e >> 24) << 16;
-  }
-#else
   for (int qb = tid; qb < 256; qb += blockDim.x) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin
     const uint32_t ps = (uint32_t)qb >> 1;
     const uint32_t sp = c_next.ep[ps >> 1] >> (16 * (ps & 1));  // byte 0: successor on the LPS path, byte 1: on the MPS path
-#if ISSCABAC_DEC_TAB_REPL
-    for (int r = 0; r < 4; r++) {
-      tab[8 * qb + 2 * r] = c_lps_rows[ps >> 1];
-      tab[8 * qb + 2 * r + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
-    }
-#else
     // raw bytes 254 / 255 (state 63, no context's state): the bypass entry of the mixed step on a dummy context
     tab[2 * qb] = qb >= (int)kDecBypassRaw ? 0u : c_lps_rows[ps >> 1];
     tab[2 * qb + 1] = qb >= (int)kDecBypassRaw ? kDecBypassHi : dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
-#endif
   }
-#endif
   __syncthreads();
   const uint64_t s0 = ((uint64_t)blockIdx.x * dec_waves_per_block(CM) + wib) * 64;
   if (s0 >= a.S) return;
@@ -548,7 +457,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     if (DL::MIXED2) st32[DL::DUMMY_OFF / 4] = kDecBypassRaw * 0x01010101u;  // the bypass bins' dummy context: stays a bypass byte (0xFE | bin)
   }
   LdsStates stx{wbase + lane * 4};
-  if (ISSCABAC_DEC_TAB_REPL) stx.rep = ((uint32_t)lane & 3u) << 3;
 
   // payload window
   uint64_t start = a.offsets[s];
@@ -573,11 +481,7 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
 
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
-#if ISSCABAC_EXP_INPLACE  // (timing experiment: the output over the ctx rows -- same pages, same lines)
-  uint8_t *out_w = const_cast<uint8_t *>(a.ctx) + s0 * a.pitch;
-#else
   uint8_t *out_w = a.bins_out + s0 * a.pitch;
-#endif
   // 128 bins of every stream leave the staging buffer as full 128-byte row segments: lane l of pass k takes chunk l % 8 of
   // row 8 k + l / 8.  Ordinarily -- all 64 rows exist, the block lies inside the row -- the eight stores are issued by
   // hand: one wave-uniform base per pass (SGPRs) + one 32-bit lane offset for all of them (the compiler hoists eight 64-bit
@@ -594,13 +498,9 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         const uint4 v = OBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
         const u32x4 w = {v.x, v.y, v.z, v.w};
         uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
-#if ISSCABAC_DEC_NOSTORE  // timing experiment only
-        if (v.x == 0x12345678u)
-#endif
         // (s_nop 1: a store of more than 64 bits must not be followed within two wait states by a VALU write of its data -- the
         // compiler keeps that wait state for its own stores, it cannot see this one)
-        if (ISSCABAC_DEC_NT_ST == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
-        else if (kDecNTst) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
+        if (kDecNTst) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
       }
       return;
@@ -619,22 +519,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     }
   };
 
-#ifndef ISSCABAC_EXP_PRIO
-#define ISSCABAC_EXP_PRIO 0  // issue-priority experiment: 1 = the wave is preferred while it issues its loads / stores (no gain)
-#endif
-#ifndef ISSCABAC_EXP_SPREAD_ST
-#define ISSCABAC_EXP_SPREAD_ST 0  // timing experiment (wrong output): one store instruction behind every chunk instead of eight per
-                                  // block -- 3.01 ms against 2.95: the bursts are not what the stores cost
-#endif
-  [[maybe_unused]] auto store_one = [&](uint32_t off, int k) {
-    const uint32_t ln = opaque((uint32_t)lane);
-    const uint32_t st_voff = (ln >> 3) * a.pitch + (ln & 7) * 16;
-    const uint32_t st_lds = (uint32_t)(uintptr_t)(LdsStates::lds_u8 *)reinterpret_cast<uint8_t *>(obuf) + 4 * OBuf::idx(ln & 7, ln >> 3);
-    const uint4 v = OBuf::unpack(*reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(st_lds ^ (32u * k))));
-    const u32x4 w = {v.x, v.y, v.z, v.w};
-    uint8_t *base = out_w + ((uint64_t)(8 * k) * a.pitch + off);
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(st_voff), "v"(w), "s"(base) : "memory");
-  };
   const uint32_t nrounds = (a.nbins + DTile::T - 1) / DTile::T;
   uint4 pc[DTile::NLD];
   auto fetch = [&](uint32_t off) {
@@ -643,32 +527,13 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
   };
   if (nrounds) fetch(0);
   wave_lds_sync();
-#if ISSCABAC_EXP_CLK
-  uint64_t clk_ctx = 0, clk_body = 0, clk_st = 0, clk_ld = 0;
-  const uint64_t clk_start = __builtin_amdgcn_s_memtime();
-#endif
   bool have_out = false;
   uint32_t out_off = 0;
   for (uint32_t t = 0; t < nrounds; t++) {
-#if ISSCABAC_DEC_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int h = 0; h < DTile::NP; h++) {
-#if ISSCABAC_EXP_CLK
-      if (h == 0) {
-        const uint64_t c0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-        clk_ctx += __builtin_amdgcn_s_memtime() - c0;
-      }
-#endif
       DTile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-#if ISSCABAC_DEC_ROLLED
-#pragma unroll 1
-#endif
       for (int j = 0; j < 2; j++) {
         const uint32_t i0 = t * DTile::T + h * DTile::H + j * 16;
         const uint32_t cidx = (i0 >> 4) & 7u;  // chunk inside the 128-bin output block
@@ -678,36 +543,14 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         if (j == 0) {
           // global stores and loads go out right AFTER the window boundary: vmcnt is in-order and counts stores, so
           // anything issued just before the boundary's wait for the payload piece would be waited for as well
-          if (have_out && !ISSCABAC_EXP_SPREAD_ST) {
-#if ISSCABAC_EXP_CLK
-            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-            const uint64_t cs0 = __builtin_amdgcn_s_memtime();
-#endif
-            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+          if (have_out) {
             store_out(out_off);
-            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
             wave_lds_sync();  // the staging buffer is rewritten from here on
-#if ISSCABAC_EXP_CLK
-            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-            clk_st += __builtin_amdgcn_s_memtime() - cs0;
-#endif
             have_out = false;
           }
-#if !ISSCABAC_EXP_NOLOAD  // (timing experiment: the first round's ctx bytes again and again)
           if (h == DTile::NP - 1 && t + 1 < nrounds && (t + 1) * DTile::T < nmax) {  // nothing to decode past the wave's longest stream
-#if ISSCABAC_EXP_CLK
-            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-            const uint64_t cf0 = __builtin_amdgcn_s_memtime();
-#endif
-            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(3);
             fetch((t + 1) * DTile::T);
-            if (ISSCABAC_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-#if ISSCABAC_EXP_CLK
-            asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-            clk_ld += __builtin_amdgcn_s_memtime() - cf0;
-#endif
           }
-#endif
         }
         if (live) {
         const uint4 wc = DTile::row_chunk(tile_c, lane, j);
@@ -720,10 +563,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         uint32_t oa = 0, ob = 0;
         if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_DEC_PRIO);
         if (full && !hi) {
-#if ISSCABAC_EXP_CLK
-          asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-          const uint64_t cb0 = __builtin_amdgcn_s_memtime();
-#endif
           // every lane decodes 16 context bins
           // latency-oriented instance: a bin's entry is read right behind the decision of the bin before it (its state may
           // be that bin's successor: forwarded in a register for a repeated context, else loaded two bins ahead), and the
@@ -756,27 +595,15 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                 const int i = 4 * g + k;
                 if (k == 0) {  // right behind the top-up: R's leading one is bit 31
                   psel = da.R >> 29;
-                  psh = ISSCABAC_DEC_LAT_MAD ? 0xFF800000u : 23u;  // the comparison point, or (ISSCABAC_DEC_LAT_MAD) -(1 << it)
+                  psh = 23u;  // the comparison point
                 }
-#if ISSCABAC_DEC_LAT_EXP
-                // timing only (wrong for a repeated context): the next bin's entry requested BEFORE this bin's decision, by the
-                // state read ahead -- what a perfect speculation of the decoder's state fetch could reach
-                uint64_t ent_n = 0;
-                if (i < 15) ent_n = stx.entry_raw(qld_nxt);
-#endif
-                const uint32_t nx = ISSCABAC_DEC_LAT_MAD ? dec_bin_nx_abs_at_mad(da, ent, psel, psh) : dec_bin_nx_abs_at(da, ent, psel, psh);
-#if ISSCABAC_DEC_LAT_EXP
-                ent = ent_n;
-#else
+                const uint32_t nx = dec_bin_nx_abs_at(da, ent, psel, psh);
                 if (i < 15) {
                   uint32_t qn;
                   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
                   ent = stx.entry_raw(qn);
                 }
-#endif
-#if ISSCABAC_DEC_LAT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
-#endif
                 stx.store_at(at_cur, nx);
                 uint32_t at_n2 = 0, qld_n2 = 0;
                 if (i < 14) {
@@ -790,15 +617,12 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
                 else put_out_byte<3>(oa, ob, nx);
                 if (i < 14) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_n2), "v"(at_nxt));
                 if (k < 3) {
-              if (ISSCABAC_DEC_LAT_MAD) abs_positions_neg(da.R, psel, psh);
-              else abs_positions(da.R, psel, psh);
-            }
+                  abs_positions(da.R, psel, psh);
+                }
                 at_cur = at_nxt;
                 at_nxt = at_n2;
                 qld_nxt = qld_n2;
-#if ISSCABAC_DEC_LAT_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
-#endif
               }
             } else {
               const CtxQuad z = stx.prep4(word_of(wc, g));
@@ -810,10 +634,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
             }
             od |= (out_word(oa, ob) & 0x01010101u) << g;
           }
-#if ISSCABAC_EXP_CLK
-          asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
-          clk_body += __builtin_amdgcn_s_memtime() - cb0;
-#endif
         } else if (DL::MIXED2 && full &&
                    !wave_any((not_ctx64_nor_bypass(wc.x) | not_ctx64_nor_bypass(wc.y) | not_ctx64_nor_bypass(wc.z) | not_ctx64_nor_bypass(wc.w)) != 0)) {
           // contexts below 64 and bypass bins only (config 5's chunks): the step on a dummy context (dec_bin_mixed2_nx_abs) -- under
@@ -898,9 +718,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
         }
         if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
         obuf[OBuf::idx(cidx, lane)] = od;
-#if ISSCABAC_EXP_SPREAD_ST
-        if (t > 0) store_one((t - 1) * DTile::T, (int)cidx);
-#endif
       }
       wave_lds_sync();
     }
@@ -922,14 +739,6 @@ __global__ void __launch_bounds__(256, ISSCABAC_DEC_OCC) k_decode(DecArgs a) {
     const uint8_t *p = a.payload + first;
     dec_from_abs(d, da);
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
-#if ISSCABAC_EXP_CLK
-    const uint64_t tot = __builtin_amdgcn_s_memtime() - clk_start;
-    if (lane == 1) a.status[s] = (uint32_t)clk_ctx;
-    if (lane == 2) a.status[s] = (uint32_t)tot;
-    if (lane == 3) a.status[s] = (uint32_t)clk_body;
-    if (lane == 4) a.status[s] = (uint32_t)clk_st;
-    if (lane == 5) a.status[s] = (uint32_t)clk_ld;
-#endif
   }
 }
 
@@ -1278,11 +1087,8 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
-#ifndef ISSCABAC_DEC_LDS_PAD  // (occupancy experiments: bytes of unused LDS per workgroup)
-#define ISSCABAC_DEC_LDS_PAD 0
-#endif
   using DL = DecLds<CM, PERM>;
-  const size_t lds_max = kDecTabBytes + dec_waves_per_block(CM) * DL::BYTES + ISSCABAC_DEC_LDS_PAD;
+  const size_t lds_max = kDecTabBytes + dec_waves_per_block(CM) * DL::BYTES;
   const size_t lds = CM == 2 ? lds_max - DL::SB + a.img_bytes : lds_max;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);

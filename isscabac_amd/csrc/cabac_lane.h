@@ -106,16 +106,10 @@ CABAC_HD uint32_t clz32(uint32_t x) { return (uint32_t)__builtin_clz(x); }
 // v_lshlrev_b32 issues at half rate and v_lshlrev_b16 at full rate (tools/ubench/valu_ops2: 1.77 against 0.99 ns per
 // instruction and SIMD at four waves; right shifts are full rate either way); the 16-bit form writes zeros to bits 16..31.
 // x must be below 2^16 and n below 16.
-#ifndef ISSCABAC_SHL16
-#define ISSCABAC_SHL16 1
-#endif
 // ... but not for the decode kernels' table address: there the 16-bit shift (inline assembly) measured SLOWER, 2.879 against
 // 2.812 ms (medians of 8 on one box) -- the compiler places its own shift better than one it cannot see into
-#ifndef ISSCABAC_DEC_SHL16
-#define ISSCABAC_DEC_SHL16 0
-#endif
 CABAC_HD uint32_t shl16(uint32_t x, uint32_t n) {
-#if defined(__HIP_DEVICE_COMPILE__) && ISSCABAC_SHL16
+#if defined(__HIP_DEVICE_COMPILE__)
   uint32_t r;
   asm("v_lshlrev_b16_e32 %0, %1, %2" : "=v"(r) : "v"(n), "v"(x));
   return r;
@@ -125,7 +119,7 @@ CABAC_HD uint32_t shl16(uint32_t x, uint32_t n) {
 }
 template <int K>
 CABAC_HD uint32_t shl16c(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__) && ISSCABAC_SHL16
+#if defined(__HIP_DEVICE_COMPILE__)
   uint32_t r;
   static_assert(K == 2 || K == 3, "the shifts the table lookups use");
   if (K == 2) asm("v_lshlrev_b16_e32 %0, 2, %1" : "=v"(r) : "v"(x));
@@ -359,61 +353,16 @@ CABAC_HD void enc_pick(const Bin &bin, uint32_t q, uint32_t t, uint32_t lps, uin
   r = select_mask(m, lps, rmps);
   a = rmps & m;
 }
-// timing experiments (wrong output, never in the product build): which half of the step bounds the kernel?
-//   ISSCABAC_EXP_STEP 1: arithmetic only -- no state read / write, the table entry by a constant state (one LDS read, no chain)
-//   ISSCABAC_EXP_STEP 2: arithmetic only, no LDS at all (the entry out of registers)
-//   ISSCABAC_EXP_STEP 3: state pass only -- state read, entry read, successor write; no range / low arithmetic
-#ifndef ISSCABAC_EXP_STEP
-#define ISSCABAC_EXP_STEP 0
-#endif
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_row_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
-#if ISSCABAC_EXP_STEP == 1 || ISSCABAC_EXP_STEP == 2
-  const uint32_t q = opaque(40u);
-#if ISSCABAC_EXP_STEP == 1
-  const uint64_t ent = st.entry_mem(q);
-#else
-  const uint64_t ent = (uint64_t)opaque(0x3B332B23u) | ((uint64_t)opaque(0x00FF2C24u) << 32);
-#endif
-  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
-  (void)at;
-#elif ISSCABAC_EXP_STEP == 3
-  const uint32_t q = st.load_at(at);
-  const uint64_t ent = st.entry_mem(q);
-  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
-  st.store_at(at, t);
-  if (first) g.T = g.S = 0;
-  g.T += (uint32_t)ent >> 31;  // (keeps the row alive)
-  return;
-#else
   const uint32_t q = st.load_at(at);
   const uint64_t ent = st.entry_mem(q);
   const uint32_t t = bin.next_of((uint32_t)(ent >> 32));  // low byte: the successor; bit 16: the bin is not q's mps
   st.store_at(at, t);
-#endif
   const uint32_t lps = lps_of((uint32_t)ent, e.range);
   const uint32_t rmps = e.range - lps;
   uint32_t r, a;
   enc_pick(bin, q, t, lps, rmps, r, a);
-  const uint32_t n = clz32(r) - 23u;
-  g.T = ((first ? 0u : g.T) + a) << n;
-  g.S = (first ? 0u : g.S) + n;
-  e.range = shl16(r, n);
-}
-// The same step on a table indexed by (state, bin): entry_bin(q | bin, m) -> the row in the low word, the successor for THIS
-// bin in byte 4 and the LPS decision as a ready 32-bit mask m (the kernel reads the entry's flag byte a second time,
-// sign-extended by the LDS instruction) -- no shift by the bin and no mask instruction: one more LDS read, two fewer
-// half-rate VALU instructions per bin.  Bin policy: or_q(q) -> q | bin.
-template <class States, class Addr, class Bin>
-CABAC_HD void enc_bin_binaddr_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, Addr at, States &st) {
-  const uint32_t q = st.load_at(at);
-  uint32_t m;
-  const uint64_t ent = st.entry_bin(bin.or_q(q), m);
-  st.store_at(at, (uint32_t)(ent >> 32));  // the store takes the low byte: the successor
-  const uint32_t lps = lps_of((uint32_t)ent, e.range);
-  const uint32_t rmps = e.range - lps;
-  const uint32_t r = select_mask(m, lps, rmps);
-  const uint32_t a = rmps & m;
   const uint32_t n = clz32(r) - 23u;
   g.T = ((first ? 0u : g.T) + a) << n;
   g.S = (first ? 0u : g.S) + n;
@@ -1171,47 +1120,6 @@ CABAC_HD uint32_t dec_bin_nx_abs_at(DecAbs &a, uint64_t ent, uint32_t sel, uint3
   a.v = diff;
   a.R = r;
 #else
-  const bool mps_path = a.v < rmps;
-  nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
-  a.R = mps_path ? rmps : lpss;
-  a.v = mps_path ? a.v : a.v - rmps;
-#endif
-  return nx;
-}
-// The same with the LPS term subtracted by ONE multiply-add: (range - LPS) << sh = R - LPS * 2^sh = R + LPS * negp with
-// negp = -(1 << sh) (fits the signed 24-bit operand of v_mad_i32_i24: sh <= 23), so that the chain from the entry's arrival to
-// the decision is perm -> mad -> sub-with-borrow instead of perm -> shift -> sub -> sub-with-borrow; LPS << sh itself (the
-// new R on the LPS path) is R - that, beside the chain.  negp is worked out with the positions, in the entry read's shadow.
-#ifndef ISSCABAC_DEC_LAT_EXP
-#define ISSCABAC_DEC_LAT_EXP 0  // timing experiment (wrong bins, never in the product build): k_decode<.., LAT, ..> without the forwarding
-#endif
-#ifndef ISSCABAC_DEC_LAT_MAD
-#define ISSCABAC_DEC_LAT_MAD 0
-#endif
-CABAC_HD void abs_positions_neg(uint32_t R, uint32_t &sel, uint32_t &negp) {
-  const uint32_t t = 29u - clz32(R);  // sh + 6
-  sel = R >> t;
-  negp = ~0u << (t - 6u);
-}
-CABAC_HD uint32_t dec_bin_nx_abs_at_mad(DecAbs &a, uint64_t ent, uint32_t sel, uint32_t negp) {
-  const uint32_t lps = lps_col((uint32_t)ent, sel);
-  uint32_t rmps, nx;
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(rmps) : "v"(lps), "v"(negp), "v"(a.R));
-  const uint32_t lpss = a.R - rmps;
-  uint32_t diff, r;
-  asm("v_sub_co_u32_e32 %0, vcc, %3, %4\n\t"
-      "v_cndmask_b32_sdwa %1, %5, %5, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n\t"
-      "v_cndmask_b32_e32 %2, %6, %4, vcc\n\t"
-      "v_cndmask_b32_e32 %0, %0, %3, vcc"
-      : "=&v"(diff), "=&v"(nx), "=&v"(r)
-      : "v"(a.v), "v"(rmps), "v"((uint32_t)(ent >> 32)), "v"(lpss)
-      : "vcc");
-  a.v = diff;
-  a.R = r;
-#else
-  rmps = a.R + lps * negp;
-  const uint32_t lpss = a.R - rmps;
   const bool mps_path = a.v < rmps;
   nx = (uint32_t)(ent >> (mps_path ? 40 : 32)) & 0xFFu;
   a.R = mps_path ? rmps : lpss;

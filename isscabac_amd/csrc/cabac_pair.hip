@@ -33,27 +33,6 @@
 
 namespace isscabac {
 
-#ifndef ISSCABAC_ENC_PAIR
-#define ISSCABAC_ENC_PAIR 1
-#endif
-#ifndef ISSCABAC_PAIR_ALT_ROLES
-#define ISSCABAC_PAIR_ALT_ROLES 0  // producer = wave (blockIdx & 1) of the workgroup instead of wave 0: successive workgroups put their
-#endif                             // producers on different SIMDs of the pair they share
-#ifndef ISSCABAC_PAIR_EXP  // timing experiments (wrong output, never in the product build): 1 = B skips its arithmetic, 2 = A skips
-#define ISSCABAC_PAIR_EXP 0  // the state pass, 3 = no barrier between the chunks, 5 = A without the forwarding (no chain: every lookup on the state read ahead)
-#endif
-#ifndef ISSCABAC_PAIR_TILE_PAIR
-#define ISSCABAC_PAIR_TILE_PAIR 1  // A's input tiles by lane pairs (TilePairT: two full-wave LDS stores per part instead of four half-active ones)
-#endif
-#ifndef ISSCABAC_PAIR_NOSYNC
-#define ISSCABAC_PAIR_NOSYNC 0  // A's tile hand-over without draining lgkmcnt: a wave's LDS operations execute in order anyway
-#endif
-#ifndef ISSCABAC_PAIR_PRIO_A
-#define ISSCABAC_PAIR_PRIO_A 1  // s_setprio of the producer wave: its few chain instructions per bin should never queue behind B's arithmetic
-#endif
-#ifndef ISSCABAC_PAIR_PRIO_B
-#define ISSCABAC_PAIR_PRIO_B 0  // s_setprio of the consumer wave while it codes a chunk
-#endif
 
 namespace pairk {
 constexpr uint32_t kKind = 1008;
@@ -136,35 +115,6 @@ __device__ __forceinline__ void pair_state_pass(const LdsStates &stx, const uint
     }
   };
   uint4 rw;
-  if (ISSCABAC_PAIR_EXP == 5) {
-    // timing only (wrong for repeated contexts): the pass two deep in flight and without forwarding -- what a chain-free
-    // producer would cost
-    uint32_t ats[16];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const CtxQuad zz = quad_of(g);
-#pragma unroll
-      for (int k = 0; k < 4; k++) ats[4 * g + k] = stx.addr32_of(zz, k);
-    }
-    uint32_t qa = stx.load_at(ats[0]), qb = stx.load_at(ats[1]);
-    uint64_t ent_cur = entry_of(qa, two);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      uint32_t qc = 0;
-      uint64_t ent_next = 0;
-      if (k + 2 < 16) qc = stx.load_at(ats[k + 2]);
-      if (k + 1 < 16) ent_next = entry_of(qb, two);
-      const uint32_t tk = pair_next_of_k(k, word_of(wb, k >> 2) << 3, (uint32_t)(ent_cur >> 32));
-      stx.store_at(ats[k], tk);
-      if (k < 8) f0 |= tk & flag_bit(k);
-      else f1 |= tk & flag_bit(k);
-      set_word(rw, k & 3, (uint32_t)ent_cur);
-      if ((k & 3) == 3) put_rows(rows_at + (k >> 2) * 1024u, rw);
-      ent_cur = ent_next;
-      qb = qc;
-    }
-    return;
-  }
   CtxQuad z = quad_of(0);
   uint32_t at = stx.addr32_of(z, 0), at_prev = 0;
   uint32_t qld = stx.load_at(at);
@@ -209,7 +159,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
   using namespace pairk;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(((tid >> 6) ^ (ISSCABAC_PAIR_ALT_ROLES ? (int)blockIdx.x : 0)) & 1);  // 0: producer (A), 1: consumer (B)
+  const int wib = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // 0: producer (A), 1: consumer (B)
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     const int ps = tid;  // 128 threads, 128 packed states
@@ -239,14 +189,11 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
       st32[16 * 64] = 0;  // the dummy context: only ever receives the all-zero entry's successor
     }
     LdsStates stx{wbase + lane * 4};
-    if (ISSCABAC_PAIR_PRIO_A) __builtin_amdgcn_s_setprio(ISSCABAC_PAIR_PRIO_A);
+    __builtin_amdgcn_s_setprio(1);
     uint8_t *tile_b = smem + kTileB, *tile_c = smem + kTileC;
-    using BTile = std::conditional<ISSCABAC_PAIR_TILE_PAIR != 0, TilePairT<4>, TileT<4>>::type;
+    using BTile = TilePairT<4>;
     using CTile = BTile;
-    auto tile_sync = [] {
-      if (ISSCABAC_PAIR_NOSYNC) asm volatile("" ::: "memory");  // (the compiler may not move LDS accesses across; the hardware keeps a wave's in order)
-      else wave_lds_sync();
-    };
+    auto tile_sync = [] { wave_lds_sync(); };
     const uint32_t nrounds = (nmax + BTile::T - 1) / BTile::T;
     const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
     const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
@@ -281,9 +228,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
           const uint32_t rows_at = lane_rows + slot, flags_at = lane_flags + slot;
           uint32_t f0 = 0, f1 = 0;
           [[maybe_unused]] uint4 rw;
-          if (ISSCABAC_PAIR_EXP == 2 || (ISSCABAC_PAIR_EXP == 4 && c >= 2)) {
-            *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kPlain;
-          } else if (full && !hi) {
+          if (full && !hi) {
             pair_state_pass<false>(stx, wb, wc, rows_at, two, f0, f1);
             *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kPlain;
           } else if (full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
@@ -319,7 +264,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
             *reinterpret_cast<lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))) = kGeneral;
           }
           *reinterpret_cast<lds_u64 *>((uintptr_t)flags_at) = (uint64_t)f0 | (uint64_t)f1 << 32;
-          if (ISSCABAC_PAIR_EXP != 3) __syncthreads();  // chunk c is in its slot; B has left slot (c + 1) & 1
+          __syncthreads();  // chunk c is in its slot; B has left slot (c + 1) & 1
           c++;
         }
         tile_sync();
@@ -345,10 +290,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
     const uint32_t kind = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const lds_u32 *>((uintptr_t)(kKind + 4u * (c & 1u))));
     const uint64_t fw = *reinterpret_cast<const lds_u64 *>((uintptr_t)flags_at);
     const uint32_t f0 = (uint32_t)fw, f1 = (uint32_t)(fw >> 32);
-    if (ISSCABAC_PAIR_PRIO_B) __builtin_amdgcn_s_setprio(ISSCABAC_PAIR_PRIO_B);
-    if (ISSCABAC_PAIR_EXP == 1) {
-      e.range += f0 + kind;
-    } else if (kind == kPlain) {
+    if (kind == kPlain) {
       EncWordAcc acc;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -392,8 +334,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
         if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
       }
     }
-    if (ISSCABAC_PAIR_PRIO_B) __builtin_amdgcn_s_setprio(0);
-    if (ISSCABAC_PAIR_EXP != 3) __syncthreads();  // slot c & 1 is free again; chunk c + 1 is there
+    __syncthreads();  // slot c & 1 is free again; chunk c + 1 is there
   }
   enc_flush16(e, sink);
   enc_finish16(e, sink);
@@ -401,7 +342,7 @@ __global__ void __launch_bounds__(128, 4) k_encode_pair(EncArgs a) {
   if (valid) a.lens[s] = sink.bytes();
 }
 
-bool encode_pair_enabled() { return ISSCABAC_ENC_PAIR != 0; }
+bool encode_pair_enabled() { return true; }
 
 hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
   static int static_lds = -1;  // absolute LDS addresses: the dynamic LDS must start at 0 (cabac_kernels.hip: run_encode)
@@ -434,18 +375,6 @@ hipError_t run_encode_pair(const EncArgs &a, hipStream_t stream) {
 // LDS of a workgroup (18 448 bytes): [0, 2048) the raw-byte entries | 4 KiB context states | 2 KiB ctx half tile (A) |
 // 2 x 2 KiB output staging (OutBuf) | 2 slots x 3 KiB: addresses of bins 0..7, of bins 8..15, the 16 ctx bytes | kinds
 // ================================================================================================
-#ifndef ISSCABAC_DEC_PAIR
-#define ISSCABAC_DEC_PAIR 1
-#endif
-#ifndef ISSCABAC_DPAIR_ALT_ROLES
-#define ISSCABAC_DPAIR_ALT_ROLES 0  // helper = wave (blockIdx & 1) of the workgroup instead of wave 0
-#endif
-#ifndef ISSCABAC_DPAIR_TILE_PAIR
-#define ISSCABAC_DPAIR_TILE_PAIR 0  // the helper's ctx tile by lane pairs (TilePairT)
-#endif
-#ifndef ISSCABAC_DPAIR_PRIO_B
-#define ISSCABAC_DPAIR_PRIO_B 0  // the decoding wave's priority OUTSIDE its chunks (inside: ISSCABAC_DEC_PRIO)
-#endif
 
 namespace dpair {
 constexpr uint32_t kStates = 2048;
@@ -466,7 +395,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
   using pairk::put_rows;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(((tid >> 6) ^ (ISSCABAC_DPAIR_ALT_ROLES ? (int)blockIdx.x : 0)) & 1);  // 0: helper (A), 1: decoder (B)
+  const int wib = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // 0: helper (A), 1: decoder (B)
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     for (int qb = tid; qb < 256; qb += 128) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin (k_decode)
@@ -492,7 +421,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
 
   if (wib == 0) {
     // -------------------------------------------------------------------------------------------- helper
-    using DTile = std::conditional<ISSCABAC_DPAIR_TILE_PAIR != 0, TilePairT<4>, TileT<4>>::type;
+    using DTile = TileT<4>;
     uint8_t *tile_c = smem + kTile;
     const uint8_t *ctx_w = a.ctx + s0 * a.pitch;
     uint8_t *out_w = a.bins_out + s0 * a.pitch;
@@ -612,7 +541,6 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
   dec_start(d, src);
   if (valid && needs_ref_decoder(d.v >> 24) && a.exact_flag) *a.exact_flag = 1u;  // (k_decode_exact takes those streams)
   DecAbs da = dec_to_abs(d);
-  if (ISSCABAC_DPAIR_PRIO_B) __builtin_amdgcn_s_setprio(ISSCABAC_DPAIR_PRIO_B);
   __syncthreads();  // chunk 0 is there
   for (uint32_t c = 0; c < nchunks; c++) {
     const uint32_t i0 = c * 16u, cidx = c & 7u;
@@ -648,17 +576,15 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
             const int i = 4 * g + k;
             if (k == 0) {  // right behind the top-up: R's leading one is bit 31
               psel = da.R >> 29;
-              psh = ISSCABAC_DEC_LAT_MAD ? 0xFF800000u : 23u;  // the comparison point, or (ISSCABAC_DEC_LAT_MAD) -(1 << it)
+              psh = 23u;  // the comparison point
             }
-            const uint32_t nx = ISSCABAC_DEC_LAT_MAD ? dec_bin_nx_abs_at_mad(da, ent, psel, psh) : dec_bin_nx_abs_at(da, ent, psel, psh);
+            const uint32_t nx = dec_bin_nx_abs_at(da, ent, psel, psh);
             if (i < 15) {
               uint32_t qn;
               asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(qn) : "v"(qld_nxt), "v"(nx), "s"(same_nxt));
               ent = stx.entry_raw(qn);
             }
-#if ISSCABAC_DEC_LAT_BARRIER
             __builtin_amdgcn_sched_barrier(0);
-#endif
             stx.store_at(at_cur, nx);
             uint32_t at_n2 = 0, qld_n2 = 0;
             if (i < 14) {
@@ -671,15 +597,12 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
             else put_out_byte<3>(oa, ob, nx);
             if (i < 14) asm volatile("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(same_nxt) : "v"(at_n2), "v"(at_nxt));
             if (k < 3) {
-              if (ISSCABAC_DEC_LAT_MAD) abs_positions_neg(da.R, psel, psh);
-              else abs_positions(da.R, psel, psh);
+              abs_positions(da.R, psel, psh);
             }
             at_cur = at_nxt;
             at_nxt = at_n2;
             qld_nxt = qld_n2;
-#if ISSCABAC_DEC_LAT_BARRIER
             __builtin_amdgcn_sched_barrier(0);
-#endif
           }
           od |= (out_word(oa, ob) & 0x01010101u) << g;
         }
@@ -741,7 +664,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
           da = dec_to_abs(d);
         }
       }
-      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(ISSCABAC_DPAIR_PRIO_B);
+      if (ISSCABAC_DEC_PRIO) __builtin_amdgcn_s_setprio(0);
     }
     obuf[OutBuf::idx(cidx, lane)] = od;
     __syncthreads();  // the chunk's bins are in the staging buffer; chunk c + 1 is in its slot
@@ -756,7 +679,7 @@ __global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
   }
 }
 
-bool decode_pair_enabled() { return ISSCABAC_DEC_PAIR != 0; }
+bool decode_pair_enabled() { return true; }
 
 hipError_t run_decode_pair(const DecArgs &a, hipStream_t stream) {
   static int static_lds = -1;  // absolute LDS addresses, as in run_encode_pair

@@ -468,7 +468,7 @@ struct WalkStates {
   __device__ __forceinline__ void store_at(uint32_t a, uint32_t q) const { *reinterpret_cast<sym_lds_u8 *>((uintptr_t)a) = (uint8_t)q; }
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)shl16c<2>(q)); }
   // the decoder's entry by raw state byte (bit 0 = a stale bin): 256 entries at LDS 0
-  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3)); }
+  __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const { return *reinterpret_cast<const sym_lds_u64 *>((uintptr_t)(qb << 3)); }
 };
 // Bin policy of enc_bin_row_acc for a bin string kept << 3: the bin at bit 3, where it is the shift that picks the successor
 struct WalkBin {
@@ -478,18 +478,13 @@ struct WalkBin {
 };
 
 // enc_pick (cabac_lane.h) on the flag byte of the shifted entry, as in k_encode: the flag byte (0x00 / 0xFF) sign-extended by
-// an SDWA move is the select mask; ISSCABAC_SYM_PICK_VCC = 1: one SDWA compare into VCC and two selects
-#ifndef ISSCABAC_SYM_PICK_VCC
-#define ISSCABAC_SYM_PICK_VCC 0
-#endif
+// an SDWA move is the select mask
 __device__ __forceinline__ void enc_pick(const WalkBin &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
-#if !ISSCABAC_SYM_PICK_VCC
   uint32_t m;
   asm("v_mov_b32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(m) : "v"(t));
   r = select_mask(m, lps, rmps);
   a = rmps & m;
   return;
-#endif
   asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
       "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
       "v_cndmask_b32_e32 %1, 0, %4, vcc"

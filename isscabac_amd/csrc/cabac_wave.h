@@ -13,27 +13,6 @@
 #include "cabac_internal.h"
 #include "cabac_lane.h"
 
-#ifndef ISSCABAC_DEC_SPLIT_TAB
-#define ISSCABAC_DEC_SPLIT_TAB 0
-#endif
-#ifndef ISSCABAC_EXP_NOLOAD  // timing experiments, never in the product build
-#define ISSCABAC_EXP_NOLOAD 0
-#endif
-#ifndef ISSCABAC_EXP_NOPAYLOAD
-#define ISSCABAC_EXP_NOPAYLOAD 0
-#endif
-#ifndef ISSCABAC_DEC_ROLLED  // the four chunks of a load round as a real loop: a quarter of the code
-#define ISSCABAC_DEC_ROLLED 0
-#endif
-#ifndef ISSCABAC_ENC_ROLLED
-#define ISSCABAC_ENC_ROLLED 0
-#endif
-#ifndef ISSCABAC_EXP_INPLACE
-#define ISSCABAC_EXP_INPLACE 0
-#endif
-#ifndef ISSCABAC_EXP_CLK  // stall accounting of the decode kernel into the status words (tools/dec_stalls.py)
-#define ISSCABAC_EXP_CLK 0
-#endif
 
 namespace isscabac {
 
@@ -102,17 +81,10 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 #ifndef ISSCABAC_ENC_PRIO
 #define ISSCABAC_ENC_PRIO 1
 #endif
-#ifndef ISSCABAC_DEC_LAT_BARRIER
-#define ISSCABAC_DEC_LAT_BARRIER 1  // scheduling barriers around the latency-oriented decoder's per-bin tail
-#endif
 // waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
-#ifndef ISSCABAC_ENC_BINADDR
-#define ISSCABAC_ENC_BINADDR 0  // the plain step's table lookup by (state, bin): see LdsStates::entry_bin
-#endif
-constexpr int kTabBin8Off = 1792;  // [1792,3840) with ISSCABAC_ENC_BINADDR: 256 entries of 8 bytes by (q | bin)
-constexpr int kTabBytes = ISSCABAC_ENC_BINADDR ? 3840 : 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
+constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
                                  // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
                                  // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
                                  // by packed state, the state's row and its two successors (by bin / by path)
@@ -312,43 +284,15 @@ struct TileLine4 {
 typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
 // the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
 // both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
-#ifndef ISSCABAC_ENC_LPR_B
-#define ISSCABAC_ENC_LPR_B 4
-#endif
-#ifndef ISSCABAC_ENC_LPR_C
-#define ISSCABAC_ENC_LPR_C 4
-#endif
-#ifndef ISSCABAC_ENC_NT
-#define ISSCABAC_ENC_NT 0
-#endif
-#ifndef ISSCABAC_ENC_DEPTH2
-#define ISSCABAC_ENC_DEPTH2 0
-#endif
-#ifndef ISSCABAC_ENC_SPLIT_FETCH
-#define ISSCABAC_ENC_SPLIT_FETCH 0  // experiment: the ctx array's loads one chunk later than the bins array's (two bursts of four instead of one of eight)
-#endif
-constexpr bool kEncNT = ISSCABAC_ENC_NT != 0;  // encode kernel: streaming loads measured 4.13 ms against 3.02 -- the second 64-byte
-                                                // half of every 128-byte line is an L2 hit one round later only if the first allocated it
-#ifndef ISSCABAC_ENC_TILE_PAIR
-#define ISSCABAC_ENC_TILE_PAIR 0
-#endif
+constexpr bool kEncNT = false;  // encode kernel: plain loads (streaming ones measured 4.13 ms against 3.02 with 64-byte segments, 2.86
+                                // against 2.79 with whole lines: profiles/r06/ab_line.txt)
 // Round 6, same box, medians of 5 (profiles/r06/ab_line.txt): both arrays by whole lines k_encode 2.885 -> 2.790 ms and FETCH_SIZE
 // 8.56 -> 4.30 GB per launch (L2 <-> fabric traffic 17.9 -> 9.5 GB = 1.05 x the algorithmic bytes); either array alone 2.876 / 2.857;
 // with streaming (nt) loads on top 2.862.  125 VGPRs, no spill (TileT<8> for both: 128 + 2 spilled, 8 quarter-wave LDS stores per part).
-#ifndef ISSCABAC_ENC_LINE_B
-#define ISSCABAC_ENC_LINE_B 1  // the bins array by whole lines (TileLine4); 0: TileT<ISSCABAC_ENC_LPR_B>
-#endif
-#ifndef ISSCABAC_ENC_LINE_C
-#define ISSCABAC_ENC_LINE_C 1  // the ctx array by whole lines
-#endif
 // (more than 128 contexts -- CM 2, at most 2.5 waves per SIMD -- keep the 64-byte segments: 190 contexts 3.98 -> 4.19 ms, 253 contexts
 // 4.77 -> 4.95 ms with whole lines, 127 contexts 3.72 -> 3.63: profiles/r06/c_other_shapes.txt)
 template <int CM, bool PERM>
-using EncTileB = typename std::conditional<!PERM && CM != 2 && ISSCABAC_ENC_LINE_B, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_B>,
-                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_B>>::type>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
-template <int CM, bool PERM>
-using EncTileC = typename std::conditional<!PERM && CM != 2 && ISSCABAC_ENC_LINE_C, TileLine4, typename std::conditional<!PERM && ISSCABAC_ENC_TILE_PAIR, TilePairT<ISSCABAC_ENC_LPR_C>,
-                                           TileT<PERM ? 4 : ISSCABAC_ENC_LPR_C>>::type>::type;
+using EncTile = typename std::conditional<!PERM && CM != 2, TileLine4, TileT<4>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
@@ -459,10 +403,6 @@ struct BinOfWord {
 
 // enc_pick (cabac_lane.h) for the kernel's bins: t = the entry's high word shifted by the bin, its byte 2 the flag "the bin
 // is not the state's mps" (enc_entry_hi) -- one SDWA compare into VCC, two selects
-#ifndef ISSCABAC_ENC_PICK_VCC
-#define ISSCABAC_ENC_PICK_VCC 2  // 2: the mask form below (same-box A/B, medians of 6: k_encode 2.870 -> 2.847 ms); 1: compare + two selects
-#endif
-#if ISSCABAC_ENC_PICK_VCC == 2
 // the flag byte is 0x00 / 0xFF: sign-extended by the operand select it IS the mask -- one SDWA move, a bit select and a
 // full-rate and (4 + 4 + 2 issue cycles against 4 + 4 + 4 for compare + two selects; the and runs at twice the rate of
 // a select on gfx950: tools/ubench/valu_ops)
@@ -473,17 +413,6 @@ __device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_
   r = select_mask(m, lps, rmps);
   a = rmps & m;
 }
-#elif ISSCABAC_ENC_PICK_VCC
-template <int K>
-__device__ __forceinline__ void enc_pick(const BinOfWord<K> &, uint32_t, uint32_t t, uint32_t lps, uint32_t rmps, uint32_t &r, uint32_t &a) {
-  asm("v_cmp_ne_u32_sdwa vcc, %5, %2 src0_sel:DWORD src1_sel:BYTE_2\n\t"
-      "v_cndmask_b32_e32 %0, %4, %3, vcc\n\t"
-      "v_cndmask_b32_e32 %1, 0, %4, vcc"
-      : "=&v"(r), "=&v"(a)
-      : "v"(t), "v"(lps), "v"(rmps), "s"(0u)
-      : "vcc");
-}
-#endif
 
 // f(BinOfWord<k & 3>{w2, w1}) for a loop counter k that is a constant once the loop is unrolled
 template <class F>
@@ -501,12 +430,8 @@ __device__ __forceinline__ auto with_bin_of_word(int k, uint32_t w2, uint32_t w1
 // ------------------------------------------------------------------------------------------------
 // One byte per (stream, ctx) in LDS at (ctx / 4) * 256 + lane * 4 + ctx % 4: whatever contexts the 64 lanes
 // pick, lane l only ever touches bank l % 32.  The tables are byte tables in LDS, read by absolute LDS address.
-#ifndef ISSCABAC_DEC_TAB_REPL
-#define ISSCABAC_DEC_TAB_REPL 0  // k_decode: four bank-partitioned copies of the raw-byte entry table, picked by lane & 3
-#endif
 struct LdsStates {
   uint8_t *base;  // wave's state region + lane * 4
-  uint32_t rep = 0;  // ISSCABAC_DEC_TAB_REPL: (lane & 3) * 8 -- the lane's copy of the decoder's entry table
   __device__ __forceinline__ uint8_t *addr(uint32_t c) const { return base + (((c & ~3u) << 6) | (c & 3u)); }
   // four contexts of one input word at a time (cabac_lane.h: lds_ctx_quad); all four must be < 128
   __device__ __forceinline__ CtxQuad prep4(uint32_t cw) const { return lds_ctx_quad(cw); }
@@ -544,31 +469,10 @@ struct LdsStates {
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabRowOff + shl16c<2>(q)));
   }
-  // the plain step's entry by (state, bin): e = q | bin -> 8 bytes at kTabBin8Off + 8 e: the state's rangeTabLps row, the
-  // successor for this bin (byte 4, what the state store takes) and the flag "the bin is not the mps" as 0x00 / 0xFF in
-  // byte 5 -- read a second time SIGN-EXTENDED (ds_read_i8), which makes it the select mask without a VALU instruction
-  __device__ __forceinline__ uint64_t entry_bin(uint32_t e, uint32_t &m) const {
-    const uint32_t a = shl16c<3>(e);
-    m = (uint32_t)(int32_t)*reinterpret_cast<const __attribute__((address_space(3))) int8_t *>((uintptr_t)(kTabBin8Off + 5 + a));
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(kTabBin8Off + a));
-  }
   // the decoder's entries by RAW state byte (cabac_lane.h: dec_bin_out): 256 x 8 bytes at LDS 0 (kDecTabBytes)
   __device__ __forceinline__ uint64_t entry_raw(uint32_t qb) const {
-#if ISSCABAC_DEC_SPLIT_TAB
-    // two conflict-free reads -- either table is 256 bytes = one LDS bank row -- instead of one 8-byte read from 2 KiB:
-    // the rangeTabLps row by state at (qb & 0xFC), the successor pair by packed state at 256 + (qb & 0xFE)
-    const uint32_t row = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)(qb & 0xFCu));
-    const uint32_t sp = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>((uintptr_t)(256u + (qb & 0xFEu)));
-    return (uint64_t)row | (uint64_t)sp << 32;
-#else
 
-#if ISSCABAC_DEC_TAB_REPL
-    // entry qb of copy r at qb * 32 + r * 8: copy r only ever touches banks 2 r, 2 r + 1 (mod 8), a quarter of the 64
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)((qb << 5) + rep));
-#else
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(ISSCABAC_DEC_SHL16 ? shl16c<3>(qb) : qb << 3));
-#endif
-#endif
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint64_t *>((uintptr_t)(qb << 3));  // (the 16-bit shift of the encoder's address measured slower here: 2.879 vs 2.812 ms)
   }
   // byte 2 of p -> the state byte at LDS address a (ds_write_b8_d16_hi: no shift)
   __device__ __forceinline__ void store_at_hi(uint32_t a, uint32_t p) const {
@@ -584,9 +488,6 @@ struct LdsStates {
 // byte sink: 16 bytes staged per lane in LDS, then one 16-byte store into this stream's HBM slot
 // (4-byte stores cost a 32-byte HBM write each: WRITE_SIZE was 8x the payload)
 // ------------------------------------------------------------------------------------------------
-#ifndef ISSCABAC_ENC_NOSTORE  // timing experiment only
-#define ISSCABAC_ENC_NOSTORE 0
-#endif
 struct SlotSink {
   uint8_t *stage;   // LDS, this lane's 16 bytes
   uint8_t *slots;   // HBM, the wave's first slot (wave-uniform, 16-byte aligned)
@@ -598,7 +499,7 @@ struct SlotSink {
     pos++;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
     }
   }
   // two bytes, high byte first; pos is even whenever this is called (16-bit digits come before any single byte)
@@ -607,7 +508,7 @@ struct SlotSink {
     pos += 2;
     if ((pos & 15u) == 0) {
       const uint4 v = *reinterpret_cast<const uint4 *>(stage);
-      if (on && !(ISSCABAC_ENC_NOSTORE && v.x != 0x12345678u)) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
+      if (on) *reinterpret_cast<uint4 *>(slots + (mine + pos - 16u)) = v;
     }
   }
   __device__ __forceinline__ uint32_t bytes() const { return pos; }
@@ -647,11 +548,7 @@ struct DevMem {
     return r;
   }
   __device__ __forceinline__ void load16(uint32_t off, uint64_t &lo, uint64_t &hi) const {
-#if ISSCABAC_EXP_NOPAYLOAD  // (timing experiment: every lane reads the same few lines)
-    const uint64_t at = off & 0xFFCu;
-#else
     const uint64_t at = abase + off;
-#endif
     if ((int32_t)off <= lim) {  // off is far below 2^31 (a stream's payload is bounded by 6/8 of its <= 2^25 bins)
       const Q4 q = *reinterpret_cast<const Q4 *>(payload + at);
       lo = (uint64_t)q.w[0] | ((uint64_t)q.w[1] << 32);
@@ -678,31 +575,16 @@ struct DecArgs {
   uint32_t ctx_init[64];
 };
 
-#ifndef ISSCABAC_DEC_OCC
-#define ISSCABAC_DEC_OCC 4  // waves per SIMD the decode kernel is register-limited to (4 measured 6% faster than 3)
-#endif
-#ifndef ISSCABAC_DEC_NT
-#define ISSCABAC_DEC_NT 1
-#endif
-#ifndef ISSCABAC_DEC_NOSTORE
-#define ISSCABAC_DEC_NOSTORE 0
-#endif
-#ifndef ISSCABAC_DEC_NT_ST
-#define ISSCABAC_DEC_NT_ST ISSCABAC_DEC_NT
-#endif
-constexpr bool kDecNT = ISSCABAC_DEC_NT != 0;  // decode kernel: ctx loads are streaming
-constexpr bool kDecNTst = ISSCABAC_DEC_NT_ST != 0;  // ... and the bin stores
+constexpr bool kDecNT = true;  // decode kernel: ctx loads are streaming
+constexpr bool kDecNTst = true;  // ... and the bin stores
 
 // LDS of the decode kernel: the raw-byte entries (256 x 8 bytes, cabac_lane.h: dec_bin_out) at 0, then per wave the
 // context states, the round tile and (bucketed launches) the wave's stream ids
-constexpr int kDecTabBytes = ISSCABAC_DEC_TAB_REPL ? 8192 : 2048;
+constexpr int kDecTabBytes = 2048;
 
 // the digit flush of the encode kernels: digits leave `low` when some lane could overflow it within the next four bins
 #ifndef ISSCABAC_FLUSH_AT
 #define ISSCABAC_FLUSH_AT 39  // four more bins add at most 22 (context) bits: W stays <= 62
-#endif
-#ifndef ISSCABAC_FLUSH_FN
-#define ISSCABAC_FLUSH_FN enc_flush16_wave  // or enc_flush16: the general loop only
 #endif
 
 // cabac_pair.hip: the encode kernel of small launches (<= 64 contexts, no length bucketing)
