@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * enc_waves_per_block(CM) + wib) * 64;
+  const uint32_t wpb = CM == 1 ? (uint32_t)enc_waves_per_block(1) : (blockDim.x >> 6);  // (> 64 contexts: chosen at launch, waves_per_block_for)
+  const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
   using WL = WaveLds<CM, PERM>;
@@ -419,7 +420,8 @@ __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
     tab[2 * qb + 1] = qb >= (int)kDecBypassRaw ? kDecBypassHi : dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
   }
   __syncthreads();
-  const uint64_t s0 = ((uint64_t)blockIdx.x * dec_waves_per_block(CM) + wib) * 64;
+  const uint32_t wpb = CM == 1 ? (uint32_t)dec_waves_per_block(1) : (blockDim.x >> 6);
+  const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
   using DL = DecLds<CM, PERM>;
@@ -1058,18 +1060,35 @@ uint64_t slot_stride_for(uint32_t nbins) {
   return (bound + 16 + 15) & ~15ull;  // the sink writes whole 16-byte pieces
 }
 
+// Waves per workgroup of the instances with more than 64 contexts: a workgroup's waves share one copy of the tables, and a CU's
+// 160 KiB of LDS hold floor(160 KiB / (tables + w x wave)) workgroups of w waves -- the w (1..4) that leaves the most waves on a CU,
+// the smallest such w.  127 contexts: encoder 10 waves either way, decoder 11 -> 12 (w = 2); 190 contexts: 8 -> 9 (w = 3) both ways.
+static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes) {
+  constexpr size_t kCuLds = 160 * 1024;
+  int best = 1;
+  size_t best_waves = 0;
+  for (int w = 1; w <= 4; w++) {
+    const size_t waves = kCuLds / (tab_bytes + w * wave_bytes) * w;
+    if (waves > best_waves) {
+      best_waves = waves;
+      best = w;
+    }
+  }
+  return best;
+}
 template <int CM, bool PERM>
-static size_t coder_lds_bytes(uint32_t img_bytes) {
-  return kTabBytes + enc_waves_per_block(CM) * (WaveLds<CM, PERM>::BYTES - WaveLds<CM, PERM>::SB + (CM == 2 ? img_bytes : WaveLds<CM, PERM>::SB));
+static size_t enc_wave_lds_bytes(uint32_t img_bytes) {
+  return WaveLds<CM, PERM>::BYTES - WaveLds<CM, PERM>::SB + (CM == 2 ? img_bytes : WaveLds<CM, PERM>::SB);
 }
 // CM 2: a wave's state image covers the batch's contexts in whole groups of four (a.nctx > 128 there)
 static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u); }
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  const size_t lds = coder_lds_bytes<CM, PERM>(a.img_bytes);
+  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes));
+  const size_t lds = kTabBytes + wpb * enc_wave_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)coder_lds_bytes<CM, PERM>(16384));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTabBytes + 4 * enc_wave_lds_bytes<CM, PERM>(16384)));
   if (err != hipSuccess) return err;
   // LdsStates<.., NEXT16> addresses its table by absolute LDS address: the dynamic LDS must start at 0
   static int static_lds = -1;
@@ -1080,16 +1099,17 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * enc_waves_per_block(CM) - 1) / (64 * enc_waves_per_block(CM));
-  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * enc_waves_per_block(CM)), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
+  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, a);
   return hipGetLastError();
 }
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   using DL = DecLds<CM, PERM>;
-  const size_t lds_max = kDecTabBytes + dec_waves_per_block(CM) * DL::BYTES;
-  const size_t lds = CM == 2 ? lds_max - DL::SB + a.img_bytes : lds_max;
+  const size_t wave_bytes = CM == 2 ? DL::BYTES - DL::SB + a.img_bytes : DL::BYTES;
+  const int wpb = CM == 1 ? dec_waves_per_block(1) : waves_per_block_for(kDecTabBytes, wave_bytes);
+  const size_t lds_max = kDecTabBytes + 4 * DL::BYTES, lds = kDecTabBytes + wpb * wave_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
   if (err != hipSuccess) return err;
@@ -1101,8 +1121,8 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
     static_lds = (int)fa.sharedSizeBytes;
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
-  const uint64_t nblk = (a.S + 64 * dec_waves_per_block(CM) - 1) / (64 * dec_waves_per_block(CM));
-  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * dec_waves_per_block(CM)), lds, stream, a);
+  const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
+  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, a);
   return hipGetLastError();
 }
 

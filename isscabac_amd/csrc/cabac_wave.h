@@ -63,8 +63,8 @@ __device__ __forceinline__ bool is_ctx_byte(uint32_t c, uint32_t lim) { return C
 template <int CM>
 __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 && is_prob_byte(c); }
 
-// waves per workgroup: 4, except with more than 64 contexts (8 or 16 KiB of states per wave): single-wave workgroups then
-// let 11 (<= 128 contexts) or 7 waves share a CU's LDS instead of 8 or 4
+// waves per workgroup of the <= 64-context instances: 4.  With more than 64 contexts (8 .. 16 KiB of states per wave) the launcher
+// picks 1 .. 4 by what fills a CU's LDS best (cabac_kernels.hip: waves_per_block_for)
 #ifndef ISSCABAC_ENC_WPB
 #define ISSCABAC_ENC_WPB 4
 #endif
@@ -81,7 +81,6 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 #ifndef ISSCABAC_ENC_PRIO
 #define ISSCABAC_ENC_PRIO 1
 #endif
-// waves per workgroup of the <= 64-context instances (the bigger state images run single-wave workgroups)
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
 constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
