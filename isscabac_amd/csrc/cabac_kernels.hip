@@ -19,7 +19,7 @@
 //     size with 16-byte stores; a scan over the lengths and
 //     a gather kernel then produce the tight payload + offsets (the reference's one-file-per-stream
 //     content, concatenated).
-//   * the decoder fetches its payload bytes 16 at a time, one chunk ahead of use (WindowSrc), and tops
+//   * the decoder fetches its payload in aligned 16-byte pieces, each byte once, 8 bytes or more ahead of use (PieceSrc), and tops
 //     its value register up bit-granularly once per four bins.
 //   * per-lane global addresses are a wave-uniform base (SGPRs) plus a 32-bit lane offset.
 //
@@ -182,7 +182,9 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
-  const uint32_t wpb = CM == 1 ? (uint32_t)enc_waves_per_block(1) : (blockDim.x >> 6);  // (> 64 contexts: chosen at launch, waves_per_block_for)
+  const uint32_t wpb = CM == 1 ? (uint32_t)enc_waves_per_block(1) : a.wpb;  // (> 64 contexts: chosen at launch, waves_per_block_for; a kernel
+                                                                            // argument: derived from blockDim.x the compiler took the wave's first stream -- and every
+                                                                            // address built on it -- for a per-lane value)
   const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
     tab[2 * qb + 1] = qb >= (int)kDecBypassRaw ? kDecBypassHi : dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
   }
   __syncthreads();
-  const uint32_t wpb = CM == 1 ? (uint32_t)dec_waves_per_block(1) : (blockDim.x >> 6);
+  const uint32_t wpb = CM == 1 ? (uint32_t)dec_waves_per_block(1) : a.wpb;
   const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
@@ -463,9 +465,16 @@ __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
   // payload window
   uint64_t start = a.offsets[s];
   const uint32_t len = clip_stream(start, a.offsets[s + 1], a.payload_bytes);
-  const uint64_t abase = start & ~3ull;
+  // Throughput instances: aligned, non-overlapping 16-byte pieces (PieceSrc: every payload byte requested once -- FETCH_SIZE of
+  // k_decode 6.45 -> 3.52 GB per config-3 launch, 2.796 -> 2.783 ms; a piece never straddles two 128-byte lines).  The latency-oriented
+  // instances keep the window's own piece (WindowSrc: fewer instructions at the chunk boundary -- 0.516 against 0.528 ms at 128 Ki
+  // streams, where the payload lines stay in the L2 anyway); profiles/r06/f_ab_pieces.txt
+  constexpr bool kPieces = CM == 1 && !LAT;  // (the instances of more than 64 contexts keep WindowSrc too: they are not the ones whose
+                                             // traffic matters, and at their 128 registers PieceSrc's seam code spills)
+  constexpr uint64_t kPieceAlign = kPieces ? 16 : 4;
+  const uint64_t abase = start & ~(kPieceAlign - 1);
   const uint32_t skew = (uint32_t)(start - abase);
-  WindowSrc<DevMem> src;
+  typename std::conditional<kPieces, PieceSrc<DevMem>, WindowSrc<DevMem>>::type src;
   src.mem.payload = a.payload;
   src.mem.total = a.payload_bytes;
   src.mem.abase = abase;
@@ -737,7 +746,7 @@ __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
   if (valid && a.status) {
     uint64_t first = a.offsets[s];  // re-read: keeping it live through the loop costs two registers
     (void)clip_stream(first, first, a.payload_bytes);
-    const uint32_t sk = (uint32_t)first & 3u;
+    const uint32_t sk = (uint32_t)first & (uint32_t)(kPieceAlign - 1);
     const uint8_t *p = a.payload + first;
     dec_from_abs(d, da);
     a.status[s] = dec_finish(d, src.bpos - 8u * sk, src.len - sk, [p](uint32_t i) { return (uint32_t)p[i]; });
@@ -1100,7 +1109,9 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
-  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, a);
+  EncArgs aw = a;
+  aw.wpb = (uint32_t)wpb;
+  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, aw);
   return hipGetLastError();
 }
 
@@ -1122,7 +1133,9 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
-  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, a);
+  DecArgs aw = a;
+  aw.wpb = (uint32_t)wpb;
+  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, aw);
   return hipGetLastError();
 }
 

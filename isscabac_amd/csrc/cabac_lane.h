@@ -1575,5 +1575,94 @@ struct WindowSrc {
   CABAC_HD uint32_t next() { return feed(0u, 8u); }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The same bit source on ALIGNED, NON-OVERLAPPING pieces (k_decode; round 6).  WindowSrc asks for a new piece at the window's own
+// position as soon as four bytes of the piece in use are consumed: consecutive pieces overlap by up to 12 of their 16 bytes, a lane
+// sends ~64 requests for its ~410 payload bytes -- 7 us apart, so nearly every one fills its 128-byte line anew: 8.6 GB of L2 fills
+// for 0.43 GB of payload (profiles/r06/e_ab_memory_side.txt: without them k_decode is 5.4 % faster).  Here piece k is bytes
+// [16 k, 16 k + 16) of the stream's buffer (Mem's base) and every byte is requested ONCE (~27 requests per lane).  The window
+// steps over the payload in 8-byte words: w0, w1 = the two words the next 64 bits lie in (big-endian, EOF fill applied), the window
+// always starts inside w0; when it has left w0, w1 moves down and the next word comes out of piece N -- its low half, then its high
+// half, then N is requested anew (16 bytes further on), at least 8 bytes of consumption before its first word is needed.
+// Same registers as WindowSrc (4 + 4), same interface.  pbit = bit position of w0's first bit (a multiple of 64): bit 6 of it says
+// which half of N comes next.
+// ------------------------------------------------------------------------------------------------
+template <class Mem>
+struct PieceSrc {
+  Mem mem;
+  uint32_t len;   // payload bytes of this stream; bytes at or past len read as 0xFF (fstream EOF)
+  uint32_t bpos;  // bit position of the next unread bit
+  uint64_t cur;   // the next bits, MSB first
+  uint32_t cend;  // bit position just past the last bit cur holds
+  uint64_t w0, w1;   // payload bits [pbit, pbit + 128)
+  uint32_t pbit;
+  uint64_t nlo, nhi; // piece N as loaded (little endian): the 16 bytes that hold the word behind w1; its load may be in flight
+
+  CABAC_HD uint32_t byte_pos() const { return bpos >> 3; }
+  CABAC_HD int32_t avail_bits() const { return (int32_t)(cend - bpos); }
+  static CABAC_HD uint64_t ff_after(uint32_t k) { return k == 0 ? ~0ull : (k >= 8 ? 0ull : (~0ull >> (8u * k))); }
+  // the 8 bytes at `at` as a big-endian number, bytes at or past len replaced by 0xFF
+  CABAC_HD uint64_t filled(uint64_t be, uint32_t at) const {
+    if (CABAC_WAVE_ANY(at + 8u > len)) be |= ff_after(len > at ? len - at : 0u);  // only near the stream's end
+    return be;
+  }
+  // (re)start at byte `at`: w0, w1 = the aligned 16 bytes `at` lies in (fetched now: blocking), N = the 16 behind them
+  CABAC_HD_RARE void restart(uint32_t at) {
+    const uint32_t p0 = at & ~15u;
+    uint64_t a, b;
+    mem.load16(p0, a, b);
+    w0 = filled(__builtin_bswap64(a), p0);
+    w1 = filled(__builtin_bswap64(b), p0 + 8u);
+    pbit = 8u * p0;
+    mem.load16(p0 + 16u, nlo, nhi);
+  }
+  CABAC_HD void start(uint32_t first_byte) {
+    bpos = 8u * first_byte;
+    cend = bpos;
+    cur = 0;
+    restart(first_byte);
+  }
+  // the window has left w0: w1 moves down, the next word comes out of N (waits for N's load when its low half is taken)
+  CABAC_HD void step_word() {
+    const bool low = (pbit & 64u) == 0;      // w0, w1 are an aligned pair: the next word is N's low half
+    const uint32_t at = (pbit >> 3) + 16u;    // its first byte
+    w0 = w1;
+    w1 = filled(__builtin_bswap64(low ? nlo : nhi), at);
+    pbit += 64u;
+    if (!low) mem.load16(at + 8u, nlo, nhi);  // N is used up: the 16 bytes behind it
+  }
+  // cur = 64 bits from bpos on.  The window started inside w0 when it was last re-based and holds 64 bits, so it starts inside w0 or
+  // w1 now (bpos - pbit < 128): at most one step
+  CABAC_HD void rebase() {
+    uint32_t b = bpos - pbit;
+    if (CABAC_WAVE_ANY(b >= 64u)) {
+      if (b >= 64u) {
+        step_word();
+        b -= 64u;
+      }
+    }
+    cur = (w0 << b) | ((w1 >> 1) >> (63u - b));
+    cend = bpos + 64u;
+  }
+  CABAC_HD void ensure(int32_t n) {  // wave-uniform: re-base when some lane's window holds fewer than n bits
+    if (CABAC_WAVE_ANY_LT(avail_bits(), n)) {
+      CABAC_RARE_BODY();
+      if (avail_bits() < n) rebase();
+    }
+  }
+  CABAC_HD void boundary() { rebase(); }  // every 16 bins
+  CABAC_HD uint32_t feed_nocheck(uint32_t v, uint32_t g) {
+    const uint64_t pair = ((uint64_t)v << 32) | (cur >> 32);
+    cur <<= g;
+    bpos += g;
+    return (uint32_t)((pair << g) >> 32);
+  }
+  CABAC_HD uint32_t feed(uint32_t v, uint32_t g) {
+    if ((int32_t)g > avail_bits()) rebase();
+    return feed_nocheck(v, g);
+  }
+  CABAC_HD uint32_t next() { return feed(0u, 8u); }
+};
+
 }  // namespace isscabac
 #endif

@@ -525,6 +525,7 @@ struct EncArgs {
   uint64_t S, slot_stride;
   uint32_t nbins, pitch, nctx;
   uint32_t img_bytes;  // CM 2: bytes of a wave's state image, 256 per four contexts
+  uint32_t wpb;        // waves per workgroup of this launch (set by the launcher)
   uint32_t ctx_init[64];
 };
 
@@ -571,6 +572,7 @@ struct DecArgs {
   uint64_t S, payload_bytes;
   uint32_t nbins, pitch, nctx;
   uint32_t img_bytes;  // as in EncArgs
+  uint32_t wpb;        // as in EncArgs
   uint32_t ctx_init[64];
 };
 

@@ -461,18 +461,22 @@ uint32_t lane_decode_stream(const uint8_t *buf, uint64_t total, uint64_t start, 
 // general (anything else: per-bin branches, the fourth bin of a word guarded) --, state bytes with the stale bin in bit 0,
 // output bytes masked with 1 at the end like store_out.  lat: the latency-oriented instance's order (state one bin ahead,
 // successor forwarded for a repeated context).  Returns the status word, or 0xDEADxxxx if an unguarded bin ran short.
-uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx,
-                                uint32_t n, const uint8_t *ctx_init, int nctx, int lat, uint8_t *bins_out,
-                                uint8_t *ctx_final, uint32_t *path_counts /* [plain, mixed, general] chunks */) {
+}  // extern "C"
+// Src: the payload source -- PieceSrc on 16-byte aligned pieces (k_decode) or WindowSrc on 4-byte aligned ones (the pair, wide
+// and symbol kernels)
+template <class Src, uint32_t ALIGN>
+static uint32_t decode_stream_out_t(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx,
+                                    uint32_t n, const uint8_t *ctx_init, int nctx, int lat, uint8_t *bins_out,
+                                    uint8_t *ctx_final, uint32_t *path_counts /* [plain, mixed, general] chunks */) {
   const int cm = nctx <= 64 ? 1 : nctx <= 128 ? 3 : 2;
   const uint32_t lim = std::min(4u * (((uint32_t)nctx + 3u) / 4u), 255u);  // cm 2: contexts of the state image (k_decode: ctx_lim)
   auto is_ctx = [&](uint32_t c) { return cm == 1 ? c < 64u : cm == 3 ? c < 128u : c < lim; };
   auto is_prob = [&](uint32_t c) { return cm != 2 && is_prob_byte(c); };
   HostStates st;
   st.init(ctx_init, nctx);
-  const uint64_t abase = start & ~3ull;
+  const uint64_t abase = start & ~(uint64_t)(ALIGN - 1u);
   const uint32_t skew = (uint32_t)(start - abase);
-  WindowSrc<HostMem> src;
+  Src src;
   src.mem = HostMem{buf + abase, total - abase, nullptr, nullptr};
   src.len = skew + len;
   src.start(skew);
@@ -606,6 +610,13 @@ uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t sta
   const uint32_t status = dec_finish(d, src.bpos - 8u * skew, len, [p](uint32_t i) { return (uint32_t)p[i]; });
   if (ctx_final) st.final_packed(ctx_final, nctx);
   return status;
+}
+extern "C" {
+uint32_t lane_decode_stream_out(const uint8_t *buf, uint64_t total, uint64_t start, uint32_t len, const uint8_t *ctx, uint32_t n,
+                                const uint8_t *ctx_init, int nctx, int lat, uint8_t *bins_out, uint8_t *ctx_final, uint32_t *path_counts) {
+  // bit 1 of lat: the previous source (WindowSrc); default: k_decode's PieceSrc
+  if (lat & 2) return decode_stream_out_t<WindowSrc<HostMem>, 4u>(buf, total, start, len, ctx, n, ctx_init, nctx, lat & 1, bins_out, ctx_final, path_counts);
+  return decode_stream_out_t<PieceSrc<HostMem>, 16u>(buf, total, start, len, ctx, n, ctx_init, nctx, lat & 1, bins_out, ctx_final, path_counts);
 }
 
 // one stream through the reference-formulation decoder (RefDec): what the engine uses for streams starting with 0xFF

@@ -112,7 +112,10 @@ def test_decode_golden(lane, golden, pads):
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
 
 
-@pytest.mark.parametrize("pads", [(0, 0, 0), (3, 0, 1), (1, 40, 0), (2, 5, 1), (7, 3, 0)])
+# lat: bit 0 = the latency-oriented order; bit 1 = the payload source -- 0: PieceSrc (k_decode: aligned 16-byte pieces, every byte
+# requested once), 2: WindowSrc (the pair / wide / symbol kernels: a piece at the window's own position)
+@pytest.mark.parametrize("pads", [(0, 0, 0), (3, 0, 1), (1, 40, 0), (2, 5, 1), (7, 3, 0), (15, 1, 0), (16, 0, 1), (9, 33, 0),
+                                  (0, 0, 2), (3, 0, 3), (1, 40, 2), (2, 5, 3), (7, 3, 2)])
 def test_decode_out_golden(lane, golden, pads):
     """the kernel's chunk structure with the bin riding in bit 0 of the state byte (dec_bin_out / _nx / _mixed_nx)"""
     for s in golden["streams"]:
@@ -152,8 +155,8 @@ def test_decode_out_fuzz_and_corrupt(lane, oracle):
             skew = rng.random(256) ** (1 + it % 4)
             bins = (rng.random(n) < skew[ctx]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        for lat in (0, 1):
-            dec, st, dfin, cnt = lane_decode_out(lane, want, ctx, init, lat=lat, pad_front=int(rng.integers(0, 9)),
+        for lat in (0, 1, 2, 3):
+            dec, st, dfin, cnt = lane_decode_out(lane, want, ctx, init, lat=lat, pad_front=int(rng.integers(0, 33)),
                                                  pad_back=int(rng.integers(0, 20)))
             assert st == 0 and (dec == bins).all() and dfin.tobytes() == want_fin.tobytes(), (it, lat, hex(st))
         paths += cnt
@@ -169,10 +172,11 @@ def test_decode_out_fuzz_and_corrupt(lane, oracle):
             if bad[0] == 0xFF:
                 continue  # the engine sends these to the reference-formulation decoder (RefDec)
             wdec, wst = oracle.decode_stream(bad, ctx, init)
-            got, st, _, _ = lane_decode_out(lane, bad, ctx, init, lat=it % 2, pad_front=2, pad_back=int(rng.integers(0, 30)))
-            assert st == wst and (got == wdec).all(), (it, hex(st), hex(wst))
+            for src in (0, 2):
+                got, st, _, _ = lane_decode_out(lane, bad, ctx, init, lat=it % 2 + src, pad_front=int(rng.integers(0, 20)), pad_back=int(rng.integers(0, 30)))
+                assert st == wst and (got == wdec).all(), (it, src, hex(st), hex(wst))
             flagged += st != 0
-    assert (paths > 50).all(), paths  # plain, mixed and general chunks were all exercised
+    assert (paths > 100).all(), paths  # plain, mixed and general chunks were all exercised
     assert flagged > 50
 
 
