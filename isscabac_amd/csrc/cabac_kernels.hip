@@ -1071,7 +1071,7 @@ uint64_t slot_stride_for(uint32_t nbins) {
 
 // Waves per workgroup of the instances with more than 64 contexts: a workgroup's waves share one copy of the tables, and a CU's
 // 160 KiB of LDS hold floor(160 KiB / (tables + w x wave)) workgroups of w waves -- the w (1..4) that leaves the most waves on a CU,
-// the smallest such w.  127 contexts: encoder 10 waves either way, decoder 11 -> 12 (w = 2); 190 contexts: 8 -> 9 (w = 3) both ways.
+// the smallest such w.  Decoder: 127 contexts 11 -> 12 waves (w = 2), 190 contexts 8 -> 9 (w = 3).
 static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes) {
   constexpr size_t kCuLds = 160 * 1024;
   int best = 1;
@@ -1094,7 +1094,9 @@ static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes));
+  // (the encoder keeps single-wave workgroups with more than 64 contexts: 190 contexts 3.98 ms so, 4.74 ms with the three-wave
+  // workgroups that would put a ninth wave on a CU -- profiles/r06/g_ctx_rates.txt; the decoder gains 5-6 % from its twelfth / ninth)
+  const int wpb = enc_waves_per_block(CM);
   const size_t lds = kTabBytes + wpb * enc_wave_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTabBytes + 4 * enc_wave_lds_bytes<CM, PERM>(16384)));
