@@ -1125,3 +1125,37 @@ def test_whole_matrix_stream_walked_in_parallel_equals_the_fused_kernel(engine, 
         assert p1.tobytes() == want.tobytes() and int(nb1[0]) == wnb
     dec, st = engine.decode_symbols(p1, o1, n, mp, init)
     assert st[0] == 0 and (dec[0, :n] == sym[0]).all()
+
+
+def test_decoder_payload_pieces_at_every_buffer_alignment_and_with_no_slack(engine, oracle):
+    """k_decode's throughput instance requests its payload in pieces aligned to 16 bytes of the buffer it is given (PieceSrc), the other
+    instances at the window's own 4-byte position (WindowSrc).  The payload pointer only has to be 4-byte aligned, and payload_bytes
+    may be the exact size: decode from a device buffer at +0 / +4 / +8 / +12 bytes with not one byte behind the last stream -- the
+    pieces of the last streams reach past the buffer's end and must come through the bounded tail path -- intact and with the last
+    stream truncated (status and bins = oracle)."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(616)
+    S, B, C = 700, 336, 40
+    ctx = rng.integers(0, C, (S, B)).astype(np.uint8)
+    ctx[rng.random((S, B)) < 0.1] = 0xFF
+    bins = (rng.random((S, B)) < 0.3).astype(np.uint8)
+    init = rng.integers(0, 126, C).astype(np.uint8)
+    payload, offsets = oracle.encode_batch(bins, ctx, init)
+    tctx = torch.from_numpy(ctx).to(dev)
+    toff = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    for shift in (0, 4, 8, 12):
+        for cut in (0, 3):  # cut: the buffer ends `cut` bytes inside the last stream
+            n = payload.size - cut
+            buf = torch.zeros(shift + n, dtype=torch.uint8, device=dev)
+            buf[shift:] = torch.from_numpy(payload[:n]).to(dev)
+            out = torch.full((S, B), 7, dtype=torch.uint8, device=dev)
+            status = torch.full((S,), 9, dtype=torch.int32, device=dev)
+            engine.decode_dev(buf.data_ptr() + shift, n, toff.data_ptr(), tctx.data_ptr(), S, B, B, init, out.data_ptr(), status.data_ptr())
+            got, st = out.cpu().numpy(), status.cpu().numpy().astype(np.uint32)
+            if cut == 0:
+                assert not st.any() and (got == bins).all(), shift
+            else:
+                want_last, want_st = oracle.decode_stream(payload[int(offsets[S - 1]):n], ctx[S - 1], init)
+                assert not st[:S - 1].any() and (got[:S - 1] == bins[:S - 1]).all(), shift
+                assert st[S - 1] == want_st and (got[S - 1] == want_last).all(), (shift, hex(int(st[S - 1])), hex(want_st))

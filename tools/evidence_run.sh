@@ -1,8 +1,8 @@
 # usage (GPU box, repo root): bash tools/evidence_run.sh <outdir>
 # bench line, rocprof kernel stats, PMC passes, the stream-count sweep and the other-shape rates of the current build into
-# <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r05
+# <outdir> (under gpurun_out/); then, back in the build container: python tools/refresh_profiles.py <outdir> r06
 set -u
-O=${1:-gpurun_out/r05z}; mkdir -p $O
+O=${1:-gpurun_out/r06z}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-verify > $O/stats.log 2>&1
 PMC_MEM=1 bash tools/pmc_case.sh $O/pmc_config3 > /dev/null 2>&1
