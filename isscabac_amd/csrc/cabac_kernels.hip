@@ -151,9 +151,14 @@ struct WaveLds {
   static constexpr uint32_t TILE = Tile::H * 64;
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
-  // one more row of the state image, behind its last context group: the "context" bypass bins read and write in the mixed
-  // step (a byte nobody else looks at).  Not with 255 contexts: there the mixed step does not run and the row would cost a wave per CU
+  // the "context" bypass bins read and write in the mixed step (a byte nobody else looks at).  <= 64 contexts (MIXED3): group 31 of the
+  // wave's region -- where a bypass byte's state address lands under the step's 5-bit group mask (enc_bin_mixed3_acc) --, which is a
+  // hole in the ctx tile (TileT<.., HOLE>: its rows 56..63 sit behind it).  <= 128 contexts: one more row behind the image's last
+  // context group.  Not with 255 contexts: there the mixed step does not run and the row would cost a wave per CU
+  static constexpr bool MIXED3 = CM == 1;
   static constexpr uint32_t DUMMY = CM != 2 ? 256u : 0u;
+  static constexpr uint32_t DUMMY_OFF = 31 * 256;
+  static_assert(!MIXED3 || SB + TILE + 56 * 32 == DUMMY_OFF, "the dummy row is the hole of the ctx tile");
   static constexpr uint32_t BYTES = SB + DUMMY + 2 * TILE + STAGE + IDS;
 };
 
@@ -179,7 +184,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     const uint32_t sb = c_next.eb[ps >> 1] >> (16 * (ps & 1));
     // state 63 is no context's state: its entries are the all-zero ones bypass lanes look up (enc_bin_mixed_acc)
     tab[kTabRowOff / 4 + 2 * ps] = ps >= 126 ? 0u : c_lps_rows[ps >> 1];
-    tab[kTabRowOff / 4 + 2 * ps + 1] = ps >= 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
+    // ... and packed state 127 (the byte 0xFE) is the bypass entry of the step on a dummy context that holds it (enc_bin_mixed3_acc)
+    tab[kTabRowOff / 4 + 2 * ps + 1] = ps == 127 ? kEncBypassHi : ps == 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
   __syncthreads();
   const uint32_t wpb = CM == 1 ? (uint32_t)enc_waves_per_block(1) : a.wpb;  // (> 64 contexts: chosen at launch, waves_per_block_for; a kernel
@@ -192,13 +198,14 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   const uint32_t sbytes = CM == 2 ? a.img_bytes : WL::SB;  // the wave's state image
   const uint32_t ctx_lim = min(sbytes >> 6, 255u), ctx_kadd = (256u - ctx_lim) * 0x01010101u;
   uint8_t *wbase = smem + kTabBytes + wib * (WL::BYTES - WL::SB + sbytes);
-  uint8_t *tile_b = wbase + sbytes + WL::DUMMY, *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE;
+  // (MIXED3: states | bins tile | ctx tile with the dummy row in its hole | staging; else: states | dummy row | tiles | staging)
+  uint8_t *tile_b = wbase + sbytes + (WL::MIXED3 ? 0u : WL::DUMMY), *tile_c = tile_b + WL::TILE, *stage = tile_c + WL::TILE + (WL::MIXED3 ? WL::DUMMY : 0u);
 
   const bool valid = s0 + lane < a.S;
   const uint64_t slot = valid ? s0 + lane : a.S - 1;       // position in the launch
   const uint64_t s = PERM ? a.order[slot] : slot;           // the stream coded here
-  using BTile = EncTile<CM, PERM>;  // the tile of both input arrays, bins and ctx
-  using CTile = BTile;
+  using BTile = EncTile<CM, PERM>;  // the tiles of the two input arrays, bins and ctx: the same load rounds
+  using CTile = EncTile<CM, PERM, WL::MIXED3>;
   uint32_t ridb[BTile::NLD] = {}, ridc[CTile::NLD] = {};
   if (PERM) {  // the ids of the rows this lane fetches pieces of, through LDS
     uint32_t *wids = reinterpret_cast<uint32_t *>(stage + WL::STAGE);
@@ -223,7 +230,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     // and overruns the slot bound of 6
     const uint32_t ngrp = sbytes / 256;
     for (uint32_t g = 0; g < ngrp; g++) st32[g * 64] = (a.ctx_init[g] & 0x7F7F7F7Fu) << 1;
-    if (WL::DUMMY) st32[ngrp * 64] = 0;  // the bypass bins' dummy context: always an even byte (it only ever receives the all-zero entry's successor, 0)
+    if (WL::MIXED3) st32[WL::DUMMY_OFF / 4] = 0xFEFEFEFEu;  // the bypass bins' dummy context holds the bypass state, and keeps it
+    else if (WL::DUMMY) st32[ngrp * 64] = 0;  // ... an even byte, made the bypass state by what the step ORs into it
   }
   LdsStates stx{wbase + lane * 4};
 
@@ -326,7 +334,24 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             // digit ready (W >= 29) emits it (8-bin cadence measured 3% slower, 2-bin guard with W >= 51 slower still)
             if ((k & 3) == 3 && wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
           }
-        } else if (CM != 2 && full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
+        } else if (WL::MIXED3 && full &&
+                   !wave_any((not_ctx64_nor_bypass(wc.x) | not_ctx64_nor_bypass(wc.y) | not_ctx64_nor_bypass(wc.z) | not_ctx64_nor_bypass(wc.w)) != 0)) {
+          // contexts below 64 and bypass bins only (config 5's chunks): the step on a dummy context that holds the bypass state
+          // (enc_bin_mixed3_acc) -- under the 5-bit group mask a bypass byte's state address is the dummy row
+          EncWordAcc acc;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const uint32_t cw = word_of(wc, k >> 2);
+            const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
+            const uint32_t cwm = (cw >> 7) & 0x01010101u, wbm = w1 & cwm;  // per word: the bypass bits as bytes of 0 / 1, the bypass bins of value 1
+            const CtxQuad z = stx.prep4(cw & 0x7F7F7F7Fu);
+            with_bin_of_word(k, w2, w1, [&](auto bin) { enc_bin_mixed3_acc(e, acc, (k & 3) == 0, bin, cwm, wbm, stx.addr_of(z, k & 3), stx); return 0; });
+            if ((k & 3) == 3) {
+              enc_word_close(e, acc);
+              if (wave_any(e.W >= ISSCABAC_FLUSH_AT)) enc_flush16_wave(e, sink);
+            }
+          }
+        } else if (CM == 3 && full && !wave_any((odd_high_bytes(wc.x) | odd_high_bytes(wc.y) | odd_high_bytes(wc.z) | odd_high_bytes(wc.w)) != 0)) {
           // context-coded and bypass bins only (config 5's chunks): one select-based step per bin for every lane, no lane
           // branches, `low` touched once per word (enc_bin_mixed_acc).  Bit 7 of a ctx byte says "bypass" here -- batches
           // of more than 128 contexts never come this way --, and the state address of a bypass lane is made valid by
@@ -339,7 +364,7 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             const uint32_t w1 = word_of(wb, k >> 2), w2 = w1 << 1;
             // per word: the bypass bits as bytes of 0 / 1, of 0 / 0xFE (or-ed into the state: 0xFE is the all-zero table entry),
             // and the bypass bins of value 1; a bypass bin's state address is the dummy context behind the image
-            constexpr uint32_t kDummy = (CM == 1 ? 64u : 128u) * 0x01010101u;
+            constexpr uint32_t kDummy = 128u * 0x01010101u;
             const uint32_t cwm = (cw >> 7) & 0x01010101u, mbfe = cwm * 0xFEu;
             const CtxQuad z = stx.prep4(select_mask(mbfe | cwm, kDummy, cw & kIn));
             const uint32_t wbm = w1 & cwm;

@@ -426,6 +426,29 @@ CABAC_HD void enc_bin_mixed2_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin,
   e.range = shl16(r, n);
 }
 
+// The mixed step with the dummy context HOLDING the bypass state (round 6; batches of <= 64 contexts): the dummy's byte is 0xFE
+// (packed state 127 = state 63, no context's state) and the table's entry for it has an all-zero row and 0xFE as both successors,
+// so a bypass bin needs nothing OR-ed into what it read -- it reads 0xFE, finds LPS 0 and "the bin is the mps", and writes 0xFE
+// back -- and, as in the decoder (dec_bin_mixed2_nx_abs), its state address is the dummy row by itself under a 5-bit group mask.
+// What is left of enc_bin_mixed2_acc's extras: the bypass bin's one-bit shift (cwm) and `low` += range for a bypass bin of 1 (wbm).
+constexpr uint32_t kEncBypassHi = 0x0000FEFEu;  // high word of the encoder's bypass entry (packed state 127): successors 0xFE, flags 0
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_mixed3_acc(EncCore &e, EncWordAcc &g, bool first, Bin bin, uint32_t cwm, uint32_t wbm, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  const uint64_t ent = st.entry_mem(q);
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  st.store_at(at, t);                                       // (a bypass bin: 0xFE into its dummy byte again)
+  const uint32_t m = bin.lps_mask_sext(t);                  // ~0: a context bin that is not its mps
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);      // a bypass bin: 0
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);             // ... the range itself
+  const uint32_t n = clz32(r) - 23u;                        // ... 0
+  const uint32_t nt = bin.add_byte(n, cwm);                 // ... which moves low by one bit all the same
+  g.T = (((first ? 0u : g.T) + (rmps & m)) << nt) + bin.mul_byte(e.range, wbm);
+  g.S = (first ? 0u : g.S) + nt;
+  e.range = shl16(r, n);
+}
+
 // Latency-oriented form of enc_bin_row_acc for the low-occupancy kernel instance (few waves per SIMD: nothing hides an
 // LDS round trip, so none may sit on a bin-to-bin dependency chain).  The caller hands in the state q -- loaded one bin
 // ahead, with the previous bin's successor forwarded in a register when both bins use the same context.  In two halves,

@@ -132,7 +132,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // instructions per array (16 registers); 8 -> 128-byte segments, 128 bytes per stream in 8 instructions (32 registers).
 // Whole 128-byte lines per request are what the memory system likes (tools/ubench/store_seg.hip: two arrays read this
 // way, 1.30 ms against 2.54 ms with 64-byte segments at the coder kernels' occupancy), registers permitting.
-template <int LPR>
+// HOLE (k_encode's ctx tile with <= 64 contexts): rows 56..63 sit 256 bytes further up -- the 256 bytes they would occupy are the
+// dummy row of the mixed step (group 31 of the wave's LDS region: where a bypass byte's state address lands under the step's 5-bit
+// group mask; cabac_kernels.hip: WaveLds).  A shift by a whole bank row: the reads and writes stay conflict-free.
+template <int LPR, bool HOLE = false>
 struct TileT {
   static constexpr int T = 16 * LPR;  // bytes per stream per load round
   static constexpr int H = 32;        // bytes per stream resident in LDS
@@ -140,7 +143,9 @@ struct TileT {
   static constexpr int NP = T / H;    // 32-byte parts per round
   // LDS image: row r = 32 bytes = two 16-byte chunks; chunk c sits in slot c ^ ((r >> 3) & 1), which makes
   // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row
-  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) {
+    return row * H + (((c ^ (row >> 3)) & 1u) << 4) + ((HOLE && row >= 56u) ? 256u : 0u);
+  }
   __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * (64 / LPR) + lane / LPR; }
   __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % LPR; }
 
@@ -239,9 +244,12 @@ struct TilePairT {
 // 0..63 of rows 16 k .. 16 k + 15 like TileT<4>, load k + 4 bytes 64..127 of the same rows, issued right behind it -- the L2 fills
 // each line once (the second request finds the fill pending) where TileT<4>'s rounds, 64 bins apart, fill it twice.  The parts go
 // to LDS exactly like TileT<4>'s (four half-wave stores per part; TileT<8> needs eight quarter-wave ones).  32 registers per array.
-struct TileLine4 {
+template <bool HOLE = false>  // (as in TileT)
+struct TileLine4T {
   static constexpr int T = 128, H = 32, NLD = 8, NP = 4;
-  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) { return row * H + (((c ^ (row >> 3)) & 1u) << 4); }
+  __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) {
+    return row * H + (((c ^ (row >> 3)) & 1u) << 4) + ((HOLE && row >= 56u) ? 256u : 0u);
+  }
   __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return (k & 3) * 16 + lane / 4; }
   __device__ static __forceinline__ uint32_t ch_of(int lane) { return lane % 4; }
   template <bool NT = false>
@@ -280,6 +288,7 @@ struct TileLine4 {
   template <bool NT = false>
   __device__ static __forceinline__ void load_rows(uint4 (&)[NLD], const uint8_t *, const uint32_t (&)[NLD], uint32_t, uint32_t, int) {}
 };
+typedef TileLine4T<false> TileLine4;
 typedef TileT<4> Tile;  // the decode kernel's (16 registers for its one input array)
 // the encode kernel's two input arrays, bins and ctx: 64-byte segments (128-byte ones measured slower here: 3.26 ms with
 // both, 3.09 with either, 3.06 with neither -- the encode kernel writes little, its reads are not what holds it up)
@@ -290,8 +299,8 @@ constexpr bool kEncNT = false;  // encode kernel: plain loads (streaming ones me
 // with streaming (nt) loads on top 2.862.  125 VGPRs, no spill (TileT<8> for both: 128 + 2 spilled, 8 quarter-wave LDS stores per part).
 // (more than 128 contexts -- CM 2, at most 2.5 waves per SIMD -- keep the 64-byte segments: 190 contexts 3.98 -> 4.19 ms, 253 contexts
 // 4.77 -> 4.95 ms with whole lines, 127 contexts 3.72 -> 3.63: profiles/r06/c_other_shapes.txt)
-template <int CM, bool PERM>
-using EncTile = typename std::conditional<!PERM && CM != 2, TileLine4, TileT<4>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+template <int CM, bool PERM, bool HOLE = false>
+using EncTile = typename std::conditional<!PERM && CM != 2, TileLine4T<HOLE>, TileT<4, HOLE>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and

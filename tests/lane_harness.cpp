@@ -51,7 +51,8 @@ struct HostStates {
   // ... and of the single-lookup steps (LdsStates::entry_mem): row | successors << 32, by bin (encoder) or by path (decoder)
   bool by_path = false;
   uint64_t entry_mem(uint32_t q) const {
-    if (!by_path && q >= kEncBypassQ) return 0;  // the encoder's all-zero entries of state 63 (k_encode's table)
+    if (!by_path && q >= 0xFEu) return (uint64_t)kEncBypassHi << 32;  // k_encode's table: packed state 127 is the bypass entry (enc_bin_mixed3_acc)
+    if (!by_path && q >= kEncBypassQ) return 0;                       // ... and 126 the all-zero one (enc_bin_mixed_acc)
     const uint32_t b0 = by_path ? next_path_mem(q) : next_mem(q), b1 = by_path ? next_path_mem(q + 1u) : next_mem(q | 1u);
     return (uint64_t)kLpsRow[q >> 2] | (uint64_t)(by_path ? (b0 | b1 << 8) : enc_entry_hi(q >> 1, b0, b1)) << 32;
   }
@@ -72,6 +73,10 @@ struct HostBin {  // Bin policy of enc_bin_at_mem
   uint32_t or_q(uint32_t q) const { return q | bin; }
   uint32_t next_of(uint32_t hi) const { return hi >> (8 * bin); }  // the store takes the low byte
   uint32_t lps_mask(uint32_t, uint32_t t) const { return (uint32_t)((int32_t)(t << 15) >> 31); }  // bit 16 of the shifted entry
+  // the kernel policy's per-bin byte of a per-word word (SDWA there); the harness hands in the bin's byte alone
+  uint32_t add_byte(uint32_t x, uint32_t y) const { return x + (y & 0xFFu); }
+  uint32_t mul_byte(uint32_t x, uint32_t y) const { return x * (y & 0xFFu); }
+  uint32_t lps_mask_sext(uint32_t t) const { return (uint32_t)((int32_t)(t << 8) >> 24); }  // byte 2 of the shifted entry, sign-extended
 };
 
 struct HostSink {
@@ -169,7 +174,10 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   const bool any = flush_every < 0;
   if (any) flush_every = -flush_every;
   // 20: the select-based step for words that mix context-coded and bypass bins (enc_bin_mixed_acc), every word it can take
-  const bool mixedw = flush_every == 20;
+  // 21: ... the step on a dummy context that holds the bypass state (enc_bin_mixed3_acc: <= 64 contexts, the kernel's 5-bit group mask
+  //     puts a bypass byte's state address on the dummy -- cm[256] here)
+  const bool mixed3 = flush_every == 21;
+  const bool mixedw = flush_every == 20 || mixed3;
   if (mixedw) flush_every = 18;
   // 19: the latency-oriented instance of that path: state read one bin ahead, successor forwarded for a repeated context
   const bool lat = flush_every == 19;
@@ -190,12 +198,17 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   int mw = 0;
   for (uint32_t i = 0; i < n; i++) {
     auto ctx_or_ep = [&](uint32_t j) { return ctx[j] < 128 || ctx[j] == kBypass; };
-    if (mixedw && nctx <= 128 && i % 4 == 0 && i + 4 <= n && ctx_or_ep(i) && ctx_or_ep(i + 1) && ctx_or_ep(i + 2) && ctx_or_ep(i + 3)) {
+    auto ctx64_or_ep = [&](uint32_t j) { return ctx[j] < 64 || ctx[j] == kBypass; };
+    if (mixedw && nctx <= (mixed3 ? 64 : 128) && i % 4 == 0 && i + 4 <= n &&
+        (mixed3 ? ctx64_or_ep(i) && ctx64_or_ep(i + 1) && ctx64_or_ep(i + 2) && ctx64_or_ep(i + 3)
+                : ctx_or_ep(i) && ctx_or_ep(i + 1) && ctx_or_ep(i + 2) && ctx_or_ep(i + 3))) {
       EncWordAcc acc;
       for (int k = 0; k < 4; k++) {  // the kernel's view: bit 7 = bypass, the state address masked into the image
         const uint32_t c = ctx[i + k], mb = (c & 0x80u) ? ~0u : 0u, bm = (bins[i + k] && mb) ? ~0u : 0u;
-        enc_bin_mixed_acc(e, acc, k == 0, HostBin{bins[i + k]}, mb, bm, st.addr(c & (nctx <= 64 ? 0x3Fu : 0x7Fu)), st);
+        if (mixed3) enc_bin_mixed3_acc(e, acc, k == 0, HostBin{bins[i + k]}, mb & 1u, bm & 1u, (c & 0x80u) ? 256u : st.addr(c), st);
+        else enc_bin_mixed_acc(e, acc, k == 0, HostBin{bins[i + k]}, mb, bm, st.addr(c & (nctx <= 64 ? 0x3Fu : 0x7Fu)), st);
       }
+      if (mixed3 && st.cm[256] != 0xFEu) return -3;  // the dummy keeps the bypass state
       if (acc.S > g_word_shift_max) g_word_shift_max = acc.S;
       enc_word_close(e, acc);
       if (e.W > mw) mw = e.W;
