@@ -148,7 +148,7 @@ struct EncLatPipe {
 template <int CM, bool PERM = false>
 struct WaveLds {
   static constexpr uint32_t SB = CM == 1 ? 4096u : CM == 3 ? 8192u : 16384u;  // CM 1: <= 64 contexts, 3: <= 128, 2: <= 255
-  static constexpr uint32_t TILE = Tile::H * 64;
+  static constexpr uint32_t TILE = EncTile<CM, PERM>::H * 64;  // (more than 64 contexts: 16 bytes per stream resident, cabac_wave.h)
   static constexpr uint32_t STAGE = 16 * 64;
   static constexpr uint32_t IDS = PERM ? 4 * 64 : 0;
   // the "context" bypass bins read and write in the mixed step (a byte nobody else looks at).  <= 64 contexts (MIXED3): group 31 of the
@@ -244,9 +244,9 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   sink.pos = 0;
   sink.on = valid;
 
-  // A load round is TM bytes of every row of both arrays, coded in 32-byte parts; the next round is requested when the round's last
+  // A load round is TM bytes of every row of both arrays, coded in parts of PB bytes (what is resident in LDS); the next round is requested when the round's last
   // part has gone to LDS (the staging registers are free again)
-  constexpr int TM = BTile::T, NPM = TM / 32;
+  constexpr int TM = BTile::T, PB = BTile::H, NPM = TM / PB;
   const uint32_t nrounds = (nmax + TM - 1) / TM;
   const uint32_t nrows = (uint32_t)min((uint64_t)64, a.S - s0);
   const uint8_t *bins_w = a.bins + s0 * a.pitch, *ctx_w = a.ctx + s0 * a.pitch;
@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   auto round = [&](uint4 (&pb)[BTile::NLD], uint4 (&pc)[CTile::NLD], uint32_t t) {
 #pragma unroll
     for (int h = 0; h < NPM; h++) {
-      const uint32_t pos = t * TM + h * 32;
+      const uint32_t pos = t * TM + h * PB;
       if (pos >= nmax) return;
       BTile::half_to_lds(tile_b, pb, h, lane);
       CTile::half_to_lds(tile_c, pc, h, lane);
       wave_lds_sync();
-      if (h == NPM - 1 && pos + 32 < nmax) fetch_into(pb, pc, pos + 32);
-      for (int j = 0; j < 2; j++) {
+      if (h == NPM - 1 && pos + PB < nmax) fetch_into(pb, pc, pos + PB);
+      for (int j = 0; j < PB / 16; j++) {
         const uint32_t i0 = pos + j * 16;
         if (i0 >= nmax) break;
         const uint4 wb = BTile::row_chunk(tile_b, lane, j);

@@ -135,15 +135,20 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // HOLE (k_encode's ctx tile with <= 64 contexts): rows 56..63 sit 256 bytes further up -- the 256 bytes they would occupy are the
 // dummy row of the mixed step (group 31 of the wave's LDS region: where a bypass byte's state address lands under the step's 5-bit
 // group mask; cabac_kernels.hip: WaveLds).  A shift by a whole bank row: the reads and writes stay conflict-free.
-template <int LPR, bool HOLE = false>
+// Q (k_encode with more than 64 contexts): 16 bytes per stream resident instead of 32 -- a tile of 1 KiB instead of 2, which with
+// 8 .. 16 KiB of state image per wave is a wave more on the CU or two; a part is then ONE chunk of 16 bins, written by a quarter of
+// the lanes (four stores per part as before: twice the LDS stores per bin).
+template <int LPR, bool HOLE = false, bool Q = false>
 struct TileT {
   static constexpr int T = 16 * LPR;  // bytes per stream per load round
-  static constexpr int H = 32;        // bytes per stream resident in LDS
+  static constexpr int H = Q ? 16 : 32;  // bytes per stream resident in LDS
   static constexpr int NLD = LPR;     // wave-wide load instructions per round (64 / LPR streams each)
-  static constexpr int NP = T / H;    // 32-byte parts per round
+  static constexpr int NP = T / H;    // H-byte parts per round
+  static_assert(!Q || LPR == 4, "quarter residency: four lanes per row");
   // LDS image: row r = 32 bytes = two 16-byte chunks; chunk c sits in slot c ^ ((r >> 3) & 1), which makes
   // the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots of the 256-byte bank row
   __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) {
+    if (Q) return row * 16;  // (consecutive rows: every store and read covers whole bank rows)
     return row * H + (((c ^ (row >> 3)) & 1u) << 4) + ((HOLE && row >= 56u) ? 256u : 0u);
   }
   __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return k * (64 / LPR) + lane / LPR; }
@@ -192,9 +197,9 @@ struct TileT {
       r[k] = NT ? nt_load16(p) : ld16(p);
     }
   }
-  // part h (bytes 32 h .. 32 h + 31 of the round) of the registers -> LDS
+  // part h (bytes H h .. H h + H - 1 of the round) of the registers -> LDS
   __device__ static __forceinline__ void half_to_lds(uint8_t *tile, const uint4 (&r)[NLD], int h, int lane) {
-    if ((int)(ch_of(lane) >> 1) == h) {
+    if (Q ? (int)ch_of(lane) == h : (int)(ch_of(lane) >> 1) == h) {
 #pragma unroll
       for (int k = 0; k < NLD; k++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane) & 1)) = r[k];
     }
@@ -244,10 +249,11 @@ struct TilePairT {
 // 0..63 of rows 16 k .. 16 k + 15 like TileT<4>, load k + 4 bytes 64..127 of the same rows, issued right behind it -- the L2 fills
 // each line once (the second request finds the fill pending) where TileT<4>'s rounds, 64 bins apart, fill it twice.  The parts go
 // to LDS exactly like TileT<4>'s (four half-wave stores per part; TileT<8> needs eight quarter-wave ones).  32 registers per array.
-template <bool HOLE = false>  // (as in TileT)
+template <bool HOLE = false, bool Q = false>  // (as in TileT)
 struct TileLine4T {
-  static constexpr int T = 128, H = 32, NLD = 8, NP = 4;
+  static constexpr int T = 128, H = Q ? 16 : 32, NLD = 8, NP = T / H;
   __device__ static __forceinline__ uint32_t lds_off(uint32_t row, uint32_t c) {
+    if (Q) return row * 16;
     return row * H + (((c ^ (row >> 3)) & 1u) << 4) + ((HOLE && row >= 56u) ? 256u : 0u);
   }
   __device__ static __forceinline__ uint32_t row_of(int k, int lane) { return (k & 3) * 16 + lane / 4; }
@@ -270,13 +276,13 @@ struct TileLine4T {
   // line's second half moves down into them before part 2 (16 moves per 128 bytes of every row; a register index computed from h
   // would put the array into scratch)
   __device__ static __forceinline__ void half_to_lds(uint8_t *tile, uint4 (&r)[NLD], int h, int lane) {
-    if (h == 2) {
+    if (h == NP / 2) {
       r[0] = r[4];
       r[1] = r[5];
       r[2] = r[6];
       r[3] = r[7];
     }
-    if ((int)(ch_of(lane) >> 1) == (h & 1)) {
+    if (Q ? (int)ch_of(lane) == (h & 3) : (int)(ch_of(lane) >> 1) == (h & 1)) {
 #pragma unroll
       for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(tile + lds_off(row_of(k, lane), ch_of(lane) & 1)) = r[k];
     }
@@ -300,7 +306,7 @@ constexpr bool kEncNT = false;  // encode kernel: plain loads (streaming ones me
 // (more than 128 contexts -- CM 2, at most 2.5 waves per SIMD -- keep the 64-byte segments: 190 contexts 3.98 -> 4.19 ms, 253 contexts
 // 4.77 -> 4.95 ms with whole lines, 127 contexts 3.72 -> 3.63: profiles/r06/c_other_shapes.txt)
 template <int CM, bool PERM, bool HOLE = false>
-using EncTile = typename std::conditional<!PERM && CM != 2, TileLine4T<HOLE>, TileT<4, HOLE>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
+using EncTile = typename std::conditional<!PERM && CM != 2, TileLine4T<HOLE, CM != 1>, TileT<4, HOLE, CM != 1>>::type;  // (the bucketed instances keep 64-byte segments: 16 + 16 registers)
 
 // The decode kernel's output staging.  A chunk's 16 output bytes (bit 0 of each = the bin, see cabac_lane.h: dec_bin_out)
 // are packed four to a byte -- bit i of byte b of the dword = bin 4 i + b -- so that 128 bins of 64 streams fit 2 KiB and
