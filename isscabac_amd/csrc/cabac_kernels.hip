@@ -1097,12 +1097,15 @@ uint64_t slot_stride_for(uint32_t nbins) {
 // Waves per workgroup of the instances with more than 64 contexts: a workgroup's waves share one copy of the tables, and a CU's
 // 160 KiB of LDS hold floor(160 KiB / (tables + w x wave)) workgroups of w waves -- the w (1..4) that leaves the most waves on a CU,
 // the smallest such w.  Decoder: 127 contexts 11 -> 12 waves (w = 2), 190 contexts 8 -> 9 (w = 3).
+// The CU hands its 160 KiB out in 128 granules of 1280 bytes (measured: tools/ubench/lds_occ.hip, profiles/r06/j_lds_occ.txt -- single-
+// wave workgroups of 10 240 bytes: 16 on a CU, of 10 496: 14, of 13 312: 11 where 160 KiB / 13 312 = 12.3; the runtime's occupancy
+// query does not know and says 12).
 static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes) {
-  constexpr size_t kCuLds = 160 * 1024;
+  constexpr size_t kGranule = 1280, kGranules = 128;
   int best = 1;
   size_t best_waves = 0;
   for (int w = 1; w <= 4; w++) {
-    const size_t waves = kCuLds / (tab_bytes + w * wave_bytes) * w;
+    const size_t waves = kGranules / ((tab_bytes + w * wave_bytes + kGranule - 1) / kGranule) * w;
     if (waves > best_waves) {
       best_waves = waves;
       best = w;
@@ -1119,9 +1122,9 @@ static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  // (the encoder keeps single-wave workgroups with more than 64 contexts: 190 contexts 3.98 ms so, 4.74 ms with the three-wave
-  // workgroups that would put a ninth wave on a CU -- profiles/r06/g_ctx_rates.txt; the decoder gains 5-6 % from its twelfth / ninth)
-  const int wpb = enc_waves_per_block(CM);
+  // (more than 64 contexts: the workgroup size that leaves the most waves on a CU -- 127 contexts: two waves share the tables, 12 waves
+  // per CU where single-wave workgroups get 11)
+  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes));
   const size_t lds = kTabBytes + wpb * enc_wave_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTabBytes + 4 * enc_wave_lds_bytes<CM, PERM>(16384)));
