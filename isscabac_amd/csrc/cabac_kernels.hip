@@ -1099,19 +1099,25 @@ uint64_t slot_stride_for(uint32_t nbins) {
 // the smallest such w.  Decoder: 127 contexts 11 -> 12 waves (w = 2), 190 contexts 8 -> 9 (w = 3).
 // The CU hands its 160 KiB out in 128 granules of 1280 bytes (measured: tools/ubench/lds_occ.hip, profiles/r06/j_lds_occ.txt -- single-
 // wave workgroups of 10 240 bytes: 16 on a CU, of 10 496: 14, of 13 312: 11 where 160 KiB / 13 312 = 12.3; the runtime's occupancy
-// query does not know and says 12).
-static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes) {
+// query does not know and says 12).  And it puts the four waves of a four-wave workgroup on its four SIMDs, one each, where the waves of
+// smaller workgroups land unevenly (tools/ubench/simd_place.hip: twelve single waves leave 4.1 on a SIMD on average, up to 6; three
+// four-wave workgroups exactly 3): four waves unless that costs more than `slack` waves per CU (127 contexts: 12 waves either way, both
+// kernels 3 % faster in fours.  The encoder gives a wave for it -- 190 contexts: 8 waves in fours beat 9 in threes, 3.69 against
+// 3.90 ms --, the decoder, whose chain holds its decision, does not: 3.68 ms with 9 in threes, 3.73 .. 4.1 with 8 in fours; 253
+// contexts: 4 waves in fours against 7 single ones -- profiles/r06/r_wpb_sweep.txt, w_wpb_190.txt).
+static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes, size_t slack) {
   constexpr size_t kGranule = 1280, kGranules = 128;
   int best = 1;
-  size_t best_waves = 0;
+  size_t best_waves = 0, waves4 = 0;
   for (int w = 1; w <= 4; w++) {
     const size_t waves = kGranules / ((tab_bytes + w * wave_bytes + kGranule - 1) / kGranule) * w;
-    if (waves > best_waves) {
+    if (waves >= best_waves) {
       best_waves = waves;
       best = w;
     }
+    if (w == 4) waves4 = waves;
   }
-  return best;
+  return waves4 + slack >= best_waves ? 4 : best;
 }
 template <int CM, bool PERM>
 static size_t enc_wave_lds_bytes(uint32_t img_bytes) {
@@ -1122,9 +1128,8 @@ static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  // (more than 64 contexts: the workgroup size that leaves the most waves on a CU -- 127 contexts: two waves share the tables, 12 waves
-  // per CU where single-wave workgroups get 11)
-  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes));
+  // (more than 64 contexts: waves_per_block_for -- 127 contexts: four waves share the tables, 12 waves per CU, three on every SIMD)
+  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes), 1);
   const size_t lds = kTabBytes + wpb * enc_wave_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTabBytes + 4 * enc_wave_lds_bytes<CM, PERM>(16384)));
@@ -1149,7 +1154,7 @@ template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   using DL = DecLds<CM, PERM>;
   const size_t wave_bytes = CM == 2 ? DL::BYTES - DL::SB + a.img_bytes : DL::BYTES;
-  const int wpb = CM == 1 ? dec_waves_per_block(1) : waves_per_block_for(kDecTabBytes, wave_bytes);
+  const int wpb = CM == 1 ? dec_waves_per_block(1) : waves_per_block_for(kDecTabBytes, wave_bytes, 0);
   const size_t lds_max = kDecTabBytes + 4 * DL::BYTES, lds = kDecTabBytes + wpb * wave_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
