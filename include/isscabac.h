@@ -92,11 +92,11 @@ int isscabac_abi_version(void);
  *               (up to 512 streams per compute unit: 128 Ki streams on an MI355X), else the throughput one
  *   THROUGHPUT  fewest instructions per bin; relies on four resident waves per SIMD to hide LDS latency
  *   LATENCY     state prefetch + register forwarding, no LDS round trip on the range recurrence; for small batches.
- *               With <= 64 contexts the encoder runs as a producer / consumer wave pair, and so does the decoder for
- *               launches of at most two waves of streams per compute unit
- *   LATENCY_SINGLE  the latency-oriented instances on ONE wave per 64 streams whatever the launch size -- what AUTO
- *               runs for the decoder between 32 Ki and 128 Ki streams (a strong-scaled job's per-GPU share); lets
- *               tests and A/B runs reach those instances with small batches
+ *               With <= 64 contexts the encoder runs as a producer / consumer wave pair and the decoder with a helper
+ *               wave, for launches of at most eight waves of streams per compute unit (128 Ki streams on an MI355X: a
+ *               strong-scaled job's per-GPU share)
+ *   LATENCY_SINGLE  the latency-oriented instances on ONE wave per 64 streams whatever the launch size (what LATENCY
+ *               runs with more than 64 contexts); lets tests and A/B runs reach those instances with small batches
  * (a strong-scaled job leaves each GPU 1/N of the streams: SURVEY.md 8(e)) */
 #define ISSCABAC_TUNE_AUTO 0
 #define ISSCABAC_TUNE_THROUGHPUT 1

@@ -18,7 +18,7 @@
 #include "cabac_internal.h"
 
 #ifndef ISSCABAC_DEC_PAIR_WAVES_PER_CU
-#define ISSCABAC_DEC_PAIR_WAVES_PER_CU 2  // launches of at most this many waves of streams per CU decode on the wave pair
+#define ISSCABAC_DEC_PAIR_WAVES_PER_CU 8  // launches of at most this many waves of streams per CU decode on the wave pair
 #endif
 
 using namespace isscabac;
@@ -207,7 +207,10 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY || e->tuning == ISSCABAC_TUNE_LATENCY_SINGLE ||
                 (e->tuning == ISSCABAC_TUNE_AUTO && (nctx > 128 || S <= 2ull * (uint64_t)e->num_cus * 4 * 64));
   // The decoder's helper wave (cabac_pair.hip: k_decode_pair) takes a fifth of the instructions off the decoding wave but not
-  // its chain: same-box sweep 16 Ki streams 0.358 -> 0.306 ms, 64 Ki 0.364 -> 0.363, 128 Ki 0.460 -> 0.486 (profiles/r05)
+  // its chain: same-box sweep 16 Ki streams 0.358 -> 0.306 ms, 64 Ki 0.364 -> 0.363, 128 Ki 0.460 -> 0.486 (profiles/r05) -- with the
+  // hardware's own placement of its two-wave workgroups.  With the pair's waves on the SIMDs a per-CU ticket names (round 6:
+  // pair_pin_role) 64 Ki 0.369 -> 0.321, 128 Ki 0.463 -> 0.448 (profiles/r06/y2_dpair_pin_sweep.txt): every launch of at most
+  // eight waves of streams per CU, which is all that its 18.5 KiB of LDS per pair lets a CU hold at once
   sh->tiny = S <= (uint64_t)e->num_cus * ISSCABAC_DEC_PAIR_WAVES_PER_CU * 64;
   sh->pair = e->tuning != ISSCABAC_TUNE_LATENCY_SINGLE;
   for (int c = 0; c < nctx; c++) {

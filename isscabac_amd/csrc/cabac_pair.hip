@@ -416,24 +416,26 @@ static_assert(8 * kLdsBytes <= 160 * 1024, "eight workgroups per CU");
 constexpr uint32_t kPlain = 0, kMixed = 1, kGeneral = 2;
 }  // namespace dpair
 
-__global__ void __launch_bounds__(128, 4) k_decode_pair(DecArgs a) {
+__global__ void __launch_bounds__(256, 4) k_decode_pair(DecArgs a) {
   using namespace dpair;
   using pairk::lds_u32;
   using pairk::get_rows;
   using pairk::put_rows;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // 0: helper (A), 1: decoder (B)
   {
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-    for (int qb = tid; qb < 256; qb += 128) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin (k_decode)
+    for (int qb = tid; qb < 256; qb += 256) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin (k_decode)
       const uint32_t ps = (uint32_t)qb >> 1;
       const uint32_t sp = c_next.ep[ps >> 1] >> (16 * (ps & 1));
       tab[2 * qb] = c_lps_rows[ps >> 1];
       tab[2 * qb + 1] = dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
     }
   }
-  __syncthreads();
+  // four waves have started, two stay: on the SIMDs the CU's ticket names (pair_pin_role; its barrier is the tables' too)
+  const int role = pairk::pair_pin_role(reinterpret_cast<uint32_t *>(smem + kLdsBytes), tid);
+  if (role < 0) return;
+  const int wib = __builtin_amdgcn_readfirstlane(role);  // 0: helper (A), 1: decoder (B)
   const uint64_t s0 = (uint64_t)blockIdx.x * 64;
   if (s0 >= a.S) return;
   const bool valid = s0 + lane < a.S;
@@ -719,7 +721,7 @@ hipError_t run_decode_pair(const DecArgs &a, hipStream_t stream) {
   }
   if (static_lds != 0) return hipErrorInvalidConfiguration;
   const uint64_t nblk = (a.S + 63) / 64;
-  hipLaunchKernelGGL(k_decode_pair, dim3((unsigned)nblk), dim3(128), dpair::kLdsBytes, stream, a);
+  hipLaunchKernelGGL(k_decode_pair, dim3((unsigned)nblk), dim3(256), dpair::kLdsBytes + 32, stream, a);  // (four waves start, two stay)
   return hipGetLastError();
 }
 

@@ -55,9 +55,9 @@ def golden():
 def engine(request):
     """The HIP engine through its C ABI (GPU tests only), once per kernel instance: the test batches are small, so under
     automatic tuning every one of them would run the wave-pair kernels only.  throughput: k_encode / k_decode<CM,false,*>;
-    latency: k_encode_pair / k_decode_pair (<= 64 contexts), k_*<CM,true,false> beyond; latency_single: k_encode /
-    k_decode<CM,true,false> for every context count -- the decoder AUTO runs for 32 Ki < S <= 128 Ki streams (an 8-GPU job's
-    per-GPU share of config 3, config 2's shape)."""
+    latency: k_encode_pair / k_decode_pair (<= 64 contexts: what AUTO runs up to 128 Ki streams -- an 8-GPU job's per-GPU
+    share of config 3, config 2's shape), k_*<CM,true,false> beyond; latency_single: k_encode / k_decode<CM,true,false> for
+    every context count."""
     import torch  # noqa: F401  (load torch's HIP runtime first so both share one libamdhip64)
     from isscabac_amd import Engine
     eng = Engine(device=0)

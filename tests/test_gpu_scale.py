@@ -75,24 +75,26 @@ def test_streams_of_the_maximum_length():
     assert 0.09 * S * B < total < 0.11 * S * B
 
 
-@pytest.mark.parametrize("S,B,C,seed,enc_inst,dec_inst", [
+@pytest.mark.parametrize("S,B,C,seed,tuning,enc_inst,dec_inst", [
     # config 3's per-GPU share of an 8-GPU strong-scaled job: what `bench.py --gpus 8` runs on every rank
-    (131072, 4096, 64, 0xCABAC003, "k_encode_pair", "k_decode<1,true,false>"),
+    (131072, 4096, 64, 0xCABAC003, "auto", "k_encode_pair", "k_decode_pair"),
     # config 2's shape
-    (65536, 1024, 3, 0xCABAC002, "k_encode_pair", "k_decode<1,true,false>"),
+    (65536, 1024, 3, 0xCABAC002, "auto", "k_encode_pair", "k_decode_pair"),
+    # the one-wave latency-oriented instances at the share's size (AUTO's decoder there until the pairs' waves were pinned to SIMDs)
+    (131072, 4096, 64, 0xCABAC003, "latency_single", "k_encode<1,true,false>", "k_decode<1,true,false>"),
 ])
-def test_per_gpu_share_under_auto_tuning_against_the_oracle(S, B, C, seed, enc_inst, dec_inst):
-    """AUTO's own kernel choice between 32 Ki and 128 Ki streams -- the wave-pair encoder and the one-wave latency-oriented
-    decoder k_decode<1,true,false> -- at the real launch sizes: device round trip over every stream, 133 sampled streams byte
-    for byte against the oracle, and 320 corrupted streams (random bit flips; 64 of them made to start with 0xFF, the
-    reference's register-overflow case) whose decoded bins AND status words must equal the oracle's
+def test_per_gpu_share_under_auto_tuning_against_the_oracle(S, B, C, seed, tuning, enc_inst, dec_inst):
+    """AUTO's own kernel choice up to 128 Ki streams -- the wave pairs, four waves started per pair and two kept on the SIMDs a
+    per-CU ticket names -- and the one-wave latency-oriented instances, at the real launch sizes: device round trip over every
+    stream, 133 sampled streams byte for byte against the oracle, and 320 corrupted streams (random bit flips; 64 of them made
+    to start with 0xFF, the reference's register-overflow case) whose decoded bins AND status words must equal the oracle's
     (ref: CABAC_ArithmeticDecoder.cpp:73-190)."""
     torch = _torch()
     from isscabac_amd import Engine
     from oracle.pyoracle import Oracle
     dev = torch.device("cuda:0")
     eng, orc = Engine(0), Oracle()
-    eng.set_tuning("auto")
+    eng.set_tuning(tuning)
     bins = torch.empty((S, B), dtype=torch.uint8, device=dev)
     ctx = torch.empty((S, B), dtype=torch.uint8, device=dev)
     eng.synth_dev(seed, 0, S, B, B, C, False, bins.data_ptr(), ctx.data_ptr())
