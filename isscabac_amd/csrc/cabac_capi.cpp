@@ -206,6 +206,9 @@ static int check_shape(isscabac_engine *e, const char *who, uint64_t S, uint32_t
   // whatever the batch's size, the latency instance's regime: 190 contexts 514 -> 542 Gbin/s, 253 contexts 434 -> 483.
   sh->latency = e->tuning == ISSCABAC_TUNE_LATENCY || e->tuning == ISSCABAC_TUNE_LATENCY_SINGLE ||
                 (e->tuning == ISSCABAC_TUNE_AUTO && (nctx > 128 || S <= 2ull * (uint64_t)e->num_cus * 4 * 64));
+  // 65 .. 128 contexts leave three waves on a SIMD: there the encoder's latency instance still wins (127 contexts, 1 Mi streams:
+  // 3.34 against 3.43 .. 3.48 ms), the decoder's does not (3.64 against 3.19) -- profiles/r06/ab_ctx_rates_by_tuning.txt
+  sh->latency_enc = sh->latency || (e->tuning == ISSCABAC_TUNE_AUTO && nctx > 64);
   // The decoder's helper wave (cabac_pair.hip: k_decode_pair) takes a fifth of the instructions off the decoding wave but not
   // its chain: same-box sweep 16 Ki streams 0.358 -> 0.306 ms, 64 Ki 0.364 -> 0.363, 128 Ki 0.460 -> 0.486 (profiles/r05) -- with the
   // hardware's own placement of its two-wave workgroups.  With the pair's waves on the SIMDs a per-CU ticket names (round 6:

@@ -103,6 +103,7 @@ struct BatchShape {
   uint32_t pitch;    // bytes between consecutive streams' rows, multiple of 16
   uint32_t nctx;     // contexts (1..255)
   bool latency;      // run the latency-oriented kernel instance (few waves per SIMD), see isscabac_set_tuning
+  bool latency_enc;  // ... the encoder's: also every launch of more than 64 contexts (at most three waves per SIMD)
   bool tiny;         // at most two waves of streams per CU: the decoder + helper wave pair pays (cabac_pair.hip)
   bool pair;         // the wave-pair kernels may run (false: ISSCABAC_TUNE_LATENCY_SINGLE, one wave per 64 streams)
   const uint32_t *d_order;  // device: stream ids sorted by bin count (length-bucketed launch, cabac_order.hip) or null

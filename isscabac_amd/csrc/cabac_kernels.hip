@@ -1182,7 +1182,7 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
     sh.instance = KN "<" #CM "," #LAT "," #PERM ">"; \
     return FN<CM, LAT, PERM>(ARGS, stream);      \
   } while (0)
-#define ISSCABAC_DISPATCH(FN, KN, ARGS)                                                                 \
+#define ISSCABAC_DISPATCH(FN, KN, ARGS, LATF)                                                                \
   do {                                                                                                  \
     if (sh.d_order) { /* length-bucketed launch */                                                      \
       if (sh.nctx <= 64) ISSCABAC_RUN(FN, KN, 1, false, true, ARGS);                                    \
@@ -1190,14 +1190,14 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
       ISSCABAC_RUN(FN, KN, 2, false, true, ARGS);                                                       \
     }                                                                                                   \
     if (sh.nctx <= 64) {                                                                                \
-      if (sh.latency) ISSCABAC_RUN(FN, KN, 1, true, false, ARGS);                                       \
+      if (LATF) ISSCABAC_RUN(FN, KN, 1, true, false, ARGS);                                       \
       ISSCABAC_RUN(FN, KN, 1, false, false, ARGS);                                                      \
     }                                                                                                   \
     if (sh.nctx <= 128) {                                                                               \
-      if (sh.latency) ISSCABAC_RUN(FN, KN, 3, true, false, ARGS);                                       \
+      if (LATF) ISSCABAC_RUN(FN, KN, 3, true, false, ARGS);                                       \
       ISSCABAC_RUN(FN, KN, 3, false, false, ARGS);                                                      \
     }                                                                                                   \
-    if (sh.latency) ISSCABAC_RUN(FN, KN, 2, true, false, ARGS);                                         \
+    if (LATF) ISSCABAC_RUN(FN, KN, 2, true, false, ARGS);                                         \
     ISSCABAC_RUN(FN, KN, 2, false, false, ARGS);                                                        \
   } while (0)
 
@@ -1222,7 +1222,7 @@ hipError_t launch_encode(const BatchShape &sh, const uint8_t *d_bins, const uint
     sh.instance = "k_encode_pair";
     return run_encode_pair(a, stream);
   }
-  ISSCABAC_DISPATCH(run_encode, "k_encode", a);
+  ISSCABAC_DISPATCH(run_encode, "k_encode", a, sh.latency_enc);
 }
 
 static void fill_dec_args(DecArgs &a, const BatchShape &sh, const uint8_t *d_payload, uint64_t payload_bytes,
@@ -1265,7 +1265,7 @@ hipError_t launch_decode(const BatchShape &sh, const uint8_t *d_payload, uint64_
     sh.instance = "k_decode_pair";
     return run_decode_pair(a, stream);
   }
-  ISSCABAC_DISPATCH(run_decode, "k_decode", a);
+  ISSCABAC_DISPATCH(run_decode, "k_decode", a, sh.latency);
 }
 
 // ------------------------------------------------------------------------------------------------

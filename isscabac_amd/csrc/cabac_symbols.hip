@@ -1145,7 +1145,7 @@ static int enc_symbols_enqueue(isscabac_engine *e, const uint8_t *d_sym, const u
     sh.nbins = (uint32_t)mat_bins;
     sh.pitch = (uint32_t)mat_pitch;
     sh.nctx = (uint32_t)nctx;
-    sh.latency = true;
+    sh.latency = sh.latency_enc = true;
     sh.tiny = true;
     sh.pair = e->tuning != ISSCABAC_TUNE_LATENCY_SINGLE;
     sh.d_order = nullptr;
