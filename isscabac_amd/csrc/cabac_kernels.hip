@@ -144,6 +144,8 @@ struct EncLatPipe {
 };
 
 
+__device__ uint32_t g_kernel_ticket[kPinTickets];  // (pinned_wave_index: workgroups of fewer than four waves)
+
 // LDS bytes of one wave: context states, two half tiles, (encoder) the output staging, (bucketed launches) the wave's stream ids
 template <int CM, bool PERM = false>
 struct WaveLds {
@@ -174,7 +176,6 @@ template <int CM, bool LAT, bool PERM>
 __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   if (tid < 64) {
     tab[tid] = c_lps_rows[tid];
@@ -187,10 +188,17 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
     // ... and packed state 127 (the byte 0xFE) is the bypass entry of the step on a dummy context that holds it (enc_bin_mixed3_acc)
     tab[kTabRowOff / 4 + 2 * ps + 1] = ps == 127 ? kEncBypassHi : ps == 126 ? 0u : enc_entry_hi(ps, sb & 0xFFu, (sb >> 8) & 0xFFu);
   }
-  __syncthreads();
   const uint32_t wpb = CM == 1 ? (uint32_t)enc_waves_per_block(1) : a.wpb;  // (> 64 contexts: chosen at launch, waves_per_block_for; a kernel
                                                                             // argument: derived from blockDim.x the compiler took the wave's first stream -- and every
                                                                             // address built on it -- for a per-lane value)
+  int wave = tid >> 6;
+  if (CM != 1 && wpb < 4) {  // four waves have started, wpb stay: the ones a per-CU ticket names (cabac_wave.h: pinned_wave_index)
+    wave = pinned_wave_index(reinterpret_cast<uint32_t *>(smem + kTabBytes), g_kernel_ticket, tid, (int)wpb, true);
+    if (wave < 0) return;
+  } else {
+    __syncthreads();
+  }
+  const int wib = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
@@ -437,7 +445,6 @@ template <int CM, bool LAT, bool PERM>
 __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
   for (int qb = tid; qb < 256; qb += blockDim.x) {  // raw state byte qb: packed state qb >> 1, bit 0 is a stale bin
     const uint32_t ps = (uint32_t)qb >> 1;
@@ -446,8 +453,15 @@ __global__ void __launch_bounds__(256, 4) k_decode(DecArgs a) {
     tab[2 * qb] = qb >= (int)kDecBypassRaw ? 0u : c_lps_rows[ps >> 1];
     tab[2 * qb + 1] = qb >= (int)kDecBypassRaw ? kDecBypassHi : dec_entry_hi_out(ps, sp & 0xFFu, (sp >> 8) & 0xFFu);
   }
-  __syncthreads();
   const uint32_t wpb = CM == 1 ? (uint32_t)dec_waves_per_block(1) : a.wpb;
+  int wave = tid >> 6;
+  if (CM != 1 && wpb < 4) {  // (as in k_encode)
+    wave = pinned_wave_index(reinterpret_cast<uint32_t *>(smem + kDecTabBytes), g_kernel_ticket, tid, (int)wpb, true);
+    if (wave < 0) return;
+  } else {
+    __syncthreads();
+  }
+  const int wib = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform: keeps s0 and everything derived from it in SGPRs
   const uint64_t s0 = ((uint64_t)blockIdx.x * wpb + wib) * 64;
   if (s0 >= a.S) return;
 
@@ -1099,25 +1113,25 @@ uint64_t slot_stride_for(uint32_t nbins) {
 // the smallest such w.  Decoder: 127 contexts 11 -> 12 waves (w = 2), 190 contexts 8 -> 9 (w = 3).
 // The CU hands its 160 KiB out in 128 granules of 1280 bytes (measured: tools/ubench/lds_occ.hip, profiles/r06/j_lds_occ.txt -- single-
 // wave workgroups of 10 240 bytes: 16 on a CU, of 10 496: 14, of 13 312: 11 where 160 KiB / 13 312 = 12.3; the runtime's occupancy
-// query does not know and says 12).  And it puts the four waves of a four-wave workgroup on its four SIMDs, one each, where the waves of
-// smaller workgroups land unevenly (tools/ubench/simd_place.hip: twelve single waves leave 4.1 on a SIMD on average, up to 6; three
-// four-wave workgroups exactly 3): four waves unless that costs more than `slack` waves per CU (127 contexts: 12 waves either way, both
-// kernels 3 % faster in fours.  The encoder gives a wave for it -- 190 contexts: 8 waves in fours beat 9 in threes, 3.69 against
-// 3.90 ms --, the decoder, whose chain holds its decision, does not: 3.68 ms with 9 in threes, 3.73 .. 4.1 with 8 in fours; 253
-// contexts: 4 waves in fours against 7 single ones -- profiles/r06/r_wpb_sweep.txt, w_wpb_190.txt).
-static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes, size_t slack) {
+// query does not know and says 12).  The workgroup size (1 .. 4 waves sharing one copy of the tables) that leaves the most waves on a
+// CU; workgroups of fewer than four waves start four and keep theirs on the SIMDs a per-CU ticket names (cabac_wave.h:
+// pinned_wave_index -- left to the hardware the waves of small workgroups land unevenly, and four-wave workgroups were the only even
+// ones: profiles/r06/r_wpb_sweep.txt).  Among sizes that leave the same number of waves, so placed: 2, then 4, then 1, then 3
+// (127 contexts, 12 waves each way: 3.29 / 3.14 ms in twos, 3.32 / 3.19 in fours, 3.39 / 3.44 single, 3.45 / 3.24 in threes; 190
+// contexts' encoder, 9 waves: 3.6 ms single, 3.85 in threes; 253 contexts' encoder, 8 waves: 3.72 in twos, 3.81 in fours --
+// profiles/r06/ae_wpb_pinned.txt).
+static int waves_per_block_for(size_t tab_bytes, size_t wave_bytes) {
   constexpr size_t kGranule = 1280, kGranules = 128;
-  int best = 1;
-  size_t best_waves = 0, waves4 = 0;
-  for (int w = 1; w <= 4; w++) {
+  int best = 2;
+  size_t best_waves = 0;
+  for (int w : {2, 4, 1, 3}) {
     const size_t waves = kGranules / ((tab_bytes + w * wave_bytes + kGranule - 1) / kGranule) * w;
-    if (waves >= best_waves) {
+    if (waves > best_waves) {
       best_waves = waves;
       best = w;
     }
-    if (w == 4) waves4 = waves;
   }
-  return waves4 + slack >= best_waves ? 4 : best;
+  return best;
 }
 template <int CM, bool PERM>
 static size_t enc_wave_lds_bytes(uint32_t img_bytes) {
@@ -1128,8 +1142,8 @@ static uint32_t image_bytes_for(uint32_t nctx) { return 256u * ((nctx + 3u) / 4u
 
 template <int CM, bool LAT, bool PERM>
 static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
-  // (more than 64 contexts: waves_per_block_for -- 127 contexts: four waves share the tables, 12 waves per CU, three on every SIMD)
-  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes), 1);
+  // (more than 64 contexts: waves_per_block_for -- 127 contexts: two waves share the tables, 12 waves per CU, three on every SIMD)
+  const int wpb = CM == 1 ? enc_waves_per_block(1) : waves_per_block_for(kTabBytes, enc_wave_lds_bytes<CM, PERM>(a.img_bytes));
   const size_t lds = kTabBytes + wpb * enc_wave_lds_bytes<CM, PERM>(a.img_bytes);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTabBytes + 4 * enc_wave_lds_bytes<CM, PERM>(16384)));
@@ -1146,7 +1160,8 @@ static hipError_t run_encode(const EncArgs &a, hipStream_t stream) {
   const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
   EncArgs aw = a;
   aw.wpb = (uint32_t)wpb;
-  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, aw);
+  // (workgroups of fewer than four waves start four: pinned_wave_index)
+  hipLaunchKernelGGL((k_encode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(CM != 1 ? 256 : 64 * wpb), lds, stream, aw);
   return hipGetLastError();
 }
 
@@ -1154,7 +1169,7 @@ template <int CM, bool LAT, bool PERM>
 static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   using DL = DecLds<CM, PERM>;
   const size_t wave_bytes = CM == 2 ? DL::BYTES - DL::SB + a.img_bytes : DL::BYTES;
-  const int wpb = CM == 1 ? dec_waves_per_block(1) : waves_per_block_for(kDecTabBytes, wave_bytes, 0);
+  const int wpb = CM == 1 ? dec_waves_per_block(1) : waves_per_block_for(kDecTabBytes, wave_bytes);
   const size_t lds_max = kDecTabBytes + 4 * DL::BYTES, lds = kDecTabBytes + wpb * wave_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decode<CM, LAT, PERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -1170,7 +1185,7 @@ static hipError_t run_decode(const DecArgs &a, hipStream_t stream) {
   const uint64_t nblk = (a.S + 64 * wpb - 1) / (64 * wpb);
   DecArgs aw = a;
   aw.wpb = (uint32_t)wpb;
-  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(64 * wpb), lds, stream, aw);
+  hipLaunchKernelGGL((k_decode<CM, LAT, PERM>), dim3((unsigned)nblk), dim3(CM != 1 ? 256 : 64 * wpb), lds, stream, aw);
   return hipGetLastError();
 }
 

@@ -67,32 +67,10 @@ __device__ __forceinline__ uint4 get_rows(uint32_t at) {
   const u32x4 w = *reinterpret_cast<const lds_v4 *>((uintptr_t)at);
   return make_uint4(w.x, w.y, w.z, w.w);
 }
-// Which two of a workgroup's four waves are the pair.  The hardware spreads the waves of TWO-wave workgroups unevenly over a CU's four
-// SIMDs (tools/ubench/simd_place.hip: eight of them on a CU -- 128 Ki streams -- leave 5.3 waves on a SIMD on average and up to 8, where
-// 4 would be even), and the busiest SIMD is the launch's time.  The four waves of a 256-thread workgroup land on the four SIMDs, one
-// each.  So k_encode_pair starts four waves; they tell each other their SIMD through LDS; the pair are the two on SIMDs (2 h, 2 h + 1),
-// the other two leave at once (an ended wave no longer takes part in the workgroup's barriers).  h and the order of the roles come
-// from a per-CU ticket (g_pair_ticket: how many pair workgroups have started on this CU; never reset, only its two low bits count), so
-// that the pairs that share a CU fill its SIMDs evenly AND every SIMD gets producers and consumers alike -- all producers on two SIMDs
-// and all consumers on the other two was measured slower than no pinning at all (profiles/r06/u_sweep_by_pin.txt).
-// Returns the wave's role (0: A, 1: B) or -1: leave.  `ids`: 32 bytes of LDS behind the kernel's own (inside its last allocation
-// granule).  If the four waves are NOT on four different SIMDs, waves 2 h and 2 h + 1 are the pair.
-__device__ uint32_t g_pair_ticket[2048];
-__device__ __forceinline__ int pair_pin_role(uint32_t *ids, int tid) {
-  uint32_t hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const uint32_t simd = (hw >> 4) & 3u;
-  if ((tid & 63) == 0) ids[tid >> 6] = simd;
-  if (tid == 0) ids[4] = atomicAdd(&g_pair_ticket[((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu)], 1u);  // (HW_ID 15:8: se | sh | cu)
-  __syncthreads();
-  const uint32_t i0 = ids[0], i1 = ids[1], i2 = ids[2], i3 = ids[3];
-  const bool perm = ((1u << i0) | (1u << i1) | (1u << i2) | (1u << i3)) == 0xFu;
-  const uint32_t me = perm ? simd : (uint32_t)tid >> 6;
-  const uint32_t j = ids[4];  // the CU's j-th pair
-  if ((me >> 1) != (j & 1u)) return -1;
-  return (int)((me & 1u) ^ ((j >> 1) & 1u));
-}
+// Which two of a workgroup's four waves are the pair: cabac_wave.h, pinned_wave_index (KEEP 2).  The wave's role (0: A, 1: B) or -1: leave.
+// `ids`: 32 bytes of LDS behind the kernel's own (inside its last allocation granule).
+__device__ uint32_t g_pair_ticket[kPinTickets];
+__device__ __forceinline__ int pair_pin_role(uint32_t *ids, int tid) { return pinned_wave_index(ids, g_pair_ticket, tid, 2, false); }
 }  // namespace pairk
 
 template <int K>

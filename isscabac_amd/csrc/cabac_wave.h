@@ -81,6 +81,40 @@ __device__ __forceinline__ bool is_prob_ctx_byte(uint32_t c) { return CM != 2 &&
 #ifndef ISSCABAC_ENC_PRIO
 #define ISSCABAC_ENC_PRIO 1
 #endif
+// ------------------------------------------------------------------------------------------------
+// Waves where the SIMDs are.  The hardware puts the four waves of a 256-thread workgroup on the CU's four SIMDs, one each, and spreads
+// the waves of smaller workgroups unevenly (tools/ubench/simd_place.hip: eight two-wave workgroups on a CU -- the wave pairs at 128 Ki
+// streams -- leave 5.3 waves on a SIMD on average and up to 8, where 4 would be even; twelve single waves 4.1 and up to 6), and the
+// busiest SIMD is the launch's time.  A kernel whose workgroup is KEEP < 4 waves therefore starts FOUR: they tell each other their SIMD
+// through 32 bytes of LDS, KEEP of them stay and the others leave at once (an ended wave no longer takes part in the workgroup's
+// barriers).  Which stay comes from a per-CU ticket (how many such workgroups have started on this CU; never reset, only its two
+// low bits count), so that the workgroups that share a CU fill its SIMDs evenly:
+//   KEEP 2: the two on SIMDs (2 h, 2 h + 1), h = ticket & 1; their order swaps with ticket & 2 -- the wave pairs' two roles then sit
+//           on every SIMD alike (all producers on two SIMDs and all consumers on the other two: slower than no pinning at all,
+//           profiles/r06/u_sweep_by_pin.txt);
+//   KEEP 3: all but the one on SIMD ticket & 3;      KEEP 1: the one on SIMD ticket & 3.
+// Returns the wave's index among those that stay (0 .. KEEP - 1) or -1: leave.  Contains a workgroup barrier (every thread of
+// the workgroup must call it; writes of the caller in front of it are visible behind it) and a second one if `reuse`: the caller
+// is about to overwrite `ids`.  If the four waves are NOT on four different SIMDs, the waves' own indices take the SIMDs' place.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pinned_wave_index(uint32_t *ids, uint32_t *tickets, int tid, int keep, bool reuse) {
+  uint32_t hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const uint32_t simd = (hw >> 4) & 3u;
+  if ((tid & 63) == 0) ids[tid >> 6] = simd;
+  if (tid == 0) ids[4] = atomicAdd(&tickets[((xcc & 7u) << 8) | ((hw >> 8) & 0xFFu)], 1u);  // (HW_ID 15:8: se | sh | cu)
+  __syncthreads();
+  const uint32_t i0 = ids[0], i1 = ids[1], i2 = ids[2], i3 = ids[3], j = ids[4];
+  if (reuse) __syncthreads();
+  const bool perm = ((1u << i0) | (1u << i1) | (1u << i2) | (1u << i3)) == 0xFu;
+  const uint32_t me = perm ? simd : (uint32_t)tid >> 6;
+  if (keep == 2) return (me >> 1) != (j & 1u) ? -1 : (int)((me & 1u) ^ ((j >> 1) & 1u));
+  if (keep == 3) return me == (j & 3u) ? -1 : (int)((me - (j & 3u) - 1u) & 3u);
+  return me == (j & 3u) ? 0 : -1;
+}
+constexpr int kPinTickets = 2048;  // (a __device__ uint32_t array of this size per translation unit that pins)
+
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
 constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the

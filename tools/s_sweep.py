@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--ep", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--streams", default="1048576,524288,262144,131072,65536,32768")
-    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency"))
+    ap.add_argument("--tuning", default="auto", choices=("auto", "throughput", "latency", "latency_single"))
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
