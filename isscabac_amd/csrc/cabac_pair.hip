@@ -29,6 +29,8 @@
 //   [9472, 10496)   B's output staging, 16 bytes per lane
 //   [10496, 19712)  the ring: per slot 4 x 1 KiB of rows (word g of lane l at g * 1024 + 16 l: both the ds_write_b128 of A
 //                   and the ds_read_b128 of B are conflict-free) + 512 bytes of flag bits (8 bytes per lane)
+//   [19712, 19744)  the words through which the FOUR waves a workgroup starts with tell each other their SIMD; two of them stay,
+//                   on the SIMDs a per-CU ticket names (cabac_wave.h: pinned_wave_index), the other two leave at once
 #include "cabac_wave.h"
 
 namespace isscabac {
