@@ -107,11 +107,11 @@ struct EncLatPipe {
 #undef ISSCABAC_LAT_AT1
     }
     asm volatile("v_lshlrev_b16_e32 %1, 2, %2\n\t"  // (full rate; the 32-bit shift is half rate: cabac_lane.h shl16)
-                 "ds_read_b64 %0, %1 offset:768"
+                 "ds_read_b64 %0, %1"
                  : "=&v"(ent), "=&v"(t)
                  : "v"(q)
                  : "memory");
-    static_assert(kTabRowOff == 768, "the offset in the assembly above");
+    static_assert(kTabRowOff == 0, "the (absent) offset in the assembly above");
     if (J > 0) asm volatile("ds_write_b8 %0, %1" : : "v"(at_prev), "v"(nx) : "memory");
     if (J < 15)
       asm volatile("ds_read_u8 %0, %2\n\t"
@@ -177,10 +177,6 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-  if (tid < 64) {
-    tab[tid] = c_lps_rows[tid];
-    tab[kTabBinOff / 4 + tid] = c_next.eb[tid];
-  }
   for (int ps = tid; ps < 128; ps += blockDim.x) {  // packed state ps = q >> 1: its row, its successors by bin
     const uint32_t sb = c_next.eb[ps >> 1] >> (16 * (ps & 1));
     // state 63 is no context's state: its entries are the all-zero ones bypass lanes look up (enc_bin_mixed_acc)
@@ -383,8 +379,8 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             }
           }
         } else {
-          // fixed-probability bins, contexts >= 128 or streams that end inside this chunk.  The byte-table
-          // bin step works under any exec mask, so every lane simply takes its own branch: context-coded bin, bypass bin,
+          // fixed-probability bins, contexts >= 128 or streams that end inside this chunk.  The single-lookup
+          // bin step (enc_bin_at_row) works under any exec mask, so every lane simply takes its own branch: context-coded bin, bypass bin,
           // or nothing once its stream is over (all sides run when a wave mixes them: ~29 VALU per bin against ~37 for
           // one combined, select-based step).
 #pragma unroll
@@ -394,10 +390,11 @@ __global__ void __launch_bounds__(256, 4) k_encode(EncArgs a) {
             if (full || i0 + k < n) {
               const uint32_t cb = byte_of(wc, k);
               if (is_ctx_byte<CM>(cb, ctx_lim)) {
-                if ((k & 3) == 0) enc_bin_at_mem(e, BinOfWord<0>{w2, w1, 0u}, stx.addr_of(z, 0), stx);
-                else if ((k & 3) == 1) enc_bin_at_mem(e, BinOfWord<1>{w2, w1, 0u}, stx.addr_of(z, 1), stx);
-                else if ((k & 3) == 2) enc_bin_at_mem(e, BinOfWord<2>{w2, w1, 0u}, stx.addr_of(z, 2), stx);
-                else enc_bin_at_mem(e, BinOfWord<3>{w2, w1, 0u}, stx.addr_of(z, 3), stx);
+                const uint32_t w8 = w1 << 3;
+                if ((k & 3) == 0) enc_bin_at_row(e, BinOfWord<0>{w2, w1, w8}, stx.addr_of(z, 0), stx);
+                else if ((k & 3) == 1) enc_bin_at_row(e, BinOfWord<1>{w2, w1, w8}, stx.addr_of(z, 1), stx);
+                else if ((k & 3) == 2) enc_bin_at_row(e, BinOfWord<2>{w2, w1, w8}, stx.addr_of(z, 2), stx);
+                else enc_bin_at_row(e, BinOfWord<3>{w2, w1, w8}, stx.addr_of(z, 3), stx);
               } else if (cb == kBypass || cb == kProbBase + 50u) {
                 enc_bin_ep(e, (w1 >> (8 * (k & 3))) & 1u);
               } else if (is_prob_ctx_byte<CM>(cb) && prob_valid(cb - kProbBase)) {

@@ -307,6 +307,24 @@ CABAC_HD void enc_bin_at(EncCore &e, Bin bin, Addr at, States &st) {
 // The same step for a States policy whose tables are byte tables in memory: lps_mem(q, range) -> rangeTabLps entry,
 // next_mem(q | bin) -> successor state (Bin::or_q(q) = q | bin, the bin at bit 0).  Both lookups need one address
 // instruction and no extraction, and the state update waits neither for the decision nor for the range arithmetic.
+// ... and on the single-lookup entries (enc_bin_row_acc's: entry_mem(q) -> row | successors by bin | flags), `low` updated at once:
+// k_encode's step for chunks it codes lane by lane (fixed-probability bins, ragged ends) -- with it the kernel's only table is the
+// 1 KiB of entries.  Same results as enc_bin_at_mem.
+template <class States, class Addr, class Bin>
+CABAC_HD void enc_bin_at_row(EncCore &e, Bin bin, Addr at, States &st) {
+  const uint32_t q = st.load_at(at);
+  const uint64_t ent = st.entry_mem(q);
+  const uint32_t t = bin.next_of((uint32_t)(ent >> 32));
+  st.store_at(at, t);
+  const uint32_t m = bin.lps_mask(q, t);  // ~0: bin != mps
+  const uint32_t lps = lps_of((uint32_t)ent, e.range);
+  const uint32_t rmps = e.range - lps;
+  const uint32_t r = select_mask(m, lps, rmps);
+  const uint32_t n = clz32(r) - 23u;
+  e.low = (e.low + (rmps & m)) << n;
+  e.range = r << n;
+  e.W += (int32_t)n;
+}
 template <class States, class Addr, class Bin>
 CABAC_HD void enc_bin_at_mem(EncCore &e, Bin bin, Addr at, States &st) {
   const uint32_t q = st.load_at(at);

@@ -117,11 +117,11 @@ constexpr int kPinTickets = 2048;  // (a __device__ uint32_t array of this size 
 
 constexpr int enc_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_ENC_WPB : 1; }
 constexpr int dec_waves_per_block(int cm) { return cm == 1 ? ISSCABAC_DEC_WPB : 1; }
-constexpr int kTabBytes = 1792;  // [0,256) rangeTabLps rows, [256,512) successor bytes by (packed state, bin) -- the
-                                 // encoder's --, [512,768) by (packed state, path) -- the decoder's --, [768,1792) the
-                                 // 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc / dec_bin_row):
-                                 // by packed state, the state's row and its two successors (by bin / by path)
-constexpr int kTabBinOff = 256, kTabPathOff = 512, kTabRowOff = 768;
+constexpr int kTabBytes = 1024;  // k_encode's tables: the 8-byte entries of the single-lookup steps (cabac_lane.h: enc_bin_row_acc,
+                                 // enc_bin_at_row) by packed state -- the state's row, its two successors by bin, two flag bytes.
+                                 // (Until round 6 two byte tables stood in front of them, 768 bytes, for the lane-by-lane step;
+                                 // without them a CU holds a tenth wave of a 190-context batch.)
+constexpr int kTabRowOff = 0;
 
 // ------------------------------------------------------------------------------------------------
 // small wave helpers
@@ -500,18 +500,6 @@ struct LdsStates {
   __device__ __forceinline__ void store(uint32_t c, uint32_t p) const { *addr(c) = (uint8_t)p; }
   // (LDS addresses as integers: the kernels' dynamic LDS starts at 0 -- they have no static __shared__, which the engine
   // checks at start-up -- so a table's offset folds into the instruction and q itself is the address)
-  // the rangeTabLps rows at LDS 0 are a [state][column] byte table
-  __device__ __forceinline__ uint32_t lps_mem(uint32_t q, uint32_t range) const {
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)((q & 0xFCu) | ((range >> 6) & 3u)));
-  }
-  // successor bytes by [packed state][path], path 0 = LPS, 1 = MPS
-  __device__ __forceinline__ uint32_t path_index(uint32_t q) const { return kTabPathOff + q; }  // = the LDS address
-  __device__ __forceinline__ uint32_t next_path_mem(uint32_t addr) const {
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)addr);
-  }
-  __device__ __forceinline__ uint32_t next_mem(uint32_t q_or_bin) const {
-    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)(kTabBinOff + q_or_bin));
-  }
   // the single-lookup steps' 8-byte entry by packed state: (q >> 1) * 8 = q << 2
   // (the address as a 16-bit shift: full rate, cabac_lane.h: shl16; a 24-bit multiply is half rate like the 32-bit shift)
   __device__ __forceinline__ uint64_t entry_mem(uint32_t q) const {

@@ -186,7 +186,10 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
   //     each bin on the single-lookup step (enc_bin_row_acc)
   const bool wordacc = flush_every == 18;
   if (wordacc) flush_every = 17;
-  const bool memtab = flush_every == 17;  // ... with the kernel's byte-table bin step (enc_bin_at_mem)
+  // 22: ... with k_encode's lane-by-lane step on the single-lookup entries (enc_bin_at_row)
+  const bool atrow = flush_every == 22;
+  if (atrow) flush_every = 16;
+  const bool memtab = flush_every == 17;  // ... with the byte-table bin step (enc_bin_at_mem: the symbol kernels')
   if (memtab) flush_every = 16;
   const bool digits16 = flush_every == 16;  // the batch kernel's output path: 16-bit digits, checked every 4 bins
   if (digits16) flush_every = 4;
@@ -250,6 +253,7 @@ long lane_encode_stream(const uint8_t *bins, const uint8_t *ctx, uint32_t n, con
     else if (any) enc_bin_any(e, (uint32_t)bins[i] << 1, ctx[i], st);
     else if (ctx[i] == kBypass) enc_bin_ep(e, bins[i]);
     else if (memtab) enc_bin_at_mem(e, HostBin{bins[i]}, st.addr(ctx[i]), st);
+    else if (atrow) enc_bin_at_row(e, HostBin{bins[i]}, st.addr(ctx[i]), st);
     else enc_bin(e, ((uint32_t)bins[i] << 1) | 0xA5A5A5A1u, ctx[i], st);  // only bit 1 may matter
     if (e.W > mw) mw = e.W;
     if ((i + 1) % (uint32_t)flush_every == 0) {

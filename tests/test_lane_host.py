@@ -93,13 +93,13 @@ def lane_decode_out(L, payload, ctx, init, lat=0, pad_front=0, pad_back=0, fill=
     return bins[:ctx.size], int(st), fin[:init.size], list(cnt)
 
 
-@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 16, 17, 18, 19, 20, 21])
+@pytest.mark.parametrize("flush_every", [1, 2, 4, -4, 16, 17, 18, 19, 20, 21, 22])
 def test_encode_golden(lane, golden, flush_every):
     for s in golden["streams"]:
         out, fin, mw = lane_encode(lane, s["bins_a"], s["ctx_a"], s["ctx_init_a"], flush_every)
         assert out.tobytes() == s["payload_a"].tobytes(), s["name"]
         assert fin.tobytes() == s["ctx_final_a"].tobytes(), s["name"]
-        assert mw <= (62 if flush_every in (16, 17, 18, 19, 20, 21) else 20 + 6 * min(abs(flush_every), 4) + 1)
+        assert mw <= (62 if flush_every in (16, 17, 18, 19, 20, 21, 22) else 20 + 6 * min(abs(flush_every), 4) + 1)
 
 
 @pytest.mark.parametrize("pads", [(0, 0, 4), (3, 0, 4), (1, 40, 4), (2, 5, 4), (7, 3, -4), (6, 2, 2), (1, 7, -2), (2, 6, 3), (3, 2, 5), (1, 4, 6)])
@@ -193,7 +193,7 @@ def test_fuzz_vs_oracle(lane, oracle):
         skew = rng.random(Cn + 1) ** (1 + it % 4)
         bins = (rng.random(n) < skew[np.where(ctx == 0xFF, Cn, ctx)]).astype(np.uint8)
         want, _bits, want_fin = oracle.encode_stream(bins, ctx, init, want_final=True)
-        got, fin, _ = lane_encode(lane, bins, ctx, init, (4, 16, 17, 18, 19, 20, 21)[it % 7])
+        got, fin, _ = lane_encode(lane, bins, ctx, init, (4, 16, 17, 18, 19, 20, 21, 22)[it % 8])
         assert got.tobytes() == want.tobytes()
         assert fin.tobytes() == want_fin.tobytes()
         dec, st, dfin, cnt = lane_decode(lane, want, ctx, init, pad_front=int(rng.integers(0, 9)),
@@ -425,7 +425,7 @@ def test_fixed_probability_bins_match_the_reference(lane):
     doc = json.load(open(os.path.join(ROOT, "tests", "golden", "cabac_golden_f4.json")))
     for s in doc["streams"]:
         bins, ctx, init = unbits(s["bins"], s["n"]), unhex(s["ctx"]), unhex(s["ctx_init"])
-        for mode in (1, 4, 16, 17, 18, 19, 20, 21):
+        for mode in (1, 4, 16, 17, 18, 19, 20, 21, 22):
             got, fin, _ = lane_encode(lane, bins, ctx, init, mode)
             assert got.tobytes().hex() == s["payload"] and fin.tobytes().hex() == s["ctx_final"], (s["name"], mode)
         for group in (4, 2, 3, 5, 6):
