@@ -72,7 +72,7 @@ def build_lib(force=False, verbose=False):
 
 
 def build_variant(tag, defines=(), patches=()):
-    """The library with extra -D flags (the ten tunables of DESIGN.md) and / or patches applied to a scratch copy of the sources
+    """The library with extra -D flags (the tunables of DESIGN.md) and / or patches applied to a scratch copy of the sources
     -> tools/ab/variant_<tag>.so, for same-box A/B runs (tools/ab_bench.py).  patches: files of tools/ab_patches/ (`patch -p1`
     against a tree that holds csrc/): timing-only builds -- no input loads, no output stores, ... -- live there, not behind
     switches in the shipped sources."""

@@ -914,10 +914,7 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_apply(const uint32_t *len
 // ------------------------------------------------------------------------------------------------
 // slots -> tight payload: 16 lanes per stream
 // ------------------------------------------------------------------------------------------------
-#ifndef ISSCABAC_GATHER_LPS
-#define ISSCABAC_GATHER_LPS 16  // lanes per stream
-#endif
-constexpr uint32_t kGatherLps = ISSCABAC_GATHER_LPS;
+constexpr uint32_t kGatherLps = 16;  // lanes per stream (k_gather_scan's block of 16 streams is built on it)
 // one stream's bytes from its slot to its place in the payload, by the kGatherLps lanes li = 0 .. kGatherLps - 1
 __device__ __forceinline__ void gather_stream(const uint8_t *slots, uint64_t slot_stride, uint64_t s, uint32_t li, uint32_t len,
                                               uint64_t off, uint8_t *payload, uint64_t cap) {
